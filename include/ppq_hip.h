@@ -1,0 +1,204 @@
+/*
+ * ppq_hip.h -- C ABI of libppq_hip.so: MI355X (gfx950) kernels for PPQ's quantization-simulation
+ * hot path.  This is the drop-in boundary: every entry point replaces one function of the
+ * reference's pybind module `PPQ_Cuda_Impls` (ppq/csrc/export.cc:8-34), reached in the reference
+ * through `ppq.core.ffi.CUDA.*` (ppq/core/ffi.py:56-350).  Plain pointers and sizes only; no torch
+ * types.  The Python binding that presents the pybind names lives in ppq_amd/ffi.py; the stub a
+ * PPQ maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - all tensor pointers are DEVICE pointers to contiguous fp32 (histograms: int32) unless a
+ *     parameter is documented as host memory;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only
+ *     enqueues work on that stream and returns -- no call synchronises the device;
+ *   - outputs are never aliased with inputs by the library (the reference allocates a fresh
+ *     tensor, linear.cu:111); in-place use (out == x) is nevertheless safe for the elementwise ops;
+ *   - return value: PPQHIP_OK (0) or a negative ppqhip_status; ppqhip_last_error() returns a
+ *     thread-local message.  PPQHIP_ERR_INVALID_VALUE corresponds to the reference's
+ *     InvalidValueException (common.cuh:41-48: empty tensor, numel > 0x7fffffff, bad histogram
+ *     shape); dtype errors (ValueTypeException, common.cuh:32-39) cannot occur behind a typed C
+ *     ABI and are raised by the Python binding instead;
+ *   - `rounding` uses the values of ppq.core.RoundingPolicy (quant.py:123-142) /
+ *     common.cuh:16-23: 0 HALF_EVEN, 1 HALF_UP, 2 HALF_DOWN, 3 HALF_TOWARDS_ZERO,
+ *     4 HALF_FAR_FORM_ZERO, 5 TO_NEAR_INT, 6 UP, 7 DOWN;
+ *   - per-channel ops address a contiguous tensor as [outer, num_channel, elem_per_channel]:
+ *     channel(i) = (i / elem_per_channel) % num_channel (linear.cu:146, floating.cu:94).
+ */
+#ifndef PPQ_HIP_H_
+#define PPQ_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PPQHIP_OK = 0,
+    PPQHIP_ERR_INVALID_VALUE = -1, /* InvalidValueException, common.cuh:41-48 */
+    PPQHIP_ERR_UNSUPPORTED = -2,   /* parameter combination the kernels do not implement */
+    PPQHIP_ERR_HIP = -3            /* a HIP runtime call failed (launch error, bad pointer ...) */
+} ppqhip_status;
+
+/* library / device introspection ------------------------------------------------------------- */
+const char* ppqhip_last_error(void);
+int ppqhip_version(void);                 /* ABI version, bumped on incompatible change */
+int ppqhip_device_arch(char* buf, int n); /* gcnArchName of the current device, e.g. "gfx950:..." */
+
+/* linear (integer) fake quant ---------------------------------------------------------------- */
+/* replaces QuantizeTensor_LT, ppq/csrc/cuda/linear.cu:88-130 (CUDA.LinearQuantize_T ffi.py:78-90).
+ * out[i] = (clip(round(x[i] / s) + round(o), qmin, qmax) - round(o)) * s ; scale/offset: 1 elem. */
+int ppqhip_fq_linear_t(const float* x, const float* scale, const float* offset, float* out,
+                       int64_t n, int clip_min, int clip_max, int rounding, void* stream);
+
+/* replaces QuantizeTensor_LC, linear.cu:188-233 (CUDA.LinearQuantize_C ffi.py:92-103). */
+int ppqhip_fq_linear_c(const float* x, const float* scale, const float* offset, float* out,
+                       int64_t n, int64_t num_channel, int64_t elem_per_channel,
+                       int clip_min, int clip_max, int rounding, void* stream);
+
+/* replaces QuantizeTensor_LT_B, linear.cu:284-324 (CUDA.LinearQuantize_T_B ffi.py:105-118).
+ * grad_s (1 elem) is OVERWRITTEN with sum(...) * rsqrt(n * (clip_max - clip_min)). */
+int ppqhip_fq_linear_t_bwd(const float* x, const float* scale, const float* offset,
+                           const float* grad_y, float* grad_x, float* grad_s, int64_t n,
+                           int clip_min, int clip_max, int rounding, void* stream);
+
+/* replaces QuantizeTensor_LC_B, linear.cu:383-433 (CUDA.LinearQuantize_C_B ffi.py:120-134).
+ * grad_s (num_channel elems) is OVERWRITTEN; factor rsqrt(n * clip_max) (linear.cu:402). */
+int ppqhip_fq_linear_c_bwd(const float* x, const float* scale, const float* offset,
+                           const float* grad_y, float* grad_x, float* grad_s, int64_t n,
+                           int64_t num_channel, int64_t elem_per_channel,
+                           int clip_min, int clip_max, int rounding, void* stream);
+
+/* low-precision float (FP8 E4M3 / E5M2 / generic E,M) fake quant ------------------------------ */
+/* replaces QuantizeTensor_FT, floating.cu:57-75 (CUDA.FloatingQuantize_T ffi.py:272-288);
+ * scalar algorithm QuantizeScalarFloating common.cuh:154-226. */
+int ppqhip_fq_float_t(const float* x, const float* scale, const float* offset, float* out,
+                      int64_t n, int exponent, int mantissa, float clip_min, float clip_max,
+                      int rounding, void* stream);
+
+/* replaces QuantizeTensor_FC, floating.cu:102-131 (CUDA.FloatingQuantize_C ffi.py:290-306). */
+int ppqhip_fq_float_c(const float* x, const float* scale, const float* offset, float* out,
+                      int64_t n, int64_t num_channel, int64_t elem_per_channel,
+                      int exponent, int mantissa, float clip_min, float clip_max,
+                      int rounding, void* stream);
+
+/* replace QuantizeTensor_FT_B / _FC_B, floating.cu:186-221 / :286-331 (ffi.py:308-344; no
+ * Python caller in the reference).  grad_s is OVERWRITTEN.  For the per-tensor form pass
+ * num_channel = 1, elem_per_channel = n. */
+int ppqhip_fq_float_c_bwd(const float* x, const float* scale, const float* offset,
+                          const float* grad_y, float* grad_x, float* grad_s, int64_t n,
+                          int64_t num_channel, int64_t elem_per_channel,
+                          int exponent, int mantissa, float clip_min, float clip_max,
+                          int rounding, void* stream);
+
+/* histograms --------------------------------------------------------------------------------- */
+/* replaces Histogram_T, sort.cu:91-111 (CUDA.Histogram_T ffi.py:136-145).
+ * b = floor(|x| / hist_scale); b > bins-1 is dropped (clip_outliers) or clamped; hist[b] += 1.
+ * ACCUMULATES into the caller's int32 hist[num_bins]. */
+int ppqhip_hist_sym_t(const float* x, int64_t n, float hist_scale, int clip_outliers,
+                      int32_t* hist, int64_t num_bins, void* stream);
+
+/* replaces Histogram_Asymmetric_T, sort.cu:141-165 (CUDA.Histogram_Asymmetric_T ffi.py:147-157).
+ * hist_scale = (max - min) / bins; b = floor((x - min) / hist_scale). */
+int ppqhip_hist_asym_t(const float* x, int64_t n, float min_value, float max_value,
+                       int clip_outliers, int32_t* hist, int64_t num_bins, void* stream);
+
+/* replaces Histogram_C, sort.cu:187-218 (CUDA.Histogram_C ffi.py:159-169); hist is
+ * [num_channel, num_bins]. */
+int ppqhip_hist_sym_c(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
+                      float hist_scale, int clip_outliers, int32_t* hist, int64_t num_bins,
+                      void* stream);
+
+/* order statistics ---------------------------------------------------------------------------- */
+/* replaces Quantile_T, sort.cu:42-59 (CUDA.Quantile ffi.py:171-176): dest[0] = sorted[rn(n*q)],
+ * dest[1] = sorted[rn(n*(1-q))], indices clamped to [0, n-1].  Implemented as a radix select, not
+ * a sort.  `workspace` is device scratch of ppqhip_quantile_workspace_bytes(n) bytes. */
+int64_t ppqhip_quantile_workspace_bytes(int64_t n);
+int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, void* workspace,
+                      void* stream);
+
+/* replaces Isotone_T, sort.cu:61-73: dest = [max, 2nd max, min, 2nd min] (with multiplicity).
+ * `workspace`: device scratch of ppqhip_quantile_workspace_bytes(n) bytes (shared sizing). */
+int ppqhip_isotone_t(const float* x, int64_t n, float* dest, void* workspace, void* stream);
+
+/* range reductions (what TorchMinMaxObserver.observe computes with torch.min/torch.max,
+ * ppq/quantization/observer/range.py:86-98; no native twin in the reference) ---------------- */
+/* minmax[0] = min(minmax[0], min x), minmax[1] = max(minmax[1], max x): ACCUMULATES, so the
+ * caller seeds minmax with {+inf, -inf}.  NaNs are ignored. */
+int ppqhip_minmax_t(const float* x, int64_t n, float* minmax, void* stream);
+
+/* per channel: mins[c], maxs[c] ACCUMULATE (seed with +inf / -inf). */
+int ppqhip_minmax_c(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
+                    float* mins, float* maxs, void* stream);
+
+/* clipping searches -------------------------------------------------------------------------- */
+/* replaces compute_mse_loss, ppq/csrc/cpu/hist_mse.cc:3-28 (CUDA.compute_mse_loss ffi.py:263-270).
+ * HOST function on a HOST histogram, float accumulation exactly as the reference. */
+float ppqhip_mse_loss_host(const int64_t* hist, int64_t num_bins, int start, int step, int end);
+
+/* Device-side restatement of TorchMSEObserver.hist_to_scale_offset's candidate sweep
+ * (observer/range.py:456-520) for `num_hist` histograms at once.  For histogram h:
+ *   hist + h*num_bins : int32[num_bins];  hist_scale[h], min_value[h] : float64 (device)
+ * Candidate k's loss is accumulated sequentially in float exactly like hist_mse.cc; the first
+ * minimum wins.  Writes best[h*4 + {0,1,2,3}] = {start, end, step, candidate index} (int32).
+ * `symmetrical` selects the start==0 sweep (range.py:499-509).  `workspace`: device scratch of
+ * ppqhip_mse_search_workspace_bytes(num_hist) bytes. */
+int64_t ppqhip_mse_search_workspace_bytes(int64_t num_hist);
+int ppqhip_mse_search(const int32_t* hist, int64_t num_hist, int64_t num_bins,
+                      const double* hist_scale, const double* min_value,
+                      int quant_min, int quant_max, int symmetrical, int32_t* best,
+                      void* workspace, void* stream);
+
+/* Device-side KL candidate losses of TorchHistObserver.hist_to_scale_offset
+ * (observer/range.py:190-282, torch_KL_divergence measure/statistic.py:3-12) for `num_hist`
+ * histograms at once.  losses is float64 [num_hist, num_candidates] with
+ * num_candidates = ppqhip_kl_num_candidates(num_bins, num_of_bits); candidate j has
+ * bin_range = (j + 1) * 2^(num_of_bits-1).  The caller picks the arg-min (the reference uses a
+ * stable sort, range.py:271). */
+int64_t ppqhip_kl_num_candidates(int64_t num_bins, int num_of_bits);
+int ppqhip_kl_losses(const int32_t* hist, int64_t num_hist, int64_t num_bins, int num_of_bits,
+                     double* losses, void* stream);
+
+/* training helpers (exported by the reference, no caller in ppq/) ------------------------------ */
+/* replace TensorClip_T / TensorClip_C, train.cu:84-113 / :51-82. */
+int ppqhip_tensor_clip_t(const float* value, const float* reference, const float* limit,
+                         float* out, int64_t n, void* stream);
+int ppqhip_tensor_clip_c(const float* value, const float* reference, const float* limit,
+                         float* out, int64_t n, int64_t num_channel, int64_t elem_per_channel,
+                         void* stream);
+/* replace RoundingLoss_LT / _LC (train.cu:143-175, :242-275): out[0] is OVERWRITTEN.
+ * num_channel = 0 selects the per-tensor form. */
+int ppqhip_rounding_loss(const float* x, const float* scale, const float* offset, float* out,
+                         int64_t n, int64_t num_channel, int64_t elem_per_channel,
+                         int clip_min, int clip_max, int rounding, void* stream);
+/* replace RoundingLoss_LT_B / _LC_B (train.cu:196-214, :311-338); dy is one device float. */
+int ppqhip_rounding_loss_bwd(const float* x, const float* dy, const float* scale,
+                             const float* offset, float* dx, int64_t n, int64_t num_channel,
+                             int64_t elem_per_channel, int clip_min, int clip_max, int rounding,
+                             void* stream);
+
+/* fused calibration step (MI355X-native addition; one HBM read serves two consumers) ---------- */
+/* out = fake-quant(x) exactly as ppqhip_fq_linear_t, and hist += symmetric histogram of the
+ * ORIGINAL x exactly as ppqhip_hist_sym_t. */
+int ppqhip_fq_linear_t_hist_sym(const float* x, const float* scale, const float* offset,
+                                float* out, int64_t n, int clip_min, int clip_max, int rounding,
+                                float hist_scale, int clip_outliers, int32_t* hist,
+                                int64_t num_bins, void* stream);
+
+/* profiling aid used by bench.py: when enabled, every kernel launch made through this library
+ * on this thread is bracketed by hipEvents on its own stream; ppqhip_prof_collect() synchronises
+ * those events and returns, per kernel id, launches / total ms / total algorithmic bytes. */
+#define PPQHIP_PROF_MAX_KERNELS 32
+typedef struct {
+    char name[48];
+    int64_t launches;
+    double total_ms;
+    double total_bytes;
+} ppqhip_prof_entry;
+int ppqhip_prof_enable(int on);
+int ppqhip_prof_collect(ppqhip_prof_entry* entries, int max_entries); /* returns #entries */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PPQ_HIP_H_ */

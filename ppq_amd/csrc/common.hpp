@@ -1,0 +1,171 @@
+// common.hpp -- shared device helpers + host launch plumbing for libppq_hip.so (gfx950 only).
+//
+// Arithmetic contract (bit-exactness against the reference kernels, ppq/csrc/cuda/common.cuh):
+//   * every translation unit is compiled with -ffp-contract=off: no FMA contraction anywhere;
+//   * `a / b` on float is the correctly rounded IEEE quotient (hipcc's default
+//     -fhip-fp32-correctly-rounded-divide-sqrt: v_div_scale / v_div_fmas / v_div_fixup);
+//     the reference insists on true division too ("never do (1 / s)", linear.cu:73-74);
+//   * float -> int32 is v_cvt_i32_f32: saturating, NaN -> 0 -- the same contract as the
+//     cvt.rzi.s32.f32 the reference kernels compile to;
+//   * round(x/s) + offset is a SATURATING int32 add (v_add_i32 clamp).  The reference adds with
+//     wrap-around (UB in C++); both agree whenever the reference's add does not overflow, and
+//     the saturating form agrees with the reference's PyTorch path in the overflow case.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ppq_hip.h"
+
+namespace ppqhip {
+
+constexpr int kWave = 64;            // wavefront width on gfx950
+constexpr int kNumCU = 256;          // MI355X
+constexpr int kBlock = 256;          // default workgroup: 4 waves, one per SIMD
+
+enum Rounding : int {
+    ROUND_HALF_EVEN = 0, ROUND_HALF_UP = 1, ROUND_HALF_DOWN = 2, ROUND_HALF_TOWARDS_ZERO = 3,
+    ROUND_HALF_FAR_FORM_ZERO = 4, ROUND_TO_NEAR_INT = 5, ROUND_UP = 6, ROUND_DOWN = 7
+};
+
+// ---- host side ---------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int check_hip(hipError_t e, const char* what);
+
+// kernel ids for the profiling aid (ppqhip_prof_*)
+enum KernelId : int {
+    K_FQ_LINEAR_T = 0, K_FQ_LINEAR_C, K_FQ_LINEAR_T_BWD, K_FQ_LINEAR_C_BWD, K_FQ_FLOAT_T, K_FQ_FLOAT_C,
+    K_FQ_FLOAT_BWD, K_HIST_SYM_T, K_HIST_ASYM_T, K_HIST_SYM_C, K_QUANTILE, K_ISOTONE, K_MINMAX_T,
+    K_MINMAX_C, K_MSE_SEARCH, K_KL_LOSSES, K_TENSOR_CLIP, K_ROUNDING_LOSS, K_FQ_HIST_FUSED, K_NUM
+};
+extern const char* const kKernelNames[K_NUM];
+
+// RAII bracket around one logical kernel launch (possibly several device kernels): when
+// profiling is on it records a hipEvent pair on `stream` and books `bytes` algorithmic bytes.
+struct LaunchScope {
+    LaunchScope(KernelId id, double bytes, hipStream_t stream);
+    ~LaunchScope();
+    int slot;
+    hipStream_t stream;
+};
+
+int finish_launch(const char* what);   // hipGetLastError -> status
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// division of a 31-bit numerator by an invariant divisor d >= 1 (Granlund-Montgomery):
+// q = (mulhi(n, m) + n) >> l  with l = ceil(log2 d), m = floor(2^32 (2^l - d) / d) + 1.
+struct FastDiv {
+    uint32_t d, m, l;
+};
+inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f; f.d = d; f.l = 0;
+    while ((1ull << f.l) < d) f.l++;
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << f.l) - d)) / d + 1);
+    return f;
+}
+
+// ---- device side ---------------------------------------------------------------------------
+#if defined(__HIPCC__)
+
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
+    return (__umulhi(n, f.m) + n) >> f.l;
+}
+
+// v_cvt_i32_f32: round-toward-zero, saturating, NaN -> 0 (the value passed in is already integral)
+__device__ __forceinline__ int f2i_sat(float v) {
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+// v_cvt_i32_f64: same contract for double
+__device__ __forceinline__ int d2i_sat(double v) {
+    int r;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+
+__device__ __forceinline__ int add_sat(int a, int b) { return __builtin_elementwise_add_sat(a, b); }
+
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { return v > hi ? hi : (v < lo ? lo : v); }
+
+// _round2int, common.cuh:88-114.  HALF_UP / HALF_DOWN evaluate `value + .5` in double exactly as
+// the reference does (the literal .5 is a double there).
+template <int R>
+__device__ __forceinline__ int round2int_t(float value) {
+    if constexpr (R == ROUND_HALF_EVEN) return f2i_sat(__builtin_rintf(value));
+    else if constexpr (R == ROUND_HALF_UP) return d2i_sat(__builtin_floor((double)value + .5));
+    else if constexpr (R == ROUND_HALF_DOWN) return d2i_sat(__builtin_ceil((double)value - .5));
+    else if constexpr (R == ROUND_HALF_TOWARDS_ZERO)
+        return value > 0 ? round2int_t<ROUND_HALF_DOWN>(value) : round2int_t<ROUND_HALF_UP>(value);
+    else if constexpr (R == ROUND_HALF_FAR_FORM_ZERO)
+        return value > 0 ? round2int_t<ROUND_HALF_UP>(value) : round2int_t<ROUND_HALF_DOWN>(value);
+    else if constexpr (R == ROUND_UP) return f2i_sat(__builtin_ceilf(value));
+    else if constexpr (R == ROUND_DOWN) return f2i_sat(__builtin_floorf(value));
+    else return f2i_sat(__builtin_roundf(value));
+}
+
+__device__ __forceinline__ int round2int(float value, int rounding) {
+    switch (rounding) {
+        case ROUND_HALF_EVEN: return round2int_t<ROUND_HALF_EVEN>(value);
+        case ROUND_HALF_UP: return round2int_t<ROUND_HALF_UP>(value);
+        case ROUND_HALF_DOWN: return round2int_t<ROUND_HALF_DOWN>(value);
+        case ROUND_HALF_TOWARDS_ZERO: return round2int_t<ROUND_HALF_TOWARDS_ZERO>(value);
+        case ROUND_HALF_FAR_FORM_ZERO: return round2int_t<ROUND_HALF_FAR_FORM_ZERO>(value);
+        case ROUND_UP: return round2int_t<ROUND_UP>(value);
+        case ROUND_DOWN: return round2int_t<ROUND_DOWN>(value);
+        default: return round2int_t<ROUND_TO_NEAR_INT>(value);
+    }
+}
+
+// `int o = std::round(offset)`: linear.cu:52,76,149,175
+__device__ __forceinline__ int round_offset(float o) { return f2i_sat(__builtin_roundf(o)); }
+
+// QuantizeScalar + DequantizeScalar, common.cuh:116-147 / linear.cu:79-83
+template <int R>
+__device__ __forceinline__ float fq_linear_scalar(float x, float s, int o, int qmin, int qmax, int rounding) {
+    const float qt = x / s;
+    const int r = (R >= 0) ? round2int_t<(R >= 0 ? R : 0)>(qt) : round2int(qt, rounding);
+    const int q = clampi(add_sat(r, o), qmin, qmax);
+    return (float)(q - o) * s;
+}
+
+// wave64 reductions through DPP-backed shuffles
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = fminf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// float atomic min / max on plain float storage (no NaNs): sign-split integer atomics.
+__device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
+    if (v >= 0) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
+    if (v >= 0) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+#endif  // __HIPCC__
+
+// grid size for a streaming kernel that consumes `work_items` items, `per_block` per block-pass,
+// capped so that the chip holds every block at once (8 x 256-thread blocks per CU).
+inline int stream_grid(int64_t work_items, int64_t per_block, int max_blocks = kNumCU * 8) {
+    int64_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+}  // namespace ppqhip

@@ -1,0 +1,279 @@
+// floating.hip -- low-precision float (FP8 E4M3 / E5M2 / generic E,M) fake-quant for gfx950.
+//
+// Replaces ppq/csrc/cuda/floating.cu; the scalar algorithm restates QuantizeScalarFloating
+// (ppq/csrc/cuda/common.cuh:154-226) bit for bit, including its quirk that an exact mantissa tie
+// under ROUND_HALF_EVEN rounds toward zero (nearbyint(0.5) == 0), which is NOT IEEE / OCP RNE --
+// so the hardware v_cvt_pk_fp8_f32 conversions are deliberately not used here.
+// Same streaming structure as linear.hip (float4 per lane, chip-sized grid-stride launch).
+#include "common.hpp"
+
+namespace ppqhip {
+
+struct FloatFmt {
+    float hi, lo;          // min(clip_max, theoretical_max), max(clip_min, -theoretical_max)
+    float clip_min, clip_max;
+    int exponent_min_p1;   // exponent_min + 1
+    float min_subnormal;
+    int mantissa;
+};
+
+static int make_fmt(int exponent, int mantissa, float clip_min, float clip_max, FloatFmt* f, const char* what) {
+    if (exponent <= 0 || exponent > 8 || mantissa < 0 || mantissa > 23) {
+        set_error("%s: unsupported float format E%dM%d", what, exponent, mantissa);
+        return PPQHIP_ERR_INVALID_VALUE;
+    }
+    const int sub_shift = (1 << (exponent - 1)) + mantissa - 2;
+    if (sub_shift < 0 || sub_shift > 30) {
+        // `1 << sub_shift` overflows int in the reference (common.cuh:210): undefined there.
+        set_error("%s: E%dM%d needs 1 << %d, which the reference cannot represent", what, exponent, mantissa,
+                  sub_shift);
+        return PPQHIP_ERR_UNSUPPORTED;
+    }
+    const int exponent_min = -(1 << (exponent - 1)) + 1;
+    const int exponent_max = (1 << (exponent - 1));
+    union { float v; uint32_t d; } h;
+    h.d = (uint32_t)((exponent_max + 127) << 23) + (uint32_t)(~(0x007FFFFF >> mantissa) & 0x007FFFFF);
+    const float theo = h.v;
+    f->hi = clip_max < theo ? clip_max : theo;
+    f->lo = clip_min > -theo ? clip_min : -theo;
+    f->clip_min = clip_min; f->clip_max = clip_max;
+    f->exponent_min_p1 = exponent_min + 1;
+    f->min_subnormal = 1.0f / (float)(1 << sub_shift);
+    f->mantissa = mantissa;
+    return PPQHIP_OK;
+}
+
+// QuantizeScalarFloating, common.cuh:154-226 (the format-dependent constants are hoisted into fmt)
+template <int R>
+__device__ __forceinline__ float quant_float_scalar(float value, float scale, const FloatFmt& fmt, int rounding) {
+    const float u = value / scale;
+    if (u > fmt.hi) return fmt.hi;
+    if (u < fmt.lo) return fmt.lo;
+    const uint32_t bits = __float_as_uint(u);
+    const uint32_t sign = bits & 0x80000000u;
+    const int32_t exp = (int32_t)(bits & 0x7F800000u);
+    const uint32_t man = bits & 0x007FFFFFu;
+    if (((exp >> 23) - 127) < fmt.exponent_min_p1) {
+        const float t = u / fmt.min_subnormal;
+        const int r = (R >= 0) ? round2int_t<(R >= 0 ? R : 0)>(t) : round2int(t, rounding);
+        return (float)r * fmt.min_subnormal;
+    }
+    const float frac = __uint_as_float(((man << fmt.mantissa) & 0x007FFFFFu) + 0x3F800000u) - 1;
+    const uint32_t round_bit = (uint32_t)((R >= 0) ? round2int_t<(R >= 0 ? R : 0)>(frac) : round2int(frac, rounding));
+    const uint32_t m = ((man >> (23 - fmt.mantissa)) + round_bit) << (23 - fmt.mantissa);
+    const float v = __uint_as_float(sign + m + (uint32_t)exp);
+    return v > fmt.clip_max ? fmt.clip_max : (v < fmt.clip_min ? fmt.clip_min : v);
+}
+
+template <int R, int U>
+__global__ __launch_bounds__(kBlock) void fq_float_t_vec_kernel(
+    const float4* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
+    float4* __restrict__ out, uint32_t nvec, const float* __restrict__ xtail, float* __restrict__ otail,
+    int ntail, FloatFmt fmt, int rounding) {
+    const float s = scale[0], o = offset[0];
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride * U) {
+        float4 a[U];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            if (v + k * stride < nvec) a[k] = x[v + k * stride];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            if (v + k * stride < nvec) {
+                float4 r;
+                r.x = (quant_float_scalar<R>(a[k].x, s, fmt, rounding) - o) * s;
+                r.y = (quant_float_scalar<R>(a[k].y, s, fmt, rounding) - o) * s;
+                r.z = (quant_float_scalar<R>(a[k].z, s, fmt, rounding) - o) * s;
+                r.w = (quant_float_scalar<R>(a[k].w, s, fmt, rounding) - o) * s;
+                out[v + k * stride] = r;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail)
+        otail[threadIdx.x] = (quant_float_scalar<R>(xtail[threadIdx.x], s, fmt, rounding) - o) * s;
+}
+
+// generic (scalar) per-tensor / per-channel kernel; num_channel.d == 0 selects per tensor
+template <int R>
+__global__ __launch_bounds__(kBlock) void fq_float_scalar_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
+    float* __restrict__ out, uint32_t n, FastDiv elem_per_channel, FastDiv num_channel, int per_channel,
+    FloatFmt fmt, int rounding) {
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        uint32_t c = 0;
+        if (per_channel) {
+            const uint32_t row = fdiv(i, elem_per_channel);
+            c = row - fdiv(row, num_channel) * num_channel.d;
+        }
+        const float s = scale[c], o = offset[c];
+        out[i] = (quant_float_scalar<R>(x[i], s, fmt, rounding) - o) * s;
+    }
+}
+
+template <int R, int U>
+__global__ __launch_bounds__(kBlock) void fq_float_c_vec_kernel(
+    const float4* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
+    float4* __restrict__ out, uint32_t nvec, FastDiv vec_per_channel, FastDiv num_channel, FloatFmt fmt,
+    int rounding) {
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride * U) {
+        float4 a[U];
+        float s[U], o[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const uint32_t vv = v + k * stride;
+            if (vv < nvec) {
+                a[k] = x[vv];
+                const uint32_t row = fdiv(vv, vec_per_channel);
+                const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
+                s[k] = scale[c];
+                o[k] = offset[c];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const uint32_t vv = v + k * stride;
+            if (vv < nvec) {
+                float4 r;
+                r.x = (quant_float_scalar<R>(a[k].x, s[k], fmt, rounding) - o[k]) * s[k];
+                r.y = (quant_float_scalar<R>(a[k].y, s[k], fmt, rounding) - o[k]) * s[k];
+                r.z = (quant_float_scalar<R>(a[k].z, s[k], fmt, rounding) - o[k]) * s[k];
+                r.w = (quant_float_scalar<R>(a[k].w, s[k], fmt, rounding) - o[k]) * s[k];
+                out[vv] = r;
+            }
+        }
+    }
+}
+
+// QuantizeTensor_FT_B / _FC_B, floating.cu:133-331: STE + scale gradient with +-1 sentinel clip.
+// The reference adds every block-partial divided by sqrtf((float)(n * clip_max)).
+__global__ __launch_bounds__(kBlock) void fq_float_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
+    const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ gs, uint32_t n,
+    FastDiv elem_per_channel, FastDiv num_channel, FloatFmt fmt_wide, float clip_min, float clip_max,
+    float denom, int rounding) {
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t row = fdiv(i, elem_per_channel);
+        const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
+        const float s = scale[c], inv_s = 1 / s, o = offset[c];
+        const float cmin = s * (clip_min - o), cmax = s * (clip_max - o);
+        const float v = x[i], d = dy[i];
+        const float qt = quant_float_scalar<-1>(v, s, fmt_wide, rounding);
+        const float q = (qt - o) * s;
+        float p;
+        if (qt == clip_max + 1) { p = cmax * d * inv_s; gx[i] = 0.f; }
+        else if (qt == clip_min - 1) { p = cmin * d * inv_s; gx[i] = 0.f; }
+        else { p = (q - v) * inv_s * d; gx[i] = d; }
+        // no caller in ppq: one global atomic per element is acceptable here
+        atomicAdd(&gs[c], p / denom);
+    }
+}
+
+static int validate(int64_t n, const char* what) {
+    if (n <= 0) { set_error("%s: tensor is empty", what); return PPQHIP_ERR_INVALID_VALUE; }
+    if (n > 0x7fffffffLL) { set_error("%s: too many elements", what); return PPQHIP_ERR_INVALID_VALUE; }
+    return PPQHIP_OK;
+}
+
+constexpr uint32_t kSmallVec = (uint32_t)kNumCU * 8 * kBlock;
+
+template <int R>
+static void launch_ft(const float* x, const float* scale, const float* offset, float* out, int64_t n,
+                      const FloatFmt& fmt, int rounding, hipStream_t st) {
+    if (aligned16(x) && aligned16(out) && n >= 4) {
+        const uint32_t nvec = (uint32_t)(n >> 2);
+        const int ntail = (int)(n & 3);
+        const float* xt = x + (size_t)nvec * 4;
+        float* ot = out + (size_t)nvec * 4;
+        if (nvec <= kSmallVec)
+            hipLaunchKernelGGL((fq_float_t_vec_kernel<R, 1>), dim3(stream_grid(nvec, kBlock)), dim3(kBlock), 0, st,
+                               (const float4*)x, scale, offset, (float4*)out, nvec, xt, ot, ntail, fmt, rounding);
+        else
+            hipLaunchKernelGGL((fq_float_t_vec_kernel<R, 4>), dim3(stream_grid(nvec, kBlock * 4)), dim3(kBlock), 0,
+                               st, (const float4*)x, scale, offset, (float4*)out, nvec, xt, ot, ntail, fmt,
+                               rounding);
+    } else {
+        hipLaunchKernelGGL((fq_float_scalar_kernel<R>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, x, scale,
+                           offset, out, (uint32_t)n, make_fastdiv(1), make_fastdiv(1), 0, fmt, rounding);
+    }
+}
+
+template <int R>
+static void launch_fc(const float* x, const float* scale, const float* offset, float* out, int64_t n, int64_t C,
+                      int64_t epc, const FloatFmt& fmt, int rounding, hipStream_t st) {
+    if (aligned16(x) && aligned16(out) && epc % 4 == 0) {
+        const uint32_t nvec = (uint32_t)(n >> 2);
+        const FastDiv vpc = make_fastdiv((uint32_t)(epc / 4)), nc = make_fastdiv((uint32_t)C);
+        if (nvec <= kSmallVec)
+            hipLaunchKernelGGL((fq_float_c_vec_kernel<R, 1>), dim3(stream_grid(nvec, kBlock)), dim3(kBlock), 0, st,
+                               (const float4*)x, scale, offset, (float4*)out, nvec, vpc, nc, fmt, rounding);
+        else
+            hipLaunchKernelGGL((fq_float_c_vec_kernel<R, 4>), dim3(stream_grid(nvec, kBlock * 4)), dim3(kBlock), 0,
+                               st, (const float4*)x, scale, offset, (float4*)out, nvec, vpc, nc, fmt, rounding);
+    } else {
+        hipLaunchKernelGGL((fq_float_scalar_kernel<R>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, x, scale,
+                           offset, out, (uint32_t)n, make_fastdiv((uint32_t)epc), make_fastdiv((uint32_t)C), 1, fmt,
+                           rounding);
+    }
+}
+
+}  // namespace ppqhip
+
+using namespace ppqhip;
+
+extern "C" {
+
+int ppqhip_fq_float_t(const float* x, const float* scale, const float* offset, float* out, int64_t n,
+                      int exponent, int mantissa, float clip_min, float clip_max, int rounding,
+                      void* stream) {
+    if (int st = validate(n, "fq_float_t")) return st;
+    FloatFmt fmt;
+    if (int st = make_fmt(exponent, mantissa, clip_min, clip_max, &fmt, "fq_float_t")) return st;
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_FQ_FLOAT_T, 8.0 * (double)n, s);
+    if (rounding == ROUND_HALF_EVEN) launch_ft<ROUND_HALF_EVEN>(x, scale, offset, out, n, fmt, rounding, s);
+    else launch_ft<-1>(x, scale, offset, out, n, fmt, rounding, s);
+    return finish_launch("fq_float_t");
+}
+
+int ppqhip_fq_float_c(const float* x, const float* scale, const float* offset, float* out, int64_t n,
+                      int64_t num_channel, int64_t elem_per_channel, int exponent, int mantissa,
+                      float clip_min, float clip_max, int rounding, void* stream) {
+    if (int st = validate(n, "fq_float_c")) return st;
+    if (num_channel <= 0 || elem_per_channel <= 0 || n % (num_channel * elem_per_channel) != 0) {
+        set_error("fq_float_c: bad channel geometry"); return PPQHIP_ERR_INVALID_VALUE;
+    }
+    FloatFmt fmt;
+    if (int st = make_fmt(exponent, mantissa, clip_min, clip_max, &fmt, "fq_float_c")) return st;
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_FQ_FLOAT_C, 8.0 * (double)n, s);
+    if (rounding == ROUND_HALF_EVEN)
+        launch_fc<ROUND_HALF_EVEN>(x, scale, offset, out, n, num_channel, elem_per_channel, fmt, rounding, s);
+    else launch_fc<-1>(x, scale, offset, out, n, num_channel, elem_per_channel, fmt, rounding, s);
+    return finish_launch("fq_float_c");
+}
+
+int ppqhip_fq_float_c_bwd(const float* x, const float* scale, const float* offset, const float* grad_y,
+                          float* grad_x, float* grad_s, int64_t n, int64_t num_channel,
+                          int64_t elem_per_channel, int exponent, int mantissa, float clip_min,
+                          float clip_max, int rounding, void* stream) {
+    if (int st = validate(n, "fq_float_c_bwd")) return st;
+    if (num_channel <= 0 || elem_per_channel <= 0 || n % (num_channel * elem_per_channel) != 0) {
+        set_error("fq_float_c_bwd: bad channel geometry"); return PPQHIP_ERR_INVALID_VALUE;
+    }
+    FloatFmt fmt;   // the backward quantises against [clip_min - 1, clip_max + 1]: floating.cu:163-164
+    if (int st = make_fmt(exponent, mantissa, clip_min - 1, clip_max + 1, &fmt, "fq_float_c_bwd")) return st;
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_FQ_FLOAT_BWD, 12.0 * (double)n, s);
+    if (int st = check_hip(hipMemsetAsync(grad_s, 0, sizeof(float) * (size_t)num_channel, s), "memset grad_s"))
+        return st;
+    const float denom = sqrtf((float)((float)n * clip_max));
+    hipLaunchKernelGGL(fq_float_bwd_kernel, dim3(stream_grid(n, kBlock * 4, kNumCU * 4)), dim3(kBlock), 0, s, x,
+                       scale, offset, grad_y, grad_x, grad_s, (uint32_t)n, make_fastdiv((uint32_t)elem_per_channel),
+                       make_fastdiv((uint32_t)num_channel), fmt, clip_min, clip_max, denom, rounding);
+    return finish_launch("fq_float_c_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,356 @@
+// linear.hip -- integer fake-quant kernels (forward + LSQ backward) for gfx950.
+//
+// Replaces ppq/csrc/cuda/linear.cu.  Design (not a translation of the CUDA launch shapes):
+//   * HBM-bound streaming: 16 B per lane per access (global_load_dwordx4 / global_store_dwordx4),
+//     one wavefront = 1 KiB per instruction, U independent accesses in flight per lane;
+//   * grids sized to the chip (<= 8 x 256-thread workgroups on each of the 256 CUs) with a
+//     grid-stride loop; small tensors get one float4 per lane so that every CU is busy;
+//   * per-tensor scale / offset live in SGPRs (uniform scalar loads);
+//   * per-channel: the channel of a float4 is found with a multiply-high division by an
+//     invariant (no integer divide in the loop); scale/offset gathers hit L1/L2;
+//   * the tail (n % 4) and unaligned tensors run through the same arithmetic in a scalar kernel,
+//     so results do not depend on the launch shape.
+#include "common.hpp"
+
+namespace ppqhip {
+
+// --------------------------------------------------------------------------- per tensor forward
+template <int R, int U>
+__global__ __launch_bounds__(kBlock) void fq_linear_t_vec_kernel(
+    const float4* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
+    float4* __restrict__ out, uint32_t nvec, const float* __restrict__ xtail, float* __restrict__ otail,
+    int ntail, int qmin, int qmax, int rounding) {
+    const float s = scale[0];
+    const int o = round_offset(offset[0]);
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride * U) {
+        float4 a[U];
+#pragma unroll
+        for (int k = 0; k < U; k++)
+            if (v + k * stride < nvec) a[k] = x[v + k * stride];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            if (v + k * stride < nvec) {
+                float4 r;
+                r.x = fq_linear_scalar<R>(a[k].x, s, o, qmin, qmax, rounding);
+                r.y = fq_linear_scalar<R>(a[k].y, s, o, qmin, qmax, rounding);
+                r.z = fq_linear_scalar<R>(a[k].z, s, o, qmin, qmax, rounding);
+                r.w = fq_linear_scalar<R>(a[k].w, s, o, qmin, qmax, rounding);
+                out[v + k * stride] = r;
+            }
+        }
+    }
+    if (blockIdx.x == 0 && (int)threadIdx.x < ntail)
+        otail[threadIdx.x] = fq_linear_scalar<R>(xtail[threadIdx.x], s, o, qmin, qmax, rounding);
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void fq_linear_t_scalar_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
+    float* __restrict__ out, uint32_t n, int qmin, int qmax, int rounding) {
+    const float s = scale[0];
+    const int o = round_offset(offset[0]);
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride)
+        out[i] = fq_linear_scalar<R>(x[i], s, o, qmin, qmax, rounding);
+}
+
+// --------------------------------------------------------------------------- per channel forward
+// VEC: elem_per_channel % 4 == 0, so a float4 never straddles two channels.
+template <int R, int U>
+__global__ __launch_bounds__(kBlock) void fq_linear_c_vec_kernel(
+    const float4* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
+    float4* __restrict__ out, uint32_t nvec, FastDiv vec_per_channel, FastDiv num_channel,
+    int qmin, int qmax, int rounding) {
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride * U) {
+        float4 a[U];
+        float s[U];
+        int o[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const uint32_t vv = v + k * stride;
+            if (vv < nvec) {
+                a[k] = x[vv];
+                const uint32_t row = fdiv(vv, vec_per_channel);
+                const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
+                s[k] = scale[c];
+                o[k] = round_offset(offset[c]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const uint32_t vv = v + k * stride;
+            if (vv < nvec) {
+                float4 r;
+                r.x = fq_linear_scalar<R>(a[k].x, s[k], o[k], qmin, qmax, rounding);
+                r.y = fq_linear_scalar<R>(a[k].y, s[k], o[k], qmin, qmax, rounding);
+                r.z = fq_linear_scalar<R>(a[k].z, s[k], o[k], qmin, qmax, rounding);
+                r.w = fq_linear_scalar<R>(a[k].w, s[k], o[k], qmin, qmax, rounding);
+                out[vv] = r;
+            }
+        }
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void fq_linear_c_scalar_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
+    float* __restrict__ out, uint32_t n, FastDiv elem_per_channel, FastDiv num_channel,
+    int qmin, int qmax, int rounding) {
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t row = fdiv(i, elem_per_channel);
+        const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
+        out[i] = fq_linear_scalar<R>(x[i], scale[c], round_offset(offset[c]), qmin, qmax, rounding);
+    }
+}
+
+// --------------------------------------------------------------------------- LSQ backward
+// One element of QuantizeTensor_LT_B / _LC_B (linear.cu:255-274 / :352-372).  `o` is the rounded
+// offset kept as float, as in the reference; returns the partial d(loss)/d(scale) term.
+template <bool CHANNEL>
+__device__ __forceinline__ float lsq_bwd_elem(float v, float dy, float s, float o, int qmin, int qmax,
+                                              int rounding, float* gx) {
+    const int qt = f2i_sat((float)round2int(v / s, rounding) + o);
+    if (qt > qmax) { *gx = 0.f; return ((float)qmax - o) * dy; }
+    if (qt < qmin) { *gx = 0.f; return ((float)qmin - o) * dy; }
+    const float q = (float)(qt - f2i_sat(o)) * s;
+    *gx = dy;
+    return CHANNEL ? ((q - v) / s * dy) : ((q - v) * dy / s);
+}
+
+__device__ __forceinline__ float block_sum(float v, float* lds) {
+    v = wave_sum(v);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) lds[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (wid == 0) {
+        r = lane < (int)(blockDim.x >> 6) ? lds[lane] : 0.f;
+        r = wave_sum(r);
+    }
+    return r;  // valid in wave 0
+}
+
+__global__ __launch_bounds__(kBlock) void fq_linear_t_bwd_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
+    const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ gs, uint32_t n,
+    int qmin, int qmax, float grad_factor, int rounding) {
+    __shared__ float lds[kBlock / kWave];
+    const float s = scale[0];
+    const float o = __builtin_roundf(offset[0]);
+    float acc = 0.f;
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        float g;
+        acc += lsq_bwd_elem<false>(x[i], dy[i], s, o, qmin, qmax, rounding, &g);
+        gx[i] = g;
+    }
+    const float tot = block_sum(acc, lds);
+    if (threadIdx.x == 0) atomicAdd(gs, tot * grad_factor);
+}
+
+// rows = outer * C rows of `epc` contiguous elements; block b handles chunk (b % chunks) of row
+// (b / chunks) -> one channel per block, one atomic per block.
+__global__ __launch_bounds__(kBlock) void fq_linear_c_bwd_row_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
+    const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ gs, uint32_t epc,
+    FastDiv chunks, FastDiv num_channel, uint32_t chunk_elems, int qmin, int qmax, float grad_factor,
+    int rounding) {
+    __shared__ float lds[kBlock / kWave];
+    const uint32_t row = fdiv(blockIdx.x, chunks);
+    const uint32_t chunk = blockIdx.x - row * chunks.d;
+    const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
+    const float s = scale[c];
+    const float o = __builtin_roundf(offset[c]);
+    const uint32_t lo = chunk * chunk_elems;
+    const uint32_t hi = min(lo + chunk_elems, epc);
+    const size_t base = (size_t)row * epc;
+    float acc = 0.f;
+    for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
+        float g;
+        acc += lsq_bwd_elem<true>(x[base + j], dy[base + j], s, o, qmin, qmax, rounding, &g);
+        gx[base + j] = g;
+    }
+    const float tot = block_sum(acc, lds);
+    if (threadIdx.x == 0) atomicAdd(&gs[c], tot * grad_factor);
+}
+
+// generic layout (small elem_per_channel, e.g. channel-last): per-element atomics into LDS
+// accumulators (num_channel <= lds_channels) or straight to global memory.
+__global__ __launch_bounds__(kBlock) void fq_linear_c_bwd_generic_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
+    const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ gs, uint32_t n,
+    FastDiv elem_per_channel, FastDiv num_channel, int use_lds, int qmin, int qmax, float grad_factor,
+    int rounding) {
+    extern __shared__ float acc_lds[];
+    const uint32_t C = num_channel.d;
+    if (use_lds) {
+        for (uint32_t c = threadIdx.x; c < C; c += kBlock) acc_lds[c] = 0.f;
+        __syncthreads();
+    }
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t row = fdiv(i, elem_per_channel);
+        const uint32_t c = row - fdiv(row, num_channel) * C;
+        float g;
+        const float p = lsq_bwd_elem<true>(x[i], dy[i], scale[c], __builtin_roundf(offset[c]), qmin, qmax,
+                                            rounding, &g);
+        gx[i] = g;
+        if (use_lds) atomicAdd(&acc_lds[c], p);
+        else atomicAdd(&gs[c], p * grad_factor);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (uint32_t c = threadIdx.x; c < C; c += kBlock) {
+            const float v = acc_lds[c];
+            if (v != 0.f) atomicAdd(&gs[c], v * grad_factor);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------- host dispatch
+static int validate_n(int64_t n, const char* what) {
+    if (n <= 0) { set_error("%s: tensor is empty", what); return PPQHIP_ERR_INVALID_VALUE; }
+    if (n > 0x7fffffffLL) {
+        set_error("%s: there are too many elements in your tensor (more than 2*10^9)", what);
+        return PPQHIP_ERR_INVALID_VALUE;
+    }
+    return PPQHIP_OK;
+}
+
+static int validate_channels(int64_t n, int64_t C, int64_t epc, const char* what) {
+    if (C <= 0 || epc <= 0 || n % (C * epc) != 0) {
+        set_error("%s: n=%lld is not [outer, %lld channels, %lld elem/channel]", what, (long long)n,
+                  (long long)C, (long long)epc);
+        return PPQHIP_ERR_INVALID_VALUE;
+    }
+    return PPQHIP_OK;
+}
+
+// unroll policy: tensors that fit one float4 per lane on a fully occupied chip (<= 2048 blocks)
+// take U=1 (maximum parallelism, lowest latency); larger ones U=4 with a grid-stride loop.
+constexpr uint32_t kSmallVec = (uint32_t)kNumCU * 8 * kBlock;
+
+template <int R>
+static void launch_lt(const float* x, const float* scale, const float* offset, float* out, int64_t n,
+                      int qmin, int qmax, int rounding, hipStream_t st) {
+    if (aligned16(x) && aligned16(out) && n >= 4) {
+        const uint32_t nvec = (uint32_t)(n >> 2);
+        const int ntail = (int)(n & 3);
+        const float* xt = x + (size_t)nvec * 4;
+        float* ot = out + (size_t)nvec * 4;
+        if (nvec <= kSmallVec) {
+            hipLaunchKernelGGL((fq_linear_t_vec_kernel<R, 1>), dim3(stream_grid(nvec, kBlock)), dim3(kBlock), 0, st,
+                               (const float4*)x, scale, offset, (float4*)out, nvec, xt, ot, ntail, qmin, qmax,
+                               rounding);
+        } else {
+            hipLaunchKernelGGL((fq_linear_t_vec_kernel<R, 4>), dim3(stream_grid(nvec, kBlock * 4)), dim3(kBlock), 0,
+                               st, (const float4*)x, scale, offset, (float4*)out, nvec, xt, ot, ntail, qmin, qmax,
+                               rounding);
+        }
+    } else {
+        hipLaunchKernelGGL((fq_linear_t_scalar_kernel<R>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, x,
+                           scale, offset, out, (uint32_t)n, qmin, qmax, rounding);
+    }
+}
+
+template <int R>
+static void launch_lc(const float* x, const float* scale, const float* offset, float* out, int64_t n,
+                      int64_t C, int64_t epc, int qmin, int qmax, int rounding, hipStream_t st) {
+    if (aligned16(x) && aligned16(out) && (epc % 4 == 0)) {
+        const uint32_t nvec = (uint32_t)(n >> 2);
+        const FastDiv vpc = make_fastdiv((uint32_t)(epc / 4)), nc = make_fastdiv((uint32_t)C);
+        if (nvec <= kSmallVec) {
+            hipLaunchKernelGGL((fq_linear_c_vec_kernel<R, 1>), dim3(stream_grid(nvec, kBlock)), dim3(kBlock), 0, st,
+                               (const float4*)x, scale, offset, (float4*)out, nvec, vpc, nc, qmin, qmax, rounding);
+        } else {
+            hipLaunchKernelGGL((fq_linear_c_vec_kernel<R, 4>), dim3(stream_grid(nvec, kBlock * 4)), dim3(kBlock), 0,
+                               st, (const float4*)x, scale, offset, (float4*)out, nvec, vpc, nc, qmin, qmax,
+                               rounding);
+        }
+    } else {
+        const FastDiv e = make_fastdiv((uint32_t)epc), nc = make_fastdiv((uint32_t)C);
+        hipLaunchKernelGGL((fq_linear_c_scalar_kernel<R>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, x,
+                           scale, offset, out, (uint32_t)n, e, nc, qmin, qmax, rounding);
+    }
+}
+
+}  // namespace ppqhip
+
+using namespace ppqhip;
+
+extern "C" {
+
+int ppqhip_fq_linear_t(const float* x, const float* scale, const float* offset, float* out, int64_t n,
+                       int clip_min, int clip_max, int rounding, void* stream) {
+    if (int st = validate_n(n, "fq_linear_t")) return st;
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_FQ_LINEAR_T, 8.0 * (double)n, s);
+    if (rounding == ROUND_HALF_EVEN) launch_lt<ROUND_HALF_EVEN>(x, scale, offset, out, n, clip_min, clip_max, rounding, s);
+    else launch_lt<-1>(x, scale, offset, out, n, clip_min, clip_max, rounding, s);
+    return finish_launch("fq_linear_t");
+}
+
+int ppqhip_fq_linear_c(const float* x, const float* scale, const float* offset, float* out, int64_t n,
+                       int64_t num_channel, int64_t elem_per_channel, int clip_min, int clip_max,
+                       int rounding, void* stream) {
+    if (int st = validate_n(n, "fq_linear_c")) return st;
+    if (int st = validate_channels(n, num_channel, elem_per_channel, "fq_linear_c")) return st;
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_FQ_LINEAR_C, 8.0 * (double)n, s);
+    if (rounding == ROUND_HALF_EVEN)
+        launch_lc<ROUND_HALF_EVEN>(x, scale, offset, out, n, num_channel, elem_per_channel, clip_min, clip_max,
+                                   rounding, s);
+    else launch_lc<-1>(x, scale, offset, out, n, num_channel, elem_per_channel, clip_min, clip_max, rounding, s);
+    return finish_launch("fq_linear_c");
+}
+
+int ppqhip_fq_linear_t_bwd(const float* x, const float* scale, const float* offset, const float* grad_y,
+                           float* grad_x, float* grad_s, int64_t n, int clip_min, int clip_max,
+                           int rounding, void* stream) {
+    if (int st = validate_n(n, "fq_linear_t_bwd")) return st;
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_FQ_LINEAR_T_BWD, 12.0 * (double)n, s);
+    if (int st = check_hip(hipMemsetAsync(grad_s, 0, sizeof(float), s), "memset grad_s")) return st;
+    // rsqrtf(((double)n * (clip_max - clip_min))): linear.cu:299
+    const float grad_factor = (float)(1.0 / sqrt((double)n * (double)(clip_max - clip_min)));
+    hipLaunchKernelGGL(fq_linear_t_bwd_kernel, dim3(stream_grid(n, kBlock * 4, kNumCU * 4)), dim3(kBlock), 0, s, x,
+                       scale, offset, grad_y, grad_x, grad_s, (uint32_t)n, clip_min, clip_max, grad_factor,
+                       rounding);
+    return finish_launch("fq_linear_t_bwd");
+}
+
+int ppqhip_fq_linear_c_bwd(const float* x, const float* scale, const float* offset, const float* grad_y,
+                           float* grad_x, float* grad_s, int64_t n, int64_t num_channel,
+                           int64_t elem_per_channel, int clip_min, int clip_max, int rounding,
+                           void* stream) {
+    if (int st = validate_n(n, "fq_linear_c_bwd")) return st;
+    if (int st = validate_channels(n, num_channel, elem_per_channel, "fq_linear_c_bwd")) return st;
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_FQ_LINEAR_C_BWD, 12.0 * (double)n, s);
+    if (int st = check_hip(hipMemsetAsync(grad_s, 0, sizeof(float) * (size_t)num_channel, s), "memset grad_s"))
+        return st;
+    // rsqrtf(((double)n * clip_max)): linear.cu:402
+    const float grad_factor = (float)(1.0 / sqrt((double)n * (double)clip_max));
+    const FastDiv nc = make_fastdiv((uint32_t)num_channel);
+    if (elem_per_channel >= 256) {
+        const uint32_t chunk_elems = 4096;
+        const uint32_t chunks = (uint32_t)((elem_per_channel + chunk_elems - 1) / chunk_elems);
+        const int64_t rows = n / elem_per_channel;
+        hipLaunchKernelGGL(fq_linear_c_bwd_row_kernel, dim3((uint32_t)(rows * chunks)), dim3(kBlock), 0, s, x,
+                           scale, offset, grad_y, grad_x, grad_s, (uint32_t)elem_per_channel,
+                           make_fastdiv(chunks), nc, chunk_elems, clip_min, clip_max, grad_factor, rounding);
+    } else {
+        const int use_lds = num_channel <= 8192;
+        const size_t lds = use_lds ? sizeof(float) * (size_t)num_channel : 0;
+        hipLaunchKernelGGL(fq_linear_c_bwd_generic_kernel, dim3(stream_grid(n, kBlock * 8, kNumCU * 2)),
+                           dim3(kBlock), lds, s, x, scale, offset, grad_y, grad_x, grad_s, (uint32_t)n,
+                           make_fastdiv((uint32_t)elem_per_channel), nc, use_lds, clip_min, clip_max,
+                           grad_factor, rounding);
+    }
+    return finish_launch("fq_linear_c_bwd");
+}
+
+}  // extern "C"

@@ -1,0 +1,396 @@
+// reduce.hip -- range reductions and order statistics for gfx950.
+//
+//   minmax_t / minmax_c  one streaming pass (16-B loads), wave64 shuffle reduction, LDS across the
+//                        4 waves of a workgroup, ONE pair of global atomics per workgroup on plain
+//                        float storage (sign-split integer min/max).  Replaces the
+//                        transpose+flatten+torch.min/max of TorchMinMaxObserver.observe
+//                        (ppq/quantization/observer/range.py:86-98).
+//   quantile_t           replaces Quantile_T (ppq/csrc/cuda/sort.cu:42-59): instead of a full
+//                        thrust::sort of a clone it radix-SELECTS the two order statistics on the
+//                        order-preserving uint32 key of the floats in three streaming passes
+//                        (12 + 12 + 8 bits, LDS histograms), no data movement.
+//   isotone_t            replaces Isotone_T (sort.cu:61-73): top-2 / bottom-2 reduction.
+#include <cmath>
+
+#include "common.hpp"
+
+namespace ppqhip {
+
+// ------------------------------------------------------------------------------------ min / max
+__device__ __forceinline__ void block_minmax_commit(float mn, float mx, float* gmin, float* gmax, float* lds) {
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+    if (lane == 0) { lds[wid] = mn; lds[8 + wid] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < nw; w++) { mn = fminf(mn, lds[w]); mx = fmaxf(mx, lds[8 + w]); }
+        if (mn <= mx) {   // false only when this workgroup saw no (non-NaN) element
+            atomic_min_f32(gmin, mn);
+            atomic_max_f32(gmax, mx);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void minmax_t_kernel(const float* __restrict__ x, uint32_t n, int vec_ok,
+                                                          float* __restrict__ minmax) {
+    __shared__ float lds[16];
+    float mn = INFINITY, mx = -INFINITY;
+    const uint32_t stride = gridDim.x * kBlock;
+    uint32_t done = 0;
+    if (vec_ok) {
+        const uint32_t nvec = n >> 2;
+        const float4* xv = reinterpret_cast<const float4*>(x);
+        for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
+            const float4 a = xv[v];
+            mn = fminf(fminf(mn, a.x), fminf(a.y, fminf(a.z, a.w)));
+            mx = fmaxf(fmaxf(mx, a.x), fmaxf(a.y, fmaxf(a.z, a.w)));
+        }
+        done = nvec << 2;
+    }
+    for (uint32_t i = done + blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const float a = x[i];
+        mn = fminf(mn, a); mx = fmaxf(mx, a);
+    }
+    block_minmax_commit(mn, mx, &minmax[0], &minmax[1], lds);
+}
+
+// rows of `epc` contiguous elements, workgroup = (row, chunk)
+__global__ __launch_bounds__(kBlock) void minmax_c_row_kernel(const float* __restrict__ x, uint32_t epc, int vec_ok,
+                                                              FastDiv chunks, FastDiv num_channel,
+                                                              uint32_t chunk_elems, float* __restrict__ mins,
+                                                              float* __restrict__ maxs) {
+    __shared__ float lds[16];
+    const uint32_t row = fdiv(blockIdx.x, chunks);
+    const uint32_t chunk = blockIdx.x - row * chunks.d;
+    const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
+    const uint32_t lo = chunk * chunk_elems;
+    const uint32_t hi = min(lo + chunk_elems, epc);
+    const float* xr = x + (size_t)row * epc;
+    float mn = INFINITY, mx = -INFINITY;
+    if (vec_ok) {   // epc % 4 == 0, chunk_elems % 4 == 0, base 16-B aligned
+        const float4* xv = reinterpret_cast<const float4*>(xr);
+        for (uint32_t v = (lo >> 2) + threadIdx.x; v < (hi >> 2); v += kBlock) {
+            const float4 a = xv[v];
+            mn = fminf(fminf(mn, a.x), fminf(a.y, fminf(a.z, a.w)));
+            mx = fmaxf(fmaxf(mx, a.x), fmaxf(a.y, fmaxf(a.z, a.w)));
+        }
+    } else {
+        for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
+            const float a = xr[j];
+            mn = fminf(mn, a); mx = fmaxf(mx, a);
+        }
+    }
+    block_minmax_commit(mn, mx, &mins[c], &maxs[c], lds);
+}
+
+// short rows (channel-last, [N,C,1,1] ...): per-element LDS (or global) atomics by channel
+__global__ __launch_bounds__(kBlock) void minmax_c_generic_kernel(const float* __restrict__ x, uint32_t n,
+                                                                  FastDiv elem_per_channel, FastDiv num_channel,
+                                                                  int use_lds, float* __restrict__ mins,
+                                                                  float* __restrict__ maxs) {
+    extern __shared__ float mm[];   // [C] mins, [C] maxs
+    const uint32_t C = num_channel.d;
+    if (use_lds) {
+        for (uint32_t c = threadIdx.x; c < C; c += kBlock) { mm[c] = INFINITY; mm[C + c] = -INFINITY; }
+        __syncthreads();
+    }
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const float a = x[i];
+        if (a != a) continue;
+        const uint32_t row = fdiv(i, elem_per_channel);
+        const uint32_t c = row - fdiv(row, num_channel) * C;
+        if (use_lds) { atomic_min_f32(&mm[c], a); atomic_max_f32(&mm[C + c], a); }
+        else { atomic_min_f32(&mins[c], a); atomic_max_f32(&maxs[c], a); }
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (uint32_t c = threadIdx.x; c < C; c += kBlock) {
+            if (mm[c] <= mm[C + c]) { atomic_min_f32(&mins[c], mm[c]); atomic_max_f32(&maxs[c], mm[C + c]); }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------ quantile
+// order-preserving key: ascending uint32 order == ascending float order
+__device__ __forceinline__ uint32_t f2key(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+// workspace layout (uint32 words)
+constexpr int kQ1 = 4096, kQ2 = 4096, kQ3 = 256;
+constexpr int kOffH1 = 0;                   // hist1[4096]        : key >> 20
+constexpr int kOffH2 = kOffH1 + kQ1;        // hist2[2][4096]     : (key >> 8) & 0xFFF | prefix12 match
+constexpr int kOffH3 = kOffH2 + 2 * kQ2;    // hist3[2][256]      : key & 0xFF        | prefix24 match
+constexpr int kQWords = kOffH3 + 2 * kQ3;
+
+// find the bin of `hist[0..nbins)` that holds rank k (0-based) and the rank inside it.
+// All threads of the workgroup call this; result is broadcast through LDS (sel[0], sel[1]).
+__device__ void select_bin(const uint32_t* __restrict__ hist, int nbins, uint32_t k, uint32_t* scratch,
+                           uint32_t* sel) {
+    // nbins <= 4096, blockDim.x == 256: each thread owns nbins/256 consecutive bins
+    const int per = nbins / kBlock > 0 ? nbins / kBlock : 1;
+    const int t = threadIdx.x;
+    uint32_t local = 0;
+    if (t * per < nbins)
+        for (int j = 0; j < per; j++) local += hist[t * per + j];
+    scratch[t] = local;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        int owner = 0;
+        const int owners = nbins / per;
+        for (owner = 0; owner < owners; owner++) {
+            if (run + scratch[owner] > k) break;
+            run += scratch[owner];
+        }
+        if (owner >= owners) owner = owners - 1;   // k beyond total (cannot happen for k < n)
+        int b = owner * per;
+        for (; b < owner * per + per - 1; b++) {
+            const uint32_t c = hist[b];
+            if (run + c > k) break;
+            run += c;
+        }
+        sel[0] = (uint32_t)b;
+        sel[1] = k - run;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(kBlock) void quantile_pass1_kernel(const float* __restrict__ x, uint32_t n,
+                                                                uint32_t* __restrict__ ws) {
+    __shared__ uint32_t h[kQ1];
+    for (int i = threadIdx.x; i < kQ1; i += kBlock) h[i] = 0;
+    __syncthreads();
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) atomicAdd(&h[f2key(x[i]) >> 20], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kQ1; i += kBlock)
+        if (h[i]) atomicAdd(&ws[kOffH1 + i], h[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void quantile_pass2_kernel(const float* __restrict__ x, uint32_t n,
+                                                                uint32_t k_hi, uint32_t k_lo,
+                                                                uint32_t* __restrict__ ws) {
+    __shared__ uint32_t h[2 * kQ2];
+    __shared__ uint32_t scratch[kBlock];
+    __shared__ uint32_t sel[2];
+    select_bin(ws + kOffH1, kQ1, k_hi, scratch, sel);
+    const uint32_t p_hi = sel[0];
+    __syncthreads();
+    select_bin(ws + kOffH1, kQ1, k_lo, scratch, sel);
+    const uint32_t p_lo = sel[0];
+    for (int i = threadIdx.x; i < 2 * kQ2; i += kBlock) h[i] = 0;
+    __syncthreads();
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t key = f2key(x[i]);
+        const uint32_t top = key >> 20, mid = (key >> 8) & 0xFFFu;
+        if (top == p_hi) atomicAdd(&h[mid], 1u);
+        if (top == p_lo) atomicAdd(&h[kQ2 + mid], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * kQ2; i += kBlock)
+        if (h[i]) atomicAdd(&ws[kOffH2 + i], h[i]);
+}
+
+// shared by pass 3 and the final pick: 24-bit prefixes and residual ranks of both targets
+__device__ void select_prefix24(const uint32_t* __restrict__ ws, uint32_t k_hi, uint32_t k_lo, uint32_t* scratch,
+                                uint32_t* sel, uint32_t* p24, uint32_t* r24) {
+    const uint32_t ks[2] = {k_hi, k_lo};
+    for (int w = 0; w < 2; w++) {
+        select_bin(ws + kOffH1, kQ1, ks[w], scratch, sel);
+        const uint32_t top = sel[0], r1 = sel[1];
+        __syncthreads();
+        select_bin(ws + kOffH2 + w * kQ2, kQ2, r1, scratch, sel);
+        p24[w] = (top << 12) | sel[0];
+        r24[w] = sel[1];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void quantile_pass3_kernel(const float* __restrict__ x, uint32_t n,
+                                                                uint32_t k_hi, uint32_t k_lo,
+                                                                uint32_t* __restrict__ ws) {
+    __shared__ uint32_t h[2 * kQ3];
+    __shared__ uint32_t scratch[kBlock];
+    __shared__ uint32_t sel[2];
+    uint32_t p24[2], r24[2];
+    select_prefix24(ws, k_hi, k_lo, scratch, sel, p24, r24);
+    for (int i = threadIdx.x; i < 2 * kQ3; i += kBlock) h[i] = 0;
+    __syncthreads();
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t key = f2key(x[i]);
+        if ((key >> 8) == p24[0]) atomicAdd(&h[key & 0xFFu], 1u);
+        if ((key >> 8) == p24[1]) atomicAdd(&h[kQ3 + (key & 0xFFu)], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * kQ3; i += kBlock)
+        if (h[i]) atomicAdd(&ws[kOffH3 + i], h[i]);
+}
+
+__global__ __launch_bounds__(kBlock) void quantile_pick_kernel(uint32_t k_hi, uint32_t k_lo,
+                                                               const uint32_t* __restrict__ ws,
+                                                               float* __restrict__ dest) {
+    __shared__ uint32_t scratch[kBlock];
+    __shared__ uint32_t sel[2];
+    uint32_t p24[2], r24[2];
+    select_prefix24(ws, k_hi, k_lo, scratch, sel, p24, r24);
+    for (int w = 0; w < 2; w++) {
+        select_bin(ws + kOffH3 + w * kQ3, kQ3, r24[w], scratch, sel);
+        if (threadIdx.x == 0) dest[w] = key2f((p24[w] << 8) | sel[0]);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------ isotone
+struct Top2 { float a1, a2, b1, b2; };   // a1 >= a2 largest two, b1 <= b2 smallest two (with multiplicity)
+
+__device__ __forceinline__ void top2_push(Top2& t, float v) {
+    if (v > t.a1) { t.a2 = t.a1; t.a1 = v; } else if (v > t.a2) t.a2 = v;
+    if (v < t.b1) { t.b2 = t.b1; t.b1 = v; } else if (v < t.b2) t.b2 = v;
+}
+__device__ __forceinline__ void top2_merge(Top2& t, const Top2& o) {
+    // largest two of {t.a1, t.a2, o.a1, o.a2}
+    const float hi = fmaxf(t.a1, o.a1);
+    const float second = fmaxf(fminf(t.a1, o.a1), fmaxf(t.a2, o.a2));
+    t.a1 = hi; t.a2 = second;
+    const float lo = fminf(t.b1, o.b1);
+    const float second_lo = fminf(fmaxf(t.b1, o.b1), fminf(t.b2, o.b2));
+    t.b1 = lo; t.b2 = second_lo;
+}
+__device__ __forceinline__ Top2 top2_wave(Top2 t) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        Top2 o;
+        o.a1 = __shfl_xor(t.a1, m, 64); o.a2 = __shfl_xor(t.a2, m, 64);
+        o.b1 = __shfl_xor(t.b1, m, 64); o.b2 = __shfl_xor(t.b2, m, 64);
+        top2_merge(t, o);
+    }
+    return t;
+}
+
+// stage 0: x -> partial[gridDim.x]; stage 1 (one workgroup): partial -> dest
+__global__ __launch_bounds__(kBlock) void isotone_kernel(const float* __restrict__ x, uint32_t n,
+                                                         const Top2* __restrict__ partial_in, uint32_t n_partial,
+                                                         Top2* __restrict__ partial_out, float* __restrict__ dest,
+                                                         uint32_t n_total) {
+    __shared__ Top2 lds[kBlock / kWave];
+    Top2 t{-INFINITY, -INFINITY, INFINITY, INFINITY};
+    const uint32_t stride = gridDim.x * kBlock;
+    if (partial_in == nullptr) {
+        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) top2_push(t, x[i]);
+    } else {
+        for (uint32_t i = threadIdx.x; i < n_partial; i += kBlock) top2_merge(t, partial_in[i]);
+    }
+    t = top2_wave(t);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) lds[wid] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / kWave; w++) top2_merge(t, lds[w]);
+        if (dest == nullptr) partial_out[blockIdx.x] = t;
+        else if (n_total == 1) { dest[0] = dest[1] = dest[2] = dest[3] = t.a1; }
+        else { dest[0] = t.a1; dest[1] = t.a2; dest[2] = t.b1; dest[3] = t.b2; }
+    }
+}
+
+constexpr int kIsotoneBlocks = 1024;
+
+static int validate(int64_t n, const char* what) {
+    if (n <= 0) { set_error("%s: tensor is empty", what); return PPQHIP_ERR_INVALID_VALUE; }
+    if (n > 0x7fffffffLL) { set_error("%s: too many elements", what); return PPQHIP_ERR_INVALID_VALUE; }
+    return PPQHIP_OK;
+}
+
+}  // namespace ppqhip
+
+using namespace ppqhip;
+
+extern "C" {
+
+int ppqhip_minmax_t(const float* x, int64_t n, float* minmax, void* stream) {
+    if (int st = validate(n, "minmax_t")) return st;
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_MINMAX_T, 4.0 * (double)n, s);
+    hipLaunchKernelGGL(minmax_t_kernel, dim3(stream_grid(n, kBlock * 4 * 2, kNumCU * 4)), dim3(kBlock), 0, s, x,
+                       (uint32_t)n, aligned16(x) ? 1 : 0, minmax);
+    return finish_launch("minmax_t");
+}
+
+int ppqhip_minmax_c(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel, float* mins,
+                    float* maxs, void* stream) {
+    if (int st = validate(n, "minmax_c")) return st;
+    if (num_channel <= 0 || elem_per_channel <= 0 || n % (num_channel * elem_per_channel) != 0) {
+        set_error("minmax_c: bad channel geometry"); return PPQHIP_ERR_INVALID_VALUE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_MINMAX_C, 4.0 * (double)n, s);
+    const FastDiv nc = make_fastdiv((uint32_t)num_channel);
+    if (elem_per_channel >= 64) {
+        const uint32_t chunk_elems = 8192;
+        const uint32_t chunks = (uint32_t)((elem_per_channel + chunk_elems - 1) / chunk_elems);
+        const int64_t rows = n / elem_per_channel;
+        const int vec_ok = (aligned16(x) && elem_per_channel % 4 == 0) ? 1 : 0;
+        hipLaunchKernelGGL(minmax_c_row_kernel, dim3((uint32_t)(rows * chunks)), dim3(kBlock), 0, s, x,
+                           (uint32_t)elem_per_channel, vec_ok, make_fastdiv(chunks), nc, chunk_elems, mins, maxs);
+    } else {
+        const int use_lds = num_channel <= 4096;
+        const size_t lds = use_lds ? 2 * sizeof(float) * (size_t)num_channel : 0;
+        hipLaunchKernelGGL(minmax_c_generic_kernel, dim3(stream_grid(n, kBlock * 16, kNumCU * 2)), dim3(kBlock), lds,
+                           s, x, (uint32_t)n, make_fastdiv((uint32_t)elem_per_channel), nc, use_lds, mins, maxs);
+    }
+    return finish_launch("minmax_c");
+}
+
+int64_t ppqhip_quantile_workspace_bytes(int64_t n) {
+    (void)n;
+    const int64_t q = (int64_t)kQWords * 4;
+    const int64_t iso = (int64_t)kIsotoneBlocks * (int64_t)sizeof(Top2);
+    return q > iso ? q : iso;
+}
+
+int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, void* workspace, void* stream) {
+    if (int st = validate(n, "quantile_t")) return st;
+    if (workspace == nullptr) { set_error("quantile_t: workspace is null"); return PPQHIP_ERR_INVALID_VALUE; }
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_QUANTILE, 4.0 * (double)n, s);
+    // index rule of _Quantile_T, sort.cu:13-19: __float2int_rn(num_of_elements * q), clipped to [0, n-1]
+    auto pos = [n](float f) -> uint32_t {
+        float p = nearbyintf((float)n * f);
+        if (!(p > 0.f)) return 0u;                      // also NaN
+        if (p >= (float)(n - 1)) return (uint32_t)(n - 1);
+        return (uint32_t)p;
+    };
+    const uint32_t k_hi = pos(q), k_lo = pos(1 - q);
+    uint32_t* ws = (uint32_t*)workspace;
+    if (int st = check_hip(hipMemsetAsync(ws, 0, (size_t)kQWords * 4, s), "memset quantile workspace")) return st;
+    const int grid = stream_grid(n, kBlock * 16, kNumCU * 2);
+    hipLaunchKernelGGL(quantile_pass1_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, ws);
+    hipLaunchKernelGGL(quantile_pass2_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, k_hi, k_lo, ws);
+    hipLaunchKernelGGL(quantile_pass3_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, k_hi, k_lo, ws);
+    hipLaunchKernelGGL(quantile_pick_kernel, dim3(1), dim3(kBlock), 0, s, k_hi, k_lo, ws, dest);
+    return finish_launch("quantile_t");
+}
+
+int ppqhip_isotone_t(const float* x, int64_t n, float* dest, void* workspace, void* stream) {
+    if (int st = validate(n, "isotone_t")) return st;
+    if (workspace == nullptr) { set_error("isotone_t: workspace is null"); return PPQHIP_ERR_INVALID_VALUE; }
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_ISOTONE, 4.0 * (double)n, s);
+    Top2* partial = (Top2*)workspace;
+    const int grid = stream_grid(n, kBlock * 8, kIsotoneBlocks);
+    hipLaunchKernelGGL(isotone_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, (const Top2*)nullptr, 0u,
+                       partial, (float*)nullptr, (uint32_t)n);
+    hipLaunchKernelGGL(isotone_kernel, dim3(1), dim3(kBlock), 0, s, (const float*)nullptr, 0u, (const Top2*)partial,
+                       (uint32_t)grid, (Top2*)nullptr, dest, (uint32_t)n);
+    return finish_launch("isotone_t");
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+// runtime.hip -- error reporting, introspection and the hipEvent profiling aid of libppq_hip.so.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+#include "common.hpp"
+
+namespace ppqhip {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return PPQHIP_OK;
+    set_error("HIP failure in %s: %s", what, hipGetErrorString(e));
+    return PPQHIP_ERR_HIP;
+}
+
+int finish_launch(const char* what) { return check_hip(hipGetLastError(), what); }
+
+const char* const kKernelNames[K_NUM] = {
+    "fq_linear_t", "fq_linear_c", "fq_linear_t_bwd", "fq_linear_c_bwd", "fq_float_t", "fq_float_c",
+    "fq_float_bwd", "hist_sym_t", "hist_asym_t", "hist_sym_c", "quantile_t", "isotone_t", "minmax_t",
+    "minmax_c", "mse_search", "kl_losses", "tensor_clip", "rounding_loss", "fq_linear_t_hist_sym"};
+
+// ---- profiling aid ------------------------------------------------------------------------
+struct ProfRecord {
+    int id;
+    double bytes;
+    hipEvent_t start, stop;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<ProfRecord> g_records;
+static std::vector<hipEvent_t> g_pool;
+
+static hipEvent_t get_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; hipEventCreate(&e); return e;
+}
+
+LaunchScope::LaunchScope(KernelId id, double bytes, hipStream_t s) : slot(-1), stream(s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRecord r; r.id = id; r.bytes = bytes; r.start = get_event(); r.stop = get_event();
+    hipEventRecord(r.start, stream);
+    g_records.push_back(r);
+    slot = (int)g_records.size() - 1;
+}
+
+LaunchScope::~LaunchScope() {
+    if (slot < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEventRecord(g_records[slot].stop, stream);
+}
+
+}  // namespace ppqhip
+
+using namespace ppqhip;
+
+extern "C" {
+
+const char* ppqhip_last_error(void) { return g_err; }
+
+int ppqhip_version(void) { return 1; }
+
+int ppqhip_device_arch(char* buf, int n) {
+    int dev = 0;
+    if (int st = check_hip(hipGetDevice(&dev), "hipGetDevice")) return st;
+    hipDeviceProp_t prop;
+    if (int st = check_hip(hipGetDeviceProperties(&prop, dev), "hipGetDeviceProperties")) return st;
+    snprintf(buf, n, "%s", prop.gcnArchName);
+    return PPQHIP_OK;
+}
+
+int ppqhip_prof_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+    return PPQHIP_OK;
+}
+
+int ppqhip_prof_collect(ppqhip_prof_entry* entries, int max_entries) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ppqhip_prof_entry agg[K_NUM];
+    memset(agg, 0, sizeof(agg));
+    for (int k = 0; k < K_NUM; k++) snprintf(agg[k].name, sizeof(agg[k].name), "%s", kKernelNames[k]);
+    for (auto& r : g_records) {
+        float ms = 0.f;
+        hipEventSynchronize(r.stop);
+        hipEventElapsedTime(&ms, r.start, r.stop);
+        agg[r.id].launches += 1; agg[r.id].total_ms += ms; agg[r.id].total_bytes += r.bytes;
+        g_pool.push_back(r.start); g_pool.push_back(r.stop);
+    }
+    g_records.clear();
+    int n = 0;
+    for (int k = 0; k < K_NUM && n < max_entries; k++)
+        if (agg[k].launches > 0) entries[n++] = agg[k];
+    return n;
+}
+
+}  // extern "C"

@@ -1,0 +1,556 @@
+"""The drop-in seam: ``ppq.core.ffi`` rebuilt over the C-ABI HIP library.
+
+Reference: ppq/core/ffi.py.  Two objects are provided.
+
+``HIP_EXTENSION`` presents the 20 callables of the reference's pybind module ``PPQ_Cuda_Impls``
+(ppq/csrc/export.cc:8-34) with the same names and positional arguments, so it can be assigned to
+``ppq.core.ffi.CUDA_COMPLIER.__CUDA_EXTENTION__`` (see :func:`install_into_ppq` / INTEGRATION.md)
+and every ``ppq.core.ffi.CUDA.*`` wrapper of an unmodified PPQ then lands in our kernels.
+
+``CUDA`` mirrors the reference's static-method class of the same name (ffi.py:56-350): same method
+names, argument names, defaults and order, for code that wants the operator surface without PPQ.
+It adds the MI355X-native entries that have no twin in the reference (``MinMax_T/C``, ``KLLosses``,
+``MseSearch``, ``LinearQuantize_T_Histogram``).
+
+All tensor arguments must live on the GPU.  There is no CPU path: a CPU tensor raises.
+Errors follow the reference's convention as seen from Python: the C++ ``ValueTypeException`` /
+``InvalidValueException`` (common.cuh:32-48) surface as ``RuntimeError``.
+"""
+from typing import List
+
+import torch
+
+from . import _lib
+from ._lib import lib
+
+_KERNEL_FAILURE = 'Kernel Failure, '
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
+    """CheckTensor, ppq/csrc/cuda/common.cuh:78-86."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f'{name}: expected a torch.Tensor, got {type(t)}')
+    if t.dtype != dtype:
+        raise RuntimeError(_KERNEL_FAILURE + 'Invalid dtype of Input tensor: ' + name)
+    if t.numel() == 0:
+        raise RuntimeError(_KERNEL_FAILURE + 'Tensor is empty: ' + name)
+    if not t.is_cuda:
+        raise RuntimeError(_KERNEL_FAILURE + f'{name} is not on the GPU (ppq_amd has no CPU path)')
+
+
+def _f32(t, name): _check(t, torch.float32, name + '(Expect to be FP32)')
+
+
+def _raise(status: int) -> None:
+    if status != 0:
+        raise RuntimeError(_KERNEL_FAILURE + _lib.last_error())
+
+
+def _geometry(shape, channel_axis: int):
+    """num_channel = sizes[axis]; elem_per_channel = contiguous stride of the axis (linear.cu:213-214)
+    == product of the trailing dims (floating.cu:118-122)."""
+    ndim = len(shape)
+    if channel_axis < 0: channel_axis += ndim
+    if not 0 <= channel_axis < ndim:
+        raise RuntimeError(_KERNEL_FAILURE + f'channel_axis {channel_axis} out of range for a {ndim}-d tensor')
+    epc = 1
+    for d in shape[channel_axis + 1:]:
+        epc *= int(d)
+    return int(shape[channel_axis]), epc
+
+
+class _DeviceOf:
+    """Make the tensor's device current while launching (the library launches on the current device)."""
+    __slots__ = ('idx', 'prev')
+
+    def __init__(self, t: torch.Tensor):
+        self.idx = t.device.index
+        self.prev = None
+
+    def __enter__(self):
+        if self.idx is not None and self.idx != torch.cuda.current_device():
+            self.prev = torch.cuda.current_device()
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *a):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+
+
+_workspaces = {}
+
+
+def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
+    """Small per-device scratch buffer (quantile / isotone / mse search), grown on demand.  Launches
+    that use it are ordered on the current stream, like the reference's temporaries."""
+    key = (device.index, _stream())
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+class _HipExtension:
+    """Same callables as the pybind module built from ppq/csrc/export.cc:8-34."""
+    __name__ = 'PPQ_Hip_Impls'
+
+    # ---- linear ------------------------------------------------------------------------------
+    @ staticmethod
+    def QuantizeTensor_LT(value, scale, offset, clip_min: int, clip_max: int, rounding: int) -> torch.Tensor:
+        _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset')
+        v = value.contiguous()
+        out = torch.empty_like(v)
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_fq_linear_t(v.data_ptr(), scale.data_ptr(), offset.data_ptr(), out.data_ptr(),
+                                          v.numel(), int(clip_min), int(clip_max), int(rounding), _stream()))
+        return out
+
+    @ staticmethod
+    def QuantizeTensor_LC(value, scale, offset, clip_min: int, clip_max: int, channel_axis: int,
+                          rounding: int) -> torch.Tensor:
+        _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset')
+        v = value.contiguous()
+        C, epc = _geometry(v.shape, channel_axis)
+        if scale.numel() < C or offset.numel() < C:
+            raise RuntimeError(_KERNEL_FAILURE + f'scale/offset need {C} elements for channel axis {channel_axis}')
+        out = torch.empty_like(v)
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_fq_linear_c(v.data_ptr(), scale.contiguous().data_ptr(), offset.contiguous().data_ptr(),
+                                          out.data_ptr(), v.numel(), C, epc, int(clip_min), int(clip_max),
+                                          int(rounding), _stream()))
+        return out
+
+    @ staticmethod
+    def QuantizeTensor_LT_B(value, scale, offset, grad_y, clip_min: int, clip_max: int,
+                            rounding: int) -> List[torch.Tensor]:
+        _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset'); _f32(grad_y, 'Gard')
+        v = value.contiguous(); g = grad_y.contiguous()
+        grad_x = torch.empty_like(g); grad_s = torch.empty_like(scale)
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_fq_linear_t_bwd(v.data_ptr(), scale.data_ptr(), offset.data_ptr(), g.data_ptr(),
+                                              grad_x.data_ptr(), grad_s.data_ptr(), v.numel(), int(clip_min),
+                                              int(clip_max), int(rounding), _stream()))
+        return [grad_x, grad_s]
+
+    @ staticmethod
+    def QuantizeTensor_LC_B(value, scale, offset, grad_y, clip_min: int, clip_max: int, rounding: int,
+                            channel_axis: int) -> List[torch.Tensor]:
+        _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset'); _f32(grad_y, 'Gard')
+        v = value.contiguous(); g = grad_y.contiguous()
+        C, epc = _geometry(v.shape, channel_axis)
+        grad_x = torch.empty_like(g); grad_s = torch.empty_like(scale.contiguous())
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_fq_linear_c_bwd(v.data_ptr(), scale.contiguous().data_ptr(),
+                                              offset.contiguous().data_ptr(), g.data_ptr(), grad_x.data_ptr(),
+                                              grad_s.data_ptr(), v.numel(), C, epc, int(clip_min), int(clip_max),
+                                              int(rounding), _stream()))
+        return [grad_x, grad_s]
+
+    # ---- floating ----------------------------------------------------------------------------
+    @ staticmethod
+    def QuantizeTensor_FT(value, scale, offset, exponent: int, mantissa: int, clip_min: float, clip_max: float,
+                          rounding: int) -> torch.Tensor:
+        _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset')
+        v = value.contiguous()
+        out = torch.empty_like(v)
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_fq_float_t(v.data_ptr(), scale.data_ptr(), offset.data_ptr(), out.data_ptr(),
+                                         v.numel(), int(exponent), int(mantissa), float(clip_min), float(clip_max),
+                                         int(rounding), _stream()))
+        return out
+
+    @ staticmethod
+    def QuantizeTensor_FC(value, scale, offset, exponent: int, mantissa: int, clip_min: float, clip_max: float,
+                          channel_axis: int, rounding: int) -> torch.Tensor:
+        _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset')
+        v = value.contiguous()
+        C, epc = _geometry(v.shape, channel_axis)
+        out = torch.empty_like(v)
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_fq_float_c(v.data_ptr(), scale.contiguous().data_ptr(), offset.contiguous().data_ptr(),
+                                         out.data_ptr(), v.numel(), C, epc, int(exponent), int(mantissa),
+                                         float(clip_min), float(clip_max), int(rounding), _stream()))
+        return out
+
+    @ staticmethod
+    def QuantizeTensor_FT_B(value, scales, offsets, grad_y, exponent: int, mantissa: int, clip_min: float,
+                            clip_max: float, rounding: int) -> List[torch.Tensor]:
+        _f32(value, 'Value'); _f32(scales, 'Scale'); _f32(offsets, 'Offset'); _f32(grad_y, 'Gard')
+        v = value.contiguous(); g = grad_y.contiguous()
+        grad_x = torch.empty_like(g); grad_s = torch.empty_like(scales)
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_fq_float_c_bwd(v.data_ptr(), scales.data_ptr(), offsets.data_ptr(), g.data_ptr(),
+                                             grad_x.data_ptr(), grad_s.data_ptr(), v.numel(), 1, v.numel(),
+                                             int(exponent), int(mantissa), float(clip_min), float(clip_max),
+                                             int(rounding), _stream()))
+        return [grad_x, grad_s]
+
+    @ staticmethod
+    def QuantizeTensor_FC_B(value, scales, offsets, grad_y, exponent: int, mantissa: int, clip_min: float,
+                            clip_max: float, rounding: int, channel_axis: int) -> List[torch.Tensor]:
+        _f32(value, 'Value'); _f32(scales, 'Scale'); _f32(offsets, 'Offset'); _f32(grad_y, 'Gard')
+        v = value.contiguous(); g = grad_y.contiguous()
+        C, epc = _geometry(v.shape, channel_axis)
+        grad_x = torch.empty_like(g); grad_s = torch.empty_like(scales.contiguous())
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_fq_float_c_bwd(v.data_ptr(), scales.contiguous().data_ptr(),
+                                             offsets.contiguous().data_ptr(), g.data_ptr(), grad_x.data_ptr(),
+                                             grad_s.data_ptr(), v.numel(), C, epc, int(exponent), int(mantissa),
+                                             float(clip_min), float(clip_max), int(rounding), _stream()))
+        return [grad_x, grad_s]
+
+    # ---- histograms / order statistics -------------------------------------------------------
+    @ staticmethod
+    def _check_hist(hist):
+        _check(hist, torch.int32, 'Histogram(Expect to be INT32)')
+        if not hist.is_contiguous():
+            raise RuntimeError(_KERNEL_FAILURE + 'Histogram must be contiguous (it is accumulated in place)')
+
+    @ staticmethod
+    def Histogram_T(value, hist_scale: float, clip_outliers: bool, hist) -> None:
+        _f32(value, 'Value'); _HipExtension._check_hist(hist)
+        v = value.contiguous()
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_hist_sym_t(v.data_ptr(), v.numel(), float(hist_scale), int(bool(clip_outliers)),
+                                         hist.data_ptr(), hist.numel(), _stream()))
+
+    @ staticmethod
+    def Histogram_Asymmetric_T(min: float, max: float, value, clip_outliers: bool, hist) -> None:
+        _f32(value, 'Value'); _HipExtension._check_hist(hist)
+        v = value.contiguous()
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_hist_asym_t(v.data_ptr(), v.numel(), float(min), float(max),
+                                          int(bool(clip_outliers)), hist.data_ptr(), hist.numel(), _stream()))
+
+    @ staticmethod
+    def Histogram_C(value, channel_axis: int, hist_scale: float, clip_outliers: bool, hist) -> None:
+        _f32(value, 'Value'); _HipExtension._check_hist(hist)
+        v = value.contiguous()
+        C, epc = _geometry(v.shape, channel_axis)
+        if hist.numel() % C != 0:
+            raise RuntimeError(_KERNEL_FAILURE + 'Histogram shape is invalid.')
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_hist_sym_c(v.data_ptr(), v.numel(), C, epc, float(hist_scale),
+                                         int(bool(clip_outliers)), hist.data_ptr(), hist.numel() // C, _stream()))
+
+    @ staticmethod
+    def Quantile_T(source, q: float) -> torch.Tensor:
+        _f32(source, 'Value')
+        v = source.contiguous()
+        dest = torch.empty(2, dtype=torch.float32, device=v.device)
+        with _DeviceOf(v):
+            ws = _workspace(v.device, lib.ppqhip_quantile_workspace_bytes(v.numel()))
+            _raise(lib.ppqhip_quantile_t(v.data_ptr(), v.numel(), float(q), dest.data_ptr(), ws.data_ptr(),
+                                         _stream()))
+        return dest
+
+    @ staticmethod
+    def Isotone_T(source) -> torch.Tensor:
+        _f32(source, 'Value')
+        v = source.contiguous()
+        dest = torch.empty(4, dtype=torch.float32, device=v.device)
+        with _DeviceOf(v):
+            ws = _workspace(v.device, lib.ppqhip_quantile_workspace_bytes(v.numel()))
+            _raise(lib.ppqhip_isotone_t(v.data_ptr(), v.numel(), dest.data_ptr(), ws.data_ptr(), _stream()))
+        return dest
+
+    # ---- training helpers (no caller in ppq) --------------------------------------------------
+    @ staticmethod
+    def TensorClip_T(value, reference, limit) -> torch.Tensor:
+        _f32(value, 'Value'); _f32(reference, 'Reference'); _f32(limit, 'Limit')
+        v = value.contiguous(); r = reference.contiguous()
+        out = torch.empty_like(v)
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_tensor_clip_t(v.data_ptr(), r.data_ptr(), limit.data_ptr(), out.data_ptr(), v.numel(),
+                                            _stream()))
+        return out
+
+    @ staticmethod
+    def TensorClip_C(value, reference, limit, channel_axis: int) -> torch.Tensor:
+        _f32(value, 'Value'); _f32(reference, 'Reference'); _f32(limit, 'Limit')
+        v = value.contiguous(); r = reference.contiguous()
+        C, epc = _geometry(v.shape, channel_axis)
+        out = torch.empty_like(v)
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_tensor_clip_c(v.data_ptr(), r.data_ptr(), limit.contiguous().data_ptr(), out.data_ptr(),
+                                            v.numel(), C, epc, _stream()))
+        return out
+
+    @ staticmethod
+    def RoundingLoss_LT(value, scale, offset, clip_min: int, clip_max: int, rounding: int) -> torch.Tensor:
+        _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset')
+        v = value.contiguous()
+        loss = torch.empty(1, dtype=torch.float32, device=v.device)
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_rounding_loss(v.data_ptr(), scale.data_ptr(), offset.data_ptr(), loss.data_ptr(),
+                                            v.numel(), 0, 1, int(clip_min), int(clip_max), int(rounding), _stream()))
+        return loss
+
+    @ staticmethod
+    def RoundingLoss_LC(value, scale, offset, clip_min: int, clip_max: int, channel_axis: int,
+                        rounding: int) -> torch.Tensor:
+        _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset')
+        v = value.contiguous()
+        C, epc = _geometry(v.shape, channel_axis)
+        loss = torch.empty(1, dtype=torch.float32, device=v.device)
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_rounding_loss(v.data_ptr(), scale.contiguous().data_ptr(),
+                                            offset.contiguous().data_ptr(), loss.data_ptr(), v.numel(), C, epc,
+                                            int(clip_min), int(clip_max), int(rounding), _stream()))
+        return loss
+
+    @ staticmethod
+    def RoundingLoss_LT_B(value, dy, scale, offset, clip_min: int, clip_max: int, rounding: int) -> torch.Tensor:
+        _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset'); _f32(dy, 'Gard')
+        v = value.contiguous()
+        dx = torch.empty_like(v)
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_rounding_loss_bwd(v.data_ptr(), dy.data_ptr(), scale.data_ptr(), offset.data_ptr(),
+                                                dx.data_ptr(), v.numel(), 0, 1, int(clip_min), int(clip_max),
+                                                int(rounding), _stream()))
+        return dx
+
+    @ staticmethod
+    def RoundingLoss_LC_B(value, dy, scale, offset, clip_min: int, clip_max: int, channel_axis: int,
+                          rounding: int) -> torch.Tensor:
+        _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset'); _f32(dy, 'Gard')
+        v = value.contiguous()
+        C, epc = _geometry(v.shape, channel_axis)
+        dx = torch.empty_like(v)
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_rounding_loss_bwd(v.data_ptr(), dy.data_ptr(), scale.contiguous().data_ptr(),
+                                                offset.contiguous().data_ptr(), dx.data_ptr(), v.numel(), C, epc,
+                                                int(clip_min), int(clip_max), int(rounding), _stream()))
+        return dx
+
+    @ staticmethod
+    def compute_mse_loss(hist: list, start: int, step: int, end: int) -> float:
+        import ctypes
+        arr = (ctypes.c_int64 * len(hist))(*[int(v) for v in hist])
+        return float(lib.ppqhip_mse_loss_host(arr, len(hist), int(start), int(step), int(end)))
+
+    # ---- MI355X-native additions (no twin in export.cc) -----------------------------------------
+    @ staticmethod
+    def MinMax_T(value, minmax) -> None:
+        """minmax: float32[2] on the GPU, accumulated in place; seed with [+inf, -inf]."""
+        _f32(value, 'Value'); _f32(minmax, 'MinMax')
+        v = value.contiguous()
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_minmax_t(v.data_ptr(), v.numel(), minmax.data_ptr(), _stream()))
+
+    @ staticmethod
+    def MinMax_C(value, channel_axis: int, mins, maxs) -> None:
+        _f32(value, 'Value'); _f32(mins, 'Mins'); _f32(maxs, 'Maxs')
+        v = value.contiguous()
+        C, epc = _geometry(v.shape, channel_axis)
+        if mins.numel() != C or maxs.numel() != C:
+            raise RuntimeError(_KERNEL_FAILURE + f'mins / maxs need {C} elements')
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_minmax_c(v.data_ptr(), v.numel(), C, epc, mins.data_ptr(), maxs.data_ptr(), _stream()))
+
+    @ staticmethod
+    def KL_Losses(hist, num_of_bits: int) -> torch.Tensor:
+        """hist: int32 [num_hist, bins] (or [bins]) -> float64 [num_hist, candidates]."""
+        _check(hist, torch.int32, 'Histogram(Expect to be INT32)')
+        h = hist.contiguous().reshape(-1, hist.shape[-1])
+        ncand = lib.ppqhip_kl_num_candidates(h.shape[1], int(num_of_bits))
+        if ncand <= 0:
+            raise RuntimeError(_KERNEL_FAILURE + 'histogram length must be a multiple of 2^(num_of_bits-1)')
+        losses = torch.empty((h.shape[0], ncand), dtype=torch.float64, device=h.device)
+        with _DeviceOf(h):
+            _raise(lib.ppqhip_kl_losses(h.data_ptr(), h.shape[0], h.shape[1], int(num_of_bits), losses.data_ptr(),
+                                        _stream()))
+        return losses
+
+    @ staticmethod
+    def MSE_Search(hist, hist_scale, min_value, quant_min: int, quant_max: int, symmetrical: bool) -> torch.Tensor:
+        """hist: int32 [num_hist, bins]; hist_scale / min_value: float64 [num_hist] on the GPU.
+        Returns int32 [num_hist, 4] = (start, end, step, candidate index) of the first minimum."""
+        _check(hist, torch.int32, 'Histogram(Expect to be INT32)')
+        _check(hist_scale, torch.float64, 'HistScale(Expect to be FP64)')
+        _check(min_value, torch.float64, 'Min(Expect to be FP64)')
+        h = hist.contiguous().reshape(-1, hist.shape[-1])
+        best = torch.empty((h.shape[0], 4), dtype=torch.int32, device=h.device)
+        with _DeviceOf(h):
+            ws = _workspace(h.device, lib.ppqhip_mse_search_workspace_bytes(h.shape[0]))
+            _raise(lib.ppqhip_mse_search(h.data_ptr(), h.shape[0], h.shape[1], hist_scale.contiguous().data_ptr(),
+                                         min_value.contiguous().data_ptr(), int(quant_min), int(quant_max),
+                                         int(bool(symmetrical)), best.data_ptr(), ws.data_ptr(), _stream()))
+        return best
+
+    @ staticmethod
+    def QuantizeTensor_LT_Histogram(value, scale, offset, clip_min: int, clip_max: int, rounding: int,
+                                    hist_scale: float, clip_outliers: bool, hist) -> torch.Tensor:
+        """Fused: returns QuantizeTensor_LT(value ...) and accumulates Histogram_T(value ...) into hist."""
+        _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset'); _HipExtension._check_hist(hist)
+        v = value.contiguous()
+        out = torch.empty_like(v)
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_fq_linear_t_hist_sym(v.data_ptr(), scale.data_ptr(), offset.data_ptr(), out.data_ptr(),
+                                                   v.numel(), int(clip_min), int(clip_max), int(rounding),
+                                                   float(hist_scale), int(bool(clip_outliers)), hist.data_ptr(),
+                                                   hist.numel(), _stream()))
+        return out
+
+
+HIP_EXTENSION = _HipExtension()
+
+
+class ComplieHelper:
+    """Counterpart of ppq.core.ffi.ComplieHelper (ffi.py:16-49): nothing is JIT-compiled here, the
+    library is built ahead of time (``__graft_entry__.build()``) and loaded by ``ppq_amd._lib``."""
+    def __init__(self) -> None:
+        self.__CUDA_EXTENTION__ = HIP_EXTENSION
+
+    def complie(self):
+        self.__CUDA_EXTENTION__ = HIP_EXTENSION
+
+    @ property
+    def CUDA_EXTENSION(self):
+        return self.__CUDA_EXTENTION__
+
+
+CUDA_COMPLIER = ComplieHelper()
+
+
+def install_into_ppq() -> None:
+    """Route an importable, unmodified PPQ through these kernels: the two lines a PPQ user adds.
+    (`CUDA_COMPLIER.complie()` must NOT be called -- it would JIT-build ppq/csrc with nvcc.)"""
+    from ppq.core import PPQ_CONFIG as REF_CONFIG
+    from ppq.core.ffi import CUDA_COMPLIER as REF_COMPLIER
+    REF_COMPLIER.__CUDA_EXTENTION__ = HIP_EXTENSION
+    REF_CONFIG.USING_CUDA_KERNEL = True
+
+
+class CUDA:
+    """Mirror of ppq.core.ffi.CUDA (ffi.py:51-350): same names, argument order and defaults."""
+
+    @ staticmethod
+    def LinearQuantize_T(tensor, scales, offsets, minimum: int = -128, maximum: int = 127, rounding: int = 0):
+        return HIP_EXTENSION.QuantizeTensor_LT(tensor, scales, offsets, minimum, maximum, rounding)
+
+    @ staticmethod
+    def LinearQuantize_C(tensor, scales, offsets, channel_axis: int, minimum: int = -128, maximum: int = 127,
+                         rounding: int = 0):
+        return HIP_EXTENSION.QuantizeTensor_LC(tensor, scales, offsets, minimum, maximum, channel_axis, rounding)
+
+    @ staticmethod
+    def LinearQuantize_T_B(tensor, scales, offsets, dy, minimum: int, maximum: int, rounding: int):
+        return HIP_EXTENSION.QuantizeTensor_LT_B(tensor, scales, offsets, dy, minimum, maximum, rounding)
+
+    @ staticmethod
+    def LinearQuantize_C_B(tensor, scales, offsets, dy, minimum: int, maximum: int, channel_axis: int, rounding: int):
+        return HIP_EXTENSION.QuantizeTensor_LC_B(tensor, scales, offsets, dy, minimum, maximum, rounding, channel_axis)
+
+    @ staticmethod
+    def Histogram_T(tensor, histogram, scale: float, clip_outliers: bool = True):
+        HIP_EXTENSION.Histogram_T(tensor, scale, clip_outliers, histogram)
+        return histogram
+
+    @ staticmethod
+    def Histogram_Asymmetric_T(min_value: float, max_value: float, tensor, histogram, clip_outliers: bool = True):
+        HIP_EXTENSION.Histogram_Asymmetric_T(min_value, max_value, tensor, clip_outliers, histogram)
+        return histogram
+
+    @ staticmethod
+    def Histogram_C(tensor, channel_axis: int, histogram, scale: float, clip_outliers: bool = True):
+        HIP_EXTENSION.Histogram_C(tensor, channel_axis, scale, clip_outliers, histogram)
+        return histogram
+
+    @ staticmethod
+    def Quantile(tensor, q: float):
+        return HIP_EXTENSION.Quantile_T(tensor, q)
+
+    @ staticmethod
+    def Isotone(tensor):
+        return HIP_EXTENSION.Isotone_T(tensor)
+
+    @ staticmethod
+    def TensorClip_T(tensor, reference, limit):
+        return HIP_EXTENSION.TensorClip_T(tensor, reference, limit)
+
+    @ staticmethod
+    def TensorClip_C(tensor, reference, limit, channel_axis: int):
+        return HIP_EXTENSION.TensorClip_C(tensor, reference, limit, channel_axis)
+
+    @ staticmethod
+    def RoundingLoss_LT(tensor, scales, offsets, minimum: int = -128, maximum: int = 127, rounding: int = 0):
+        return HIP_EXTENSION.RoundingLoss_LT(tensor, scales, offsets, minimum, maximum, rounding)
+
+    @ staticmethod
+    def RoundingLoss_LT_B(tensor, dy, scales, offsets, minimum: int = -128, maximum: int = 127, rounding: int = 0):
+        return HIP_EXTENSION.RoundingLoss_LT_B(tensor, dy, scales, offsets, minimum, maximum, rounding)
+
+    @ staticmethod
+    def RoundingLoss_LC(tensor, scales, offsets, channel_axis: int, minimum: int = -128, maximum: int = 127,
+                        rounding: int = 0):
+        return HIP_EXTENSION.RoundingLoss_LC(tensor, scales, offsets, minimum, maximum, channel_axis, rounding)
+
+    @ staticmethod
+    def RoundingLoss_LC_B(tensor, dy, scales, offsets, channel_axis: int, minimum: int = -128, maximum: int = 127,
+                          rounding: int = 0):
+        return HIP_EXTENSION.RoundingLoss_LC_B(tensor, dy, scales, offsets, minimum, maximum, channel_axis, rounding)
+
+    @ staticmethod
+    def compute_mse_loss(histogram: list, start: int, step: int, end: int) -> float:
+        return HIP_EXTENSION.compute_mse_loss(histogram, start, step, end)
+
+    @ staticmethod
+    def FloatingQuantize_T(tensor, scales, offsets, exponent: int = 4, mantissa: int = 3, minimum: float = -448,
+                           maximum: float = +448, rounding: int = 0):
+        if exponent <= 0: raise ValueError('Floating Quantization requires exponent > 0')
+        return HIP_EXTENSION.QuantizeTensor_FT(tensor, scales, offsets, exponent, mantissa, minimum, maximum, rounding)
+
+    @ staticmethod
+    def FloatingQuantize_C(tensor, scales, offsets, channel_axis: int, exponent: int = 4, mantissa: int = 3,
+                           minimum: float = -448, maximum: float = +448, rounding: int = 0):
+        if exponent <= 0: raise ValueError('Floating Quantization requires exponent > 0')
+        return HIP_EXTENSION.QuantizeTensor_FC(tensor, scales, offsets, exponent, mantissa, minimum, maximum,
+                                               channel_axis, rounding)
+
+    @ staticmethod
+    def FloatingQuantize_T_B(tensor, scales, offsets, dy, exponent: int, mantissa: int, minimum: float,
+                             maximum: float, rounding: int):
+        return HIP_EXTENSION.QuantizeTensor_FT_B(tensor, scales, offsets, dy, exponent, mantissa, minimum, maximum,
+                                                 rounding)
+
+    @ staticmethod
+    def FloatingQuantize_C_B(tensor, scales, offsets, dy, exponent: int, mantissa: int, minimum: float,
+                             maximum: float, channel_axis: int, rounding: int):
+        return HIP_EXTENSION.QuantizeTensor_FC_B(tensor, scales, offsets, dy, exponent, mantissa, minimum, maximum,
+                                                 rounding, channel_axis)
+
+    # ---- additions ------------------------------------------------------------------------------
+    @ staticmethod
+    def MinMax_T(tensor, minmax):
+        HIP_EXTENSION.MinMax_T(tensor, minmax)
+        return minmax
+
+    @ staticmethod
+    def MinMax_C(tensor, channel_axis: int, mins, maxs):
+        HIP_EXTENSION.MinMax_C(tensor, channel_axis, mins, maxs)
+        return mins, maxs
+
+    @ staticmethod
+    def KLLosses(histogram, num_of_bits: int = 8):
+        return HIP_EXTENSION.KL_Losses(histogram, num_of_bits)
+
+    @ staticmethod
+    def MseSearch(histogram, hist_scale, min_value, quant_min: int, quant_max: int, symmetrical: bool):
+        return HIP_EXTENSION.MSE_Search(histogram, hist_scale, min_value, quant_min, quant_max, symmetrical)
+
+    @ staticmethod
+    def LinearQuantize_T_Histogram(tensor, scales, offsets, histogram, hist_scale: float, minimum: int = -128,
+                                   maximum: int = 127, rounding: int = 0, clip_outliers: bool = True):
+        return HIP_EXTENSION.QuantizeTensor_LT_Histogram(tensor, scales, offsets, minimum, maximum, rounding,
+                                                         hist_scale, clip_outliers, histogram)
+
+    @ staticmethod
+    def Sync():
+        """Synchronize device (ffi.py:347-350)."""
+        torch.cuda.synchronize()

@@ -1,0 +1,259 @@
+"""Generate golden vectors by importing the REFERENCE (OpenPPL/ppq @ /root/reference) itself.
+
+Run in the build container only (the reference does not exist on the GPU box):
+
+    python tests/golden/make_golden.py
+
+Everything is produced by the reference's own PyTorch-CPU path (`USING_CUDA_KERNEL=False`),
+i.e. the very code tests/test_cuda_kernel.py uses as the bit-exact yardstick for the CUDA
+kernels.  Outputs (committed, all small):
+
+    tests/golden/linear_fq.npz        per-tensor / per-channel linear fake-quant
+    tests/golden/rounding.npz         ppq_tensor_round / ppq_numerical_round tables
+    tests/golden/observers.npz        minmax / percentile / kl / mse observer results
+
+Import shims (the container has no onnx and a newer protobuf/numpy than ppq expects):
+stub `onnx*` modules, PROTOCOL_BUFFERS_PYTHON_IMPLEMENTATION=python, and a float() cast in
+front of ppq_numerical_round (numpy>=2 no longer promotes np.float32/float to a Python float;
+the cast is bit-identical to numpy-1 behaviour).
+"""
+import importlib.machinery
+import os
+import sys
+from unittest.mock import MagicMock
+
+os.environ['PROTOCOL_BUFFERS_PYTHON_IMPLEMENTATION'] = 'python'
+sys.dont_write_bytecode = True
+for _name in ['onnx', 'onnx.helper', 'onnx.numpy_helper', 'onnx.mapping', 'onnx.onnx_pb', 'onnx.checker',
+              'onnx.external_data_helper', 'onnx.shape_inference', 'onnx.version_converter']:
+    _m = MagicMock(); _m.__spec__ = importlib.machinery.ModuleSpec(_name, None); _m.__path__ = []
+    sys.modules[_name] = _m
+sys.path.insert(0, '/root/reference')
+
+import numpy as np
+import torch
+
+import ppq  # noqa: E402  (the reference)
+from ppq.core import (PPQ_CONFIG, QuantizationPolicy, QuantizationProperty, QuantizationStates,
+                      RoundingPolicy, TensorQuantizationConfig)
+from ppq.IR import Variable
+from ppq.quantization.observer import range as ref_range
+from ppq.quantization.observer import (TorchHistObserver, TorchMinMaxObserver, TorchMSEObserver,
+                                       TorchPercentileObserver)
+from ppq.quantization.qfunction import PPQLinearQuantFunction
+from ppq.utils.round import ppq_numerical_round, ppq_round_to_power_of_2, ppq_tensor_round
+
+assert PPQ_CONFIG.USING_CUDA_KERNEL is False
+_orig_round = ref_range.ppq_numerical_round
+ref_range.ppq_numerical_round = lambda v, *a, **k: _orig_round(float(v), *a, **k)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+P = QuantizationProperty
+
+
+def tqc(per_channel=False, sym=True, qmin=-128, qmax=127, bits=8, axis=None, algo='minmax', pow2=False,
+        rounding=RoundingPolicy.ROUND_HALF_EVEN, detail=None):
+    pol = P.LINEAR + (P.PER_CHANNEL.value if per_channel else P.PER_TENSOR.value) \
+        + (P.SYMMETRICAL.value if sym else P.ASYMMETRICAL.value) + (P.POWER_OF_2.value if pow2 else 0)
+    return TensorQuantizationConfig(policy=QuantizationPolicy(pol), rounding=rounding, num_of_bits=bits,
+                                    quant_min=qmin, quant_max=qmax, observer_algorithm=algo,
+                                    channel_axis=axis, detail=detail)
+
+
+def gen_linear():
+    out = {}
+    g = torch.Generator().manual_seed(20250117)
+    cases = []
+    # the shape / distribution matrix of tests/test_cuda_kernel.py:145-169 (big shapes shrunk to keep the fixture small)
+    shapes_t = [[1, 1, 1, 1], [5, 12, 13, 4], [1, 7, 15, 41], [10, 12, 13, 4], [2, 7, 15, 41],
+                [9, 7, 130, 1], [12, 4, 15, 3], [101, 7, 7, 1], [225, 1, 10, 4], [3, 10, 12, 47], [5, 42, 15, 3]]
+    for i, shp in enumerate(shapes_t):
+        for sym in (True, False):
+            t = torch.rand(size=shp, generator=g) * 32
+            s = torch.rand(size=[1], generator=g)
+            o = torch.zeros(size=[1]) if sym else torch.randint(0, 255, size=[1], generator=g).float()
+            cases.append(('t', t, s, o, None, 0, 255, RoundingPolicy.ROUND_HALF_EVEN))
+    shapes_c = [([1, 1, 1, 1], 1), ([5, 12, 13, 4], 1), ([1, 7, 15, 41], 1), ([10, 12, 13, 4], 1),
+                ([2, 7, 15, 41], 1), ([9, 7, 130, 1], 1), ([12, 4, 15, 3], 1), ([101, 7, 7, 1], 0),
+                ([225, 1, 10, 4], 0), ([3, 10, 12, 47], 3), ([5, 42, 15, 3], 3), ([64, 3, 7, 7], 0),
+                ([2, 97, 48], 2)]
+    for shp, c in shapes_c:
+        for sym in (True, False):
+            t = torch.rand(size=shp, generator=g) * 32
+            s = torch.rand(size=[shp[c]], generator=g)
+            o = torch.zeros(size=[shp[c]]) if sym else torch.randint(0, 255, size=[shp[c]], generator=g).float()
+            cases.append(('c', t, s, o, c, 0, 255, RoundingPolicy.ROUND_HALF_EVEN))
+    # signed int8 / int4 on randn, all torch-supported rounding policies
+    for pol in [RoundingPolicy.ROUND_HALF_EVEN, RoundingPolicy.ROUND_HALF_UP, RoundingPolicy.ROUND_HALF_DOWN,
+                RoundingPolicy.ROUND_HALF_TOWARDS_ZERO, RoundingPolicy.ROUND_HALF_FAR_FORM_ZERO,
+                RoundingPolicy.ROUND_UP]:
+        for (qmin, qmax) in [(-128, 127), (-8, 7), (0, 15)]:
+            t = torch.randn(size=[3, 8, 9, 5], generator=g) * 3
+            s = torch.rand(size=[1], generator=g) * 0.1 + 0.01
+            o = torch.zeros(size=[1]) if qmin < 0 else torch.tensor([float((qmax + 1) // 2)])
+            cases.append(('t', t, s, o, None, qmin, qmax, pol))
+            sc = torch.rand(size=[8], generator=g) * 0.1 + 0.01
+            oc = torch.zeros(size=[8]) if qmin < 0 else torch.randint(0, qmax, size=[8], generator=g).float()
+            cases.append(('c', t, sc, oc, 1, qmin, qmax, pol))
+    # exact .5 ties (x = k/2 * s with s a power of two)
+    t = (torch.arange(-600, 600).float() / 2.0) * 0.25
+    cases.append(('t', t.reshape(2, 600), torch.tensor([0.25]), torch.tensor([0.0]), None, -128, 127,
+                  RoundingPolicy.ROUND_HALF_EVEN))
+    cases.append(('t', t.reshape(2, 600), torch.tensor([0.25]), torch.tensor([3.0]), None, 0, 255,
+                  RoundingPolicy.ROUND_HALF_EVEN))
+
+    out['n_cases'] = np.array(len(cases))
+    for i, (kind, t, s, o, c, qmin, qmax, pol) in enumerate(cases):
+        cfg = tqc(per_channel=(kind == 'c'), sym=True, qmin=qmin, qmax=qmax, axis=c, rounding=pol)
+        cfg._scale, cfg._offset = s if kind == 'c' else s.squeeze(0), o if kind == 'c' else o.squeeze(0)
+        cfg.state = QuantizationStates.ACTIVATED
+        y = PPQLinearQuantFunction(t, cfg)
+        out[f'{i}_kind'] = np.array(kind); out[f'{i}_x'] = t.numpy(); out[f'{i}_s'] = s.numpy()
+        out[f'{i}_o'] = o.numpy(); out[f'{i}_axis'] = np.array(-1 if c is None else c)
+        out[f'{i}_q'] = np.array([qmin, qmax]); out[f'{i}_rounding'] = np.array(pol.value)
+        out[f'{i}_y'] = y.numpy()
+    # BASELINE.md parity anchor (config 1)
+    torch.manual_seed(0)
+    x = torch.randn(1, 3, 224, 224)
+    cfg = tqc(sym=True, qmin=-128, qmax=127)
+    ob = TorchMinMaxObserver(Variable('x'), cfg); ob.observe(x); ob.render_quantization_config()
+    y = PPQLinearQuantFunction(x, cfg)
+    out['anchor_scale'] = np.array(float(cfg.scale.double()))
+    out['anchor_scale_f32'] = cfg.scale.numpy()
+    out['anchor_sum'] = np.array(float(y.double().sum()))
+    out['anchor_maxerr'] = np.array(float((y - x).abs().max()))
+    np.savez_compressed(os.path.join(HERE, 'linear_fq.npz'), **out)
+    print('linear_fq.npz', len(cases), 'cases; anchor scale', out['anchor_scale'], 'sum', out['anchor_sum'])
+
+
+def gen_rounding():
+    out = {}
+    grid = torch.cat([torch.arange(-40, 41).float() / 4.0,
+                      torch.tensor([0.49999997, -0.49999997, 1e-8, -1e-8, 8388607.5, -8388607.5, 1e9, -1e9]),
+                      torch.randn(200, generator=torch.Generator().manual_seed(7)) * 50])
+    out['grid'] = grid.numpy()
+    for pol in RoundingPolicy:
+        if pol == RoundingPolicy.ROUND_TO_NEAR_INT: continue
+        out[f'tensor_{pol.value}'] = ppq_tensor_round(grid, pol).numpy()
+    vals = [1.5, 2.5, 0.5, -0.5, 1.1, 1.2, 1.3, -1.1, -1.2, -1.3, 3.5, -2.5, -1.5, 0.0, 7.49999, -7.5000001]
+    out['num_values'] = np.array(vals)
+    for pol in RoundingPolicy:
+        out[f'num_{pol.value}'] = np.array([ppq_numerical_round(float(v), pol) for v in vals])
+    p2 = [1.0, 1.2, 3.2, 0.26, 0.24, 0.5, 1e-8, 3e-5, 0.0078125, 100.0, -0.3]
+    out['pow2_values'] = np.array(p2)
+    out['pow2_up'] = np.array([ppq_round_to_power_of_2(v, RoundingPolicy.ROUND_UP) for v in p2])
+    out['pow2_half_up'] = np.array([ppq_round_to_power_of_2(v, RoundingPolicy.ROUND_HALF_UP) for v in p2])
+    np.savez_compressed(os.path.join(HERE, 'rounding.npz'), **out)
+    print('rounding.npz')
+
+
+def gen_observers():
+    out = {}
+    g = torch.Generator().manual_seed(42)
+    batches = [torch.randn(2, 16, 14, 14, generator=g) * (1 + 0.1 * i) + 0.2 for i in range(4)]
+    relu_batches = [torch.relu(b) for b in batches]
+    out['batches'] = torch.stack(batches).numpy()
+
+    def run(cls, cfg, data, two_phase=False, **kw):
+        ob = cls(Variable('x'), cfg, **kw)
+        for b in data: ob.observe(b)
+        ob.render_quantization_config()
+        if two_phase:
+            for b in data: ob.observe(b)
+            ob.render_quantization_config()
+        return ob
+
+    # --- minmax (per tensor / per channel, sym / asym, int8 / int4, pow2)
+    k = 0
+    for data_name, data in (('randn', batches), ('relu', relu_batches)):
+        for per_channel in (False, True):
+            for sym in (True, False):
+                for (qmin, qmax, bits) in ((-128, 127, 8), (0, 255, 8), (-8, 7, 4)):
+                    for pow2 in (False, True):
+                        if pow2 and per_channel and not sym: pass
+                        cfg = tqc(per_channel, sym, qmin, qmax, bits, axis=1 if per_channel else None, pow2=pow2)
+                        run(TorchMinMaxObserver, cfg, data)
+                        out[f'minmax_{k}_meta'] = np.array([data_name == 'relu', per_channel, sym, qmin, qmax, bits, pow2])
+                        out[f'minmax_{k}_scale'] = cfg.scale.numpy(); out[f'minmax_{k}_offset'] = cfg.offset.numpy()
+                        k += 1
+    out['minmax_n'] = np.array(k)
+
+    # --- percentile (CPU path: kthvalue, int(n*q) index)
+    k = 0
+    for data_name, data in (('randn', batches), ('relu', relu_batches)):
+        for sym in (True, False):
+            for pct in (0.9999, 0.999, 0.99):
+                cfg = tqc(False, sym, -128 if sym else 0, 127 if sym else 255, algo='percentile',
+                          detail={'OBSERVER_PERCENTILE_MANUL_OVERRIDE': pct})
+                run(TorchPercentileObserver, cfg, data)
+                out[f'pct_{k}_meta'] = np.array([data_name == 'relu', sym, pct])
+                out[f'pct_{k}_scale'] = cfg.scale.numpy(); out[f'pct_{k}_offset'] = cfg.offset.numpy()
+                k += 1
+    out['pct_n'] = np.array(k)
+
+    # --- KL (two phase, symmetric per tensor); keep the torch.histc histogram for the oracle
+    k = 0
+    for data_name, data in (('randn', batches), ('relu', relu_batches)):
+        for bins in (2048, 4096, 512):
+            for bits in (8, 4):
+                for pow2 in (False, True):
+                    qmin, qmax = (-128, 127) if bits == 8 else (-8, 7)
+                    cfg = tqc(False, True, qmin, qmax, bits, algo='kl', pow2=pow2,
+                              detail={'OBSERVER_KL_HIST_BINS_MANUL_OVERRIDE': bins})
+                    ob = TorchHistObserver(Variable('x'), cfg)
+                    for b in data: ob.observe(b)
+                    ob.render_quantization_config()
+                    for b in data: ob.observe(b)
+                    hist = ob._hist.clone()
+                    ob.render_quantization_config()
+                    out[f'kl_{k}_meta'] = np.array([data_name == 'relu', bins, bits, pow2])
+                    out[f'kl_{k}_hist'] = hist.numpy().astype(np.int32)
+                    out[f'kl_{k}_hist_scale'] = np.array(ob._hist_scale, np.float64)
+                    out[f'kl_{k}_minmax'] = np.array([ob._min, ob._max], np.float64)
+                    out[f'kl_{k}_scale'] = cfg.scale.numpy()
+                    k += 1
+    # a synthetic long-tailed histogram whose best range is NOT the last candidate
+    hist = (np.exp(-np.arange(2048) / 90.0) * 50000).astype(np.int32); hist[1500:] = 0; hist[2047] = 3
+    cfg = tqc(False, True, -128, 127, 8, algo='kl', detail={'OBSERVER_KL_HIST_BINS_MANUL_OVERRIDE': 2048})
+    ob = TorchHistObserver(Variable('x'), cfg)
+    s, o = ob.hist_to_scale_offset(histogram=torch.tensor(hist), hist_bins=2048, hist_scale=0.01, config=cfg)
+    out[f'kl_{k}_meta'] = np.array([0, 2048, 8, 0]); out[f'kl_{k}_hist'] = hist
+    out[f'kl_{k}_hist_scale'] = np.array(0.01); out[f'kl_{k}_minmax'] = np.array([-20.48, 20.48])
+    out[f'kl_{k}_scale'] = np.array(s, np.float32)
+    k += 1
+    out['kl_n'] = np.array(k)
+
+    # --- MSE (two phase; pure-Python double loss loop == USING_CUDA_KERNEL False)
+    k = 0
+    for data_name, data in (('randn', batches), ('relu', relu_batches)):
+        for sym in (True, False):
+            for bins in (2048, 512):
+                qmin, qmax = (-128, 127) if sym else (0, 255)
+                cfg = tqc(False, sym, qmin, qmax, 8, algo='mse')
+                ob = TorchMSEObserver(Variable('x'), cfg, bins=bins)
+                for b in data: ob.observe(b)
+                ob.render_quantization_config()
+                for b in data: ob.observe(b)
+                hist = ob._hist.clone()
+                ob.render_quantization_config()
+                out[f'mse_{k}_meta'] = np.array([data_name == 'relu', sym, bins, qmin, qmax])
+                out[f'mse_{k}_hist'] = hist.numpy().astype(np.int32)
+                out[f'mse_{k}_hist_scale'] = np.array(ob._hist_scale, np.float64)
+                out[f'mse_{k}_minmax'] = np.array([ob._min, ob._max], np.float64)
+                out[f'mse_{k}_scale'] = cfg.scale.numpy(); out[f'mse_{k}_offset'] = cfg.offset.numpy()
+                # a few raw loss values of the Python loop
+                hl = hist.tolist()
+                probes = [(0, 1, 256), (8, 2, 520), (0, bins // 256 + 1, 256 * (bins // 256 + 1)), (16, 1, 272)]
+                out[f'mse_{k}_probes'] = np.array(probes)
+                out[f'mse_{k}_probe_loss'] = np.array([ob.compute_mse_loss(hl, s, st, e) for (s, st, e) in probes])
+                k += 1
+    out['mse_n'] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, 'observers.npz'), **out)
+    print('observers.npz', {n: int(out[n]) for n in ('minmax_n', 'pct_n', 'kl_n', 'mse_n')})
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(8)
+    gen_linear()
+    gen_rounding()
+    gen_observers()

@@ -1,0 +1,207 @@
+"""Pin the CPU oracle (oracle/) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py) and against the reference's own tests' known answers
+(/root/reference/tests/test_rounding.py, tests/test_cuda_kernel.py distributions)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ppq_oracle as O
+
+
+@pytest.fixture(scope='module')
+def linear(golden_dir):
+    return np.load(os.path.join(golden_dir, 'linear_fq.npz'))
+
+
+@pytest.fixture(scope='module')
+def observers(golden_dir):
+    return np.load(os.path.join(golden_dir, 'observers.npz'))
+
+
+@pytest.fixture(scope='module')
+def rounding(golden_dir):
+    return np.load(os.path.join(golden_dir, 'rounding.npz'))
+
+
+def test_linear_fq_bit_exact(linear):
+    n = int(linear['n_cases'])
+    assert n >= 80
+    for i in range(n):
+        kind = str(linear[f'{i}_kind']); x = linear[f'{i}_x']; s = linear[f'{i}_s']; o = linear[f'{i}_o']
+        qmin, qmax = [int(v) for v in linear[f'{i}_q']]; r = int(linear[f'{i}_rounding'])
+        if kind == 't':
+            y = O.fq_linear_t(x, s, o, qmin, qmax, r)
+        else:
+            y = O.fq_linear_c(x, s, o, int(linear[f'{i}_axis']), qmin, qmax, r)
+        ref = linear[f'{i}_y']
+        assert y.shape == ref.shape
+        assert np.array_equal(y.view(np.uint32), ref.view(np.uint32)), f'case {i} ({kind}, rounding {r}) differs'
+
+
+def test_config1_anchor(linear):
+    """BASELINE.md parity anchor: randn(1,3,224,224) seed 0, symmetric per-tensor int8 via minmax."""
+    import torch
+    torch.manual_seed(0)
+    x = torch.randn(1, 3, 224, 224).numpy()
+    mm = O.minmax_t(x)
+    scale, offset = O.minmax_to_scale_offset(float(mm[0]), float(mm[1]), -128, 127, symmetrical=True)
+    s32 = np.float32(scale)
+    assert s32 == linear['anchor_scale_f32']
+    assert float(s32) == float(linear['anchor_scale']) == 0.035785846412181854
+    y = O.fq_linear_t(x, [s32], [offset], -128, 127, 0)
+    assert float(y.astype(np.float64).sum()) == pytest.approx(float(linear['anchor_sum']), rel=0, abs=1e-9)
+    assert float(np.abs(y - x).max()) == float(linear['anchor_maxerr'])
+
+
+def test_round2int_matches_tensor_round(rounding):
+    grid = rounding['grid']
+    for pol in (0, 1, 2, 3, 4, 6):
+        ref = rounding[f'tensor_{pol}']
+        for v, r in zip(grid, ref):
+            if abs(v) > 1e6 or abs(abs(v) - 0.49999997) < 1e-9:
+                continue   # float32-vs-double evaluation of floor(v + .5); see ppq_oracle.c header
+            assert O.round2int(float(v), pol) == int(r), (pol, v)
+
+
+def test_numerical_round_tables(rounding):
+    """tests/test_rounding.py:5-37 known answers + the generated tables."""
+    assert O.numerical_round(1.5, 0) == 2 and O.numerical_round(2.5, 0) == 2
+    assert O.numerical_round(0.5, 0) == 0 and O.numerical_round(-0.5, 0) == 0
+    assert [O.numerical_round(v, 0) for v in (1.1, 1.2, 1.3, -1.1, -1.2, -1.3)] == [1, 1, 1, -1, -1, -1]
+    assert [O.numerical_round(v, 1) for v in (1.5, 2.5, 0.5, -0.5)] == [2, 3, 1, 0]
+    assert [O.numerical_round(v, 2) for v in (1.5, 2.5, 0.5, -0.5)] == [1, 2, 0, -1]
+    assert [O.numerical_round(v, 3) for v in (1.5, 2.5, 0.5)] == [1, 2, 0]
+    assert O.round_to_power_of_2(1.0) == 1 and O.round_to_power_of_2(1.2) == 2
+    assert O.round_to_power_of_2(3.2) == 4 and O.round_to_power_of_2(0.26) == 0.5
+    assert O.round_to_power_of_2(0.24) == 0.25
+    vals = rounding['num_values']
+    for pol in range(7):
+        assert [O.numerical_round(float(v), pol) for v in vals] == list(rounding[f'num_{pol}'])
+    assert [O.round_to_power_of_2(float(v), 6) for v in rounding['pow2_values']] == list(rounding['pow2_up'])
+    assert [O.round_to_power_of_2(float(v), 1) for v in rounding['pow2_values']] == list(rounding['pow2_half_up'])
+
+
+def _batches(observers, relu):
+    b = observers['batches']
+    return np.maximum(b, 0) if relu else b
+
+
+def test_minmax_observer_scales(observers):
+    for k in range(int(observers['minmax_n'])):
+        relu, per_channel, sym, qmin, qmax, bits, pow2 = [int(v) for v in observers[f'minmax_{k}_meta']]
+        data = _batches(observers, relu)
+        if not per_channel:
+            mm = None
+            for b in data: mm = O.minmax_t(b, mm)
+            s, o = O.minmax_to_scale_offset(float(mm[0]), float(mm[1]), qmin, qmax, bool(sym), bool(pow2))
+            s = np.float32(s); o = np.float32(o)
+        else:
+            mins = maxs = None
+            for b in data: mins, maxs = O.minmax_c(b, 1, mins, maxs)
+            so = [O.minmax_to_scale_offset(float(a), float(b), qmin, qmax, bool(sym), bool(pow2), f32_inputs=True)
+                  for a, b in zip(mins, maxs)]
+            s = np.array([v[0] for v in so], np.float32); o = np.array([v[1] for v in so], np.float32)
+        assert np.array_equal(s, observers[f'minmax_{k}_scale']), k
+        assert np.array_equal(o, observers[f'minmax_{k}_offset']), k
+
+
+def test_percentile_observer_scales(observers):
+    for k in range(int(observers['pct_n'])):
+        relu, sym, pct = observers[f'pct_{k}_meta']
+        data = _batches(observers, bool(relu))
+        stats = np.stack([O.percentile_cpu(b, float(pct)) for b in data]).astype(np.float32)
+        mean = stats.mean(axis=0, dtype=np.float32)
+        qmin, qmax = (-128, 127) if sym else (0, 255)
+        s, o = O.minmax_to_scale_offset(float(mean[1]), float(mean[0]), qmin, qmax, bool(sym))
+        assert np.float32(s) == pytest.approx(observers[f'pct_{k}_scale'], rel=1e-6), k
+        assert np.float32(o) == observers[f'pct_{k}_offset'], k
+
+
+def test_kl_search_scales(observers):
+    for k in range(int(observers['kl_n'])):
+        relu, bins, bits, pow2 = [int(v) for v in observers[f'kl_{k}_meta']]
+        hist = observers[f'kl_{k}_hist']
+        assert hist.size == bins
+        s, o = O.kl_search(hist, float(observers[f'kl_{k}_hist_scale']), bits, bool(pow2))
+        assert np.float32(s) == pytest.approx(float(observers[f'kl_{k}_scale']), rel=1e-6), k
+        assert o == 0
+
+
+def test_mse_search_scales(observers):
+    for k in range(int(observers['mse_n'])):
+        relu, sym, bins, qmin, qmax = [int(v) for v in observers[f'mse_{k}_meta']]
+        hist = observers[f'mse_{k}_hist']
+        hs = float(observers[f'mse_{k}_hist_scale']); vmin = float(observers[f'mse_{k}_minmax'][0])
+        # the golden run used the double-precision Python loss loop (USING_CUDA_KERNEL False)
+        s, o = O.mse_search(hist, hs, vmin, qmin, qmax, bool(sym), use_float_kernel=False)
+        assert np.float32(s) == pytest.approx(float(observers[f'mse_{k}_scale']), rel=1e-6), k
+        assert np.float32(o) == float(observers[f'mse_{k}_offset']), k
+        for (st, step, end), ref in zip(observers[f'mse_{k}_probes'], observers[f'mse_{k}_probe_loss']):
+            assert O.mse_loss_f64(hist, int(st), int(step), int(end)) == pytest.approx(float(ref), rel=1e-12)
+            assert O.mse_loss(hist, int(st), int(step), int(end)) == pytest.approx(float(ref), rel=2e-4)
+
+
+def test_mse_loss_matches_reference_binary(observers):
+    """oracle/_ref = the reference's own hist_mse.cc compiled where it lies (bit-exact float)."""
+    if O.ref_lib() is None:
+        pytest.skip('oracle/_ref not built (no /root/reference on this machine)')
+    rng = np.random.default_rng(3)
+    for k in range(int(observers['mse_n'])):
+        hist = observers[f'mse_{k}_hist']
+        bins = hist.size
+        for _ in range(40):
+            start = int(rng.integers(0, bins // 2)); step = int(rng.integers(1, bins // 256 + 2))
+            end = start + 256 * step
+            assert O.mse_loss(hist, start, step, end) == O.ref_mse_loss(hist, start, step, end)
+
+
+def test_fp8_known_answers():
+    """SURVEY.md section 8c known-answer table (RNE policy, scale 1).  Parity for FP8 is otherwise
+    unpinned: the reference has no CPU twin and no test for these kernels."""
+    e4m3 = {1.0625: 1.0, 1.1875: 1.125, 1.3125: 1.25, 1.96875: 2.0, 0.3: 0.3125, 17.0: 16.0, 447.0: 448.0,
+            460.0: 448.0, -1.1875: -1.125, 2.0 ** -7: 2.0 ** -7, 0.0146484375: 0.015625, 0.001: 0.001953125,
+            0.0009: 0.0, 0.0: 0.0, 1e9: 448.0, -1e9: -448.0}
+    for v, want in e4m3.items():
+        assert O.fq_float_scalar(v, 1.0, 4, 3, -448.0, 448.0, 0) == want, v
+    e5m2 = {1.125: 1.0, 1.375: 1.25, 3.3: 3.5, 60000.0: 57344.0, 2.0 ** -16: 2.0 ** -16, 1e-5: 2.0 ** -16}
+    for v, want in e5m2.items():
+        assert O.fq_float_scalar(v, 1.0, 5, 2, -57344.0, 57344.0, 0) == want, v
+    # theoretical maxima (common.cuh:169-180): clip wider than the format -> 480 / 114688
+    assert O.fq_float_scalar(1e6, 1.0, 4, 3, -1e9, 1e9, 0) == 480.0
+    assert O.fq_float_scalar(1e6, 1.0, 5, 2, -1e9, 1e9, 0) == 114688.0
+    # every exactly representable E4M3 value is a fixed point
+    for e in range(-6, 9):
+        for m in range(8):
+            v = (1 + m / 8.0) * 2.0 ** e
+            if v <= 448: assert O.fq_float_scalar(v) == v
+    x = np.array([1.1875, -3.3, 100.0], np.float32)
+    y = O.fq_float_t(x, [0.5], [0.0])
+    assert list(y) == [1.125, -3.25, 96.0] or np.allclose(y, [1.1875 // 0.0625 * 0.0625, -3.25, 96.0])
+
+
+def test_hist_rule_vs_histc():
+    """tests/test_cuda_kernel.py:198-208: Histogram_T within 100 counts/bin of torch.histc."""
+    import torch
+    torch.manual_seed(1)
+    t = torch.rand(size=[8, 3, 224, 224])
+    ref = torch.histc(torch.abs(t), bins=50, min=0, max=0.5).numpy()
+    h = O.hist_sym_t(t.numpy(), 0.01, np.zeros(50, np.int32))
+    assert np.abs(ref - h).max() < 100
+    assert h.sum() <= t.numel()          # clip_outliers drops everything >= 0.5
+    h2 = O.hist_sym_t(t.numpy(), 0.01, np.zeros(50, np.int32), clip_outliers=False)
+    assert h2.sum() == t.numel() and h2[-1] > h[-1]
+    # accumulation semantics: a second call adds into the same buffer
+    h3 = O.hist_sym_t(t.numpy(), 0.01, h.copy())
+    assert np.array_equal(h3, 2 * h)
+
+
+def test_quantile_and_isotone_rules():
+    x = np.arange(1000, dtype=np.float32)[::-1].copy()
+    q = O.quantile_t(x, 0.999)
+    assert q[0] == 999.0 and q[1] == 1.0       # rn(1000*.999)=999, rn(1000*(1-.999f))=1
+    q = O.quantile_t(x, 0.5)
+    assert q[0] == 500.0 and q[1] == 500.0
+    iso = O.isotone_t(np.array([3, 1, 4, 1, 5, 9, 2, 6], np.float32))
+    assert list(iso) == [9, 6, 1, 1]
+    assert list(O.isotone_t(np.array([7], np.float32))) == [7, 7, 7, 7]

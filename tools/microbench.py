@@ -1,0 +1,69 @@
+"""Kernel micro-benchmark: GB/s of every hot kernel on A=[1,3,224,224], B=[1,512,56,56], Bx32.
+Timing: torch.cuda.Event pairs on the current stream (the stream the library launches on),
+`iters` back-to-back launches per measurement -> average launch-to-launch time."""
+import argparse
+import json
+import sys
+import os
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ppq_amd import CUDA  # noqa: E402
+
+
+def timeit(fn, iters=50, warmup=5):
+    for _ in range(warmup): fn()
+    torch.cuda.synchronize()
+    a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters): fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--relu', action='store_true')
+    ap.add_argument('--bins', type=int, default=2048)
+    args = ap.parse_args()
+    dev = 'cuda'
+    torch.manual_seed(0)
+    shapes = {'A': (1, 3, 224, 224), 'B': (1, 512, 56, 56), 'Bx8': (8, 512, 56, 56), 'Bx32': (32, 512, 56, 56)}
+    rows = []
+    for name, shp in shapes.items():
+        x = torch.randn(*shp, device=dev)
+        if args.relu: x = torch.relu(x)
+        n = x.numel()
+        C = shp[1]
+        s1 = torch.tensor([0.03], device=dev); o1 = torch.zeros(1, device=dev)
+        sc = torch.rand(C, device=dev) * 0.05 + 0.01; oc = torch.randint(0, 255, [C], device=dev).float()
+        hist = torch.zeros(args.bins, dtype=torch.int32, device=dev)
+        mm = torch.tensor([float('inf'), float('-inf')], device=dev)
+        mins = torch.full([C], float('inf'), device=dev); maxs = torch.full([C], float('-inf'), device=dev)
+        hs = float(x.abs().max()) / args.bins
+        lo, hi = float(x.min()), float(x.max())
+        cases = {
+            'fq_linear_t': (8, lambda: CUDA.LinearQuantize_T(x, s1, o1, -128, 127, 0)),
+            'fq_linear_c': (8, lambda: CUDA.LinearQuantize_C(x, sc, oc, 1, 0, 255, 0)),
+            'fq_float_t': (8, lambda: CUDA.FloatingQuantize_T(x, s1, o1)),
+            'hist_sym_t': (4, lambda: CUDA.Histogram_T(x, hist, hs)),
+            'hist_asym_t': (4, lambda: CUDA.Histogram_Asymmetric_T(lo, hi, x, hist)),
+            'minmax_t': (4, lambda: CUDA.MinMax_T(x, mm)),
+            'minmax_c': (4, lambda: CUDA.MinMax_C(x, 1, mins, maxs)),
+            'quantile_t': (4, lambda: CUDA.Quantile(x, 0.9999)),
+            'fq_t+hist fused': (8, lambda: CUDA.LinearQuantize_T_Histogram(x, s1, o1, hist, hs)),
+            'torch copy (ref)': (8, lambda: x.clone()),
+            'torch abs().max (ref)': (4, lambda: x.abs().max()),
+        }
+        for k, (bpe, fn) in cases.items():
+            t = timeit(fn, iters=200 if n < 10_000_000 else 30)
+            rows.append({'kernel': k, 'tensor': name, 'us': round(t * 1e6, 2), 'GBps': round(bpe * n / t / 1e9, 1)})
+            print(f'{k:24s} {name:5s} {t*1e6:10.2f} us  {bpe*n/t/1e9:9.1f} GB/s', flush=True)
+    os.makedirs('gpurun_out', exist_ok=True)
+    tag = ('relu' if args.relu else 'randn') + f'_{args.bins}'
+    json.dump(rows, open(f'gpurun_out/microbench_{tag}.json', 'w'), indent=1)
+
+
+if __name__ == '__main__':
+    main()
