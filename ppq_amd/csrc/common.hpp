@@ -50,6 +50,7 @@ struct LaunchScope {
 };
 
 int finish_launch(const char* what);   // hipGetLastError -> status
+void* scratch(hipStream_t stream, size_t bytes);   // device scratch private to (device, stream)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -155,6 +156,30 @@ __device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
 __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
     if (v >= 0) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
     else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+// Stream every element of x[0..n) through f(value): 16-B loads, U of them in flight per lane,
+// grid-stride; the tail and unaligned tensors fall back to 4-B loads.  Order is unspecified.
+template <int U, typename F>
+__device__ __forceinline__ void stream_elems(const float* __restrict__ x, uint32_t n, bool vec_ok, F f) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t done = 0;
+    if (vec_ok) {
+        const uint32_t nvec = n >> 2;
+        const float4* xv = reinterpret_cast<const float4*>(x);
+        for (uint32_t v = tid; v < nvec; v += stride * U) {
+            float4 a[U];
+#pragma unroll
+            for (int k = 0; k < U; k++)
+                if (v + k * stride < nvec) a[k] = xv[v + k * stride];
+#pragma unroll
+            for (int k = 0; k < U; k++)
+                if (v + k * stride < nvec) { f(a[k].x); f(a[k].y); f(a[k].z); f(a[k].w); }
+        }
+        done = nvec << 2;
+    }
+    for (uint32_t i = done + tid; i < n; i += stride) f(x[i]);
 }
 
 #endif  // __HIPCC__

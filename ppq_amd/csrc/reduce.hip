@@ -32,27 +32,45 @@ __device__ __forceinline__ void block_minmax_commit(float mn, float mx, float* g
     }
 }
 
+// partial == nullptr: commit with one pair of global atomics per workgroup (few workgroups);
+// otherwise write this workgroup's (min, max) to partial[2*blockIdx.x ..] for minmax_finish_kernel:
+// same-address device atomics serialise at ~12 ns each, which would dominate a 2048-workgroup launch.
 __global__ __launch_bounds__(kBlock) void minmax_t_kernel(const float* __restrict__ x, uint32_t n, int vec_ok,
-                                                          float* __restrict__ minmax) {
+                                                          float* __restrict__ minmax, float* __restrict__ partial) {
     __shared__ float lds[16];
     float mn = INFINITY, mx = -INFINITY;
-    const uint32_t stride = gridDim.x * kBlock;
-    uint32_t done = 0;
-    if (vec_ok) {
-        const uint32_t nvec = n >> 2;
-        const float4* xv = reinterpret_cast<const float4*>(x);
-        for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride) {
-            const float4 a = xv[v];
-            mn = fminf(fminf(mn, a.x), fminf(a.y, fminf(a.z, a.w)));
-            mx = fmaxf(fmaxf(mx, a.x), fmaxf(a.y, fmaxf(a.z, a.w)));
-        }
-        done = nvec << 2;
+    stream_elems<4>(x, n, vec_ok != 0, [&](float a) { mn = fminf(mn, a); mx = fmaxf(mx, a); });
+    if (partial == nullptr) { block_minmax_commit(mn, mx, &minmax[0], &minmax[1], lds); return; }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { lds[wid] = mn; lds[8 + wid] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / kWave; w++) { mn = fminf(mn, lds[w]); mx = fmaxf(mx, lds[8 + w]); }
+        partial[2 * blockIdx.x] = mn;
+        partial[2 * blockIdx.x + 1] = mx;
     }
-    for (uint32_t i = done + blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const float a = x[i];
-        mn = fminf(mn, a); mx = fmaxf(mx, a);
+}
+
+__global__ __launch_bounds__(kBlock) void minmax_finish_kernel(const float* __restrict__ partial, uint32_t count,
+                                                               float* __restrict__ minmax) {
+    __shared__ float lds[16];
+    float mn = INFINITY, mx = -INFINITY;
+    for (uint32_t i = threadIdx.x; i < count; i += kBlock) {
+        mn = fminf(mn, partial[2 * i]);
+        mx = fmaxf(mx, partial[2 * i + 1]);
     }
-    block_minmax_commit(mn, mx, &minmax[0], &minmax[1], lds);
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { lds[wid] = mn; lds[8 + wid] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / kWave; w++) { mn = fminf(mn, lds[w]); mx = fmaxf(mx, lds[8 + w]); }
+        minmax[0] = fminf(minmax[0], mn);   // stream-ordered read-modify-write (accumulate semantics)
+        minmax[1] = fmaxf(minmax[1], mx);
+    }
 }
 
 // rows of `epc` contiguous elements, workgroup = (row, chunk)
@@ -130,51 +148,59 @@ constexpr int kOffH3 = kOffH2 + 2 * kQ2;    // hist3[2][256]      : key & 0xFF  
 constexpr int kQWords = kOffH3 + 2 * kQ3;
 
 // find the bin of `hist[0..nbins)` that holds rank k (0-based) and the rank inside it.
-// All threads of the workgroup call this; result is broadcast through LDS (sel[0], sel[1]).
+// All threads of the workgroup call this (blockDim.x == 256, nbins in {256, 4096}); thread t owns
+// `per` consecutive bins, an LDS Hillis-Steele scan gives every owner its exclusive prefix and the
+// one owner whose range covers k walks its (register-resident) bins.  Result: sel[0], sel[1].
 __device__ void select_bin(const uint32_t* __restrict__ hist, int nbins, uint32_t k, uint32_t* scratch,
                            uint32_t* sel) {
-    // nbins <= 4096, blockDim.x == 256: each thread owns nbins/256 consecutive bins
-    const int per = nbins / kBlock > 0 ? nbins / kBlock : 1;
+    const int per = nbins / kBlock;   // 1 or 16
     const int t = threadIdx.x;
+    uint32_t mine[16];
     uint32_t local = 0;
-    if (t * per < nbins)
-        for (int j = 0; j < per; j++) local += hist[t * per + j];
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        mine[j] = j < per ? hist[t * per + j] : 0u;
+        local += mine[j];
+    }
+    __syncthreads();                  // scratch / sel may still be read from a previous call
     scratch[t] = local;
     __syncthreads();
-    if (t == 0) {
-        uint32_t run = 0;
-        int owner = 0;
-        const int owners = nbins / per;
-        for (owner = 0; owner < owners; owner++) {
-            if (run + scratch[owner] > k) break;
-            run += scratch[owner];
+    uint32_t incl = local;
+    for (int d = 1; d < kBlock; d <<= 1) {
+        const uint32_t add = t >= d ? scratch[t - d] : 0u;
+        __syncthreads();
+        incl += add;
+        scratch[t] = incl;
+        __syncthreads();
+    }
+    const uint32_t excl = incl - local;
+    const uint32_t total = scratch[kBlock - 1];
+    const uint32_t kk = k < total ? k : (total ? total - 1 : 0u);   // k < n always; guard anyway
+    if (kk >= excl && kk < incl) {
+        uint32_t run = excl;
+        int j = 0;
+#pragma unroll
+        for (int jj = 0; jj < 15; jj++) {
+            if (jj < per - 1 && j == jj && run + mine[jj] <= kk) { run += mine[jj]; j = jj + 1; }
         }
-        if (owner >= owners) owner = owners - 1;   // k beyond total (cannot happen for k < n)
-        int b = owner * per;
-        for (; b < owner * per + per - 1; b++) {
-            const uint32_t c = hist[b];
-            if (run + c > k) break;
-            run += c;
-        }
-        sel[0] = (uint32_t)b;
-        sel[1] = k - run;
+        sel[0] = (uint32_t)(t * per + j);
+        sel[1] = kk - run;
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(kBlock) void quantile_pass1_kernel(const float* __restrict__ x, uint32_t n,
+__global__ __launch_bounds__(kBlock) void quantile_pass1_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
                                                                 uint32_t* __restrict__ ws) {
     __shared__ uint32_t h[kQ1];
     for (int i = threadIdx.x; i < kQ1; i += kBlock) h[i] = 0;
     __syncthreads();
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) atomicAdd(&h[f2key(x[i]) >> 20], 1u);
+    stream_elems<4>(x, n, vec_ok, [&](float v) { atomicAdd(&h[f2key(v) >> 20], 1u); });
     __syncthreads();
     for (int i = threadIdx.x; i < kQ1; i += kBlock)
         if (h[i]) atomicAdd(&ws[kOffH1 + i], h[i]);
 }
 
-__global__ __launch_bounds__(kBlock) void quantile_pass2_kernel(const float* __restrict__ x, uint32_t n,
+__global__ __launch_bounds__(kBlock) void quantile_pass2_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
                                                                 uint32_t k_hi, uint32_t k_lo,
                                                                 uint32_t* __restrict__ ws) {
     __shared__ uint32_t h[2 * kQ2];
@@ -187,13 +213,12 @@ __global__ __launch_bounds__(kBlock) void quantile_pass2_kernel(const float* __r
     const uint32_t p_lo = sel[0];
     for (int i = threadIdx.x; i < 2 * kQ2; i += kBlock) h[i] = 0;
     __syncthreads();
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const uint32_t key = f2key(x[i]);
+    stream_elems<4>(x, n, vec_ok, [&](float v) {
+        const uint32_t key = f2key(v);
         const uint32_t top = key >> 20, mid = (key >> 8) & 0xFFFu;
         if (top == p_hi) atomicAdd(&h[mid], 1u);
         if (top == p_lo) atomicAdd(&h[kQ2 + mid], 1u);
-    }
+    });
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * kQ2; i += kBlock)
         if (h[i]) atomicAdd(&ws[kOffH2 + i], h[i]);
@@ -214,7 +239,7 @@ __device__ void select_prefix24(const uint32_t* __restrict__ ws, uint32_t k_hi, 
     }
 }
 
-__global__ __launch_bounds__(kBlock) void quantile_pass3_kernel(const float* __restrict__ x, uint32_t n,
+__global__ __launch_bounds__(kBlock) void quantile_pass3_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
                                                                 uint32_t k_hi, uint32_t k_lo,
                                                                 uint32_t* __restrict__ ws) {
     __shared__ uint32_t h[2 * kQ3];
@@ -224,12 +249,11 @@ __global__ __launch_bounds__(kBlock) void quantile_pass3_kernel(const float* __r
     select_prefix24(ws, k_hi, k_lo, scratch, sel, p24, r24);
     for (int i = threadIdx.x; i < 2 * kQ3; i += kBlock) h[i] = 0;
     __syncthreads();
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        const uint32_t key = f2key(x[i]);
+    stream_elems<4>(x, n, vec_ok, [&](float v) {
+        const uint32_t key = f2key(v);
         if ((key >> 8) == p24[0]) atomicAdd(&h[key & 0xFFu], 1u);
         if ((key >> 8) == p24[1]) atomicAdd(&h[kQ3 + (key & 0xFFu)], 1u);
-    }
+    });
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * kQ3; i += kBlock)
         if (h[i]) atomicAdd(&ws[kOffH3 + i], h[i]);
@@ -250,6 +274,8 @@ __global__ __launch_bounds__(kBlock) void quantile_pick_kernel(uint32_t k_hi, ui
 }
 
 // ------------------------------------------------------------------------------------ isotone
+__device__ __forceinline__ bool aligned16_dev(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 struct Top2 { float a1, a2, b1, b2; };   // a1 >= a2 largest two, b1 <= b2 smallest two (with multiplicity)
 
 __device__ __forceinline__ void top2_push(Top2& t, float v) {
@@ -283,9 +309,8 @@ __global__ __launch_bounds__(kBlock) void isotone_kernel(const float* __restrict
                                                          uint32_t n_total) {
     __shared__ Top2 lds[kBlock / kWave];
     Top2 t{-INFINITY, -INFINITY, INFINITY, INFINITY};
-    const uint32_t stride = gridDim.x * kBlock;
     if (partial_in == nullptr) {
-        for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) top2_push(t, x[i]);
+        stream_elems<4>(x, n, aligned16_dev(x), [&](float v) { top2_push(t, v); });
     } else {
         for (uint32_t i = threadIdx.x; i < n_partial; i += kBlock) top2_merge(t, partial_in[i]);
     }
@@ -319,8 +344,18 @@ int ppqhip_minmax_t(const float* x, int64_t n, float* minmax, void* stream) {
     if (int st = validate(n, "minmax_t")) return st;
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_MINMAX_T, 4.0 * (double)n, s);
-    hipLaunchKernelGGL(minmax_t_kernel, dim3(stream_grid(n, kBlock * 4 * 2, kNumCU * 4)), dim3(kBlock), 0, s, x,
-                       (uint32_t)n, aligned16(x) ? 1 : 0, minmax);
+    const int grid = stream_grid(n, kBlock * 4 * 4, kNumCU * 8);
+    if (grid <= 32) {
+        hipLaunchKernelGGL(minmax_t_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, aligned16(x) ? 1 : 0,
+                           minmax, (float*)nullptr);
+    } else {
+        float* partial = (float*)scratch(s, sizeof(float) * 2 * (size_t)grid);
+        if (partial == nullptr) return PPQHIP_ERR_HIP;
+        hipLaunchKernelGGL(minmax_t_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, aligned16(x) ? 1 : 0,
+                           minmax, partial);
+        hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(kBlock), 0, s, (const float*)partial, (uint32_t)grid,
+                           minmax);
+    }
     return finish_launch("minmax_t");
 }
 
@@ -372,9 +407,10 @@ int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, void* wor
     uint32_t* ws = (uint32_t*)workspace;
     if (int st = check_hip(hipMemsetAsync(ws, 0, (size_t)kQWords * 4, s), "memset quantile workspace")) return st;
     const int grid = stream_grid(n, kBlock * 16, kNumCU * 2);
-    hipLaunchKernelGGL(quantile_pass1_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, ws);
-    hipLaunchKernelGGL(quantile_pass2_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, k_hi, k_lo, ws);
-    hipLaunchKernelGGL(quantile_pass3_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, k_hi, k_lo, ws);
+    const bool vec_ok = aligned16(x);
+    hipLaunchKernelGGL(quantile_pass1_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, vec_ok, ws);
+    hipLaunchKernelGGL(quantile_pass2_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, vec_ok, k_hi, k_lo, ws);
+    hipLaunchKernelGGL(quantile_pass3_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, vec_ok, k_hi, k_lo, ws);
     hipLaunchKernelGGL(quantile_pick_kernel, dim3(1), dim3(kBlock), 0, s, k_hi, k_lo, ws, dest);
     return finish_launch("quantile_t");
 }

@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -31,6 +32,31 @@ const char* const kKernelNames[K_NUM] = {
     "fq_float_bwd", "hist_sym_t", "hist_asym_t", "hist_sym_c", "quantile_t", "isotone_t", "minmax_t",
     "minmax_c", "mse_search", "kl_losses", "tensor_clip", "rounding_loss", "fq_linear_t_hist_sym"};
 
+// ---- per-(device, stream) scratch arena ---------------------------------------------------
+// Kernels that need a few KiB..MiB of device scratch (two-stage reductions) take it from here:
+// launches on one stream are ordered, so one buffer per (device, stream) is race-free.
+static std::mutex g_scratch_mu;
+static std::map<std::pair<int, hipStream_t>, std::pair<void*, size_t>> g_scratch;
+
+void* scratch(hipStream_t stream, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    auto& slot = g_scratch[{dev, stream}];
+    if (slot.second < bytes) {
+        if (slot.first) {   // the old buffer may still be in use by queued work on this stream
+            if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;
+            (void)hipFree(slot.first);
+            slot = {nullptr, 0};
+        }
+        size_t want = bytes < (1u << 20) ? (1u << 20) : bytes;
+        void* p = nullptr;
+        if (hipMalloc(&p, want) != hipSuccess) { set_error("scratch: hipMalloc(%zu) failed", want); return nullptr; }
+        slot = {p, want};
+    }
+    return slot.first;
+}
+
 // ---- profiling aid ------------------------------------------------------------------------
 struct ProfRecord {
     int id;
@@ -44,14 +70,14 @@ static std::vector<hipEvent_t> g_pool;
 
 static hipEvent_t get_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
-    hipEvent_t e; hipEventCreate(&e); return e;
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 
 LaunchScope::LaunchScope(KernelId id, double bytes, hipStream_t s) : slot(-1), stream(s) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRecord r; r.id = id; r.bytes = bytes; r.start = get_event(); r.stop = get_event();
-    hipEventRecord(r.start, stream);
+    (void)hipEventRecord(r.start, stream);
     g_records.push_back(r);
     slot = (int)g_records.size() - 1;
 }
@@ -59,7 +85,7 @@ LaunchScope::LaunchScope(KernelId id, double bytes, hipStream_t s) : slot(-1), s
 LaunchScope::~LaunchScope() {
     if (slot < 0) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    hipEventRecord(g_records[slot].stop, stream);
+    (void)hipEventRecord(g_records[slot].stop, stream);
 }
 
 }  // namespace ppqhip
@@ -94,8 +120,8 @@ int ppqhip_prof_collect(ppqhip_prof_entry* entries, int max_entries) {
     for (int k = 0; k < K_NUM; k++) snprintf(agg[k].name, sizeof(agg[k].name), "%s", kKernelNames[k]);
     for (auto& r : g_records) {
         float ms = 0.f;
-        hipEventSynchronize(r.stop);
-        hipEventElapsedTime(&ms, r.start, r.stop);
+        (void)hipEventSynchronize(r.stop);
+        (void)hipEventElapsedTime(&ms, r.start, r.stop);
         agg[r.id].launches += 1; agg[r.id].total_ms += ms; agg[r.id].total_bytes += r.bytes;
         g_pool.push_back(r.start); g_pool.push_back(r.stop);
     }

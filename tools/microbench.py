@@ -26,12 +26,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--relu', action='store_true')
     ap.add_argument('--bins', type=int, default=2048)
+    ap.add_argument('--only', type=str, default='')
+    ap.add_argument('--tensors', type=str, default='A,B,Bx8,Bx32')
     args = ap.parse_args()
     dev = 'cuda'
     torch.manual_seed(0)
     shapes = {'A': (1, 3, 224, 224), 'B': (1, 512, 56, 56), 'Bx8': (8, 512, 56, 56), 'Bx32': (32, 512, 56, 56)}
     rows = []
     for name, shp in shapes.items():
+        if name not in args.tensors.split(','): continue
         x = torch.randn(*shp, device=dev)
         if args.relu: x = torch.relu(x)
         n = x.numel()
@@ -57,6 +60,7 @@ def main():
             'torch abs().max (ref)': (4, lambda: x.abs().max()),
         }
         for k, (bpe, fn) in cases.items():
+            if args.only and not any(o in k for o in args.only.split(',')): continue
             t = timeit(fn, iters=200 if n < 10_000_000 else 30)
             rows.append({'kernel': k, 'tensor': name, 'us': round(t * 1e6, 2), 'GBps': round(bpe * n / t / 1e9, 1)})
             print(f'{k:24s} {name:5s} {t*1e6:10.2f} us  {bpe*n/t/1e9:9.1f} GB/s', flush=True)
