@@ -1,0 +1,192 @@
+"""bench.py -- calibration samples/s of RuntimeCalibrationPass (KL, 2048 bins) on ResNet-50 INT8.
+
+Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by
+torch.distributed.run, one rank per GPU over RCCL).  A *step* is one calibration batch
+(`--batch` samples, default 32) taken through BOTH phases of the pass; the timed region is exactly
+one `RuntimeCalibrationPass.optimize(...)` with `calib_steps = K` (phase 1 range collection, render,
+phase 2 histogram collection incl. the per-forward weight fake-quant the reference performs, batched
+KL search, render), bracketed by barrier + torch.cuda.synchronize on both sides, MAX over ranks.
+Inputs (K batches of torch.rand(batch,3,224,224)) are resident in HBM before the timer starts.
+Weak scaling: every rank calibrates K batches of its own; statistics merge with one RCCL all-reduce
+per phase (ppq_amd/distributed.py); value = N*K*batch / time.
+
+Rank 0 prints ONE JSON line; `roofline` describes the dominant ppq_amd kernel of the timed workload
+(hipEvent pairs on the launch stream, collected in a second identical pass), `cpu_baseline` is the
+CPU oracle (oracle/cpu_calibration.py: torch-CPU dense ops + the C restatement of the kernels) on a
+bounded sample of the same workload (N == 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def setup_dist(n_gpus: int):
+    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    return rank, world, local
+
+
+def barrier(world):
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def build_workload(dev, bins, method):
+    from ppq_amd import harness
+    graph = harness.resnet50_graph(seed=0)
+    harness.quantize_graph(graph, method, hist_bins=bins)
+    ex = harness.TorchExecutor(graph, dev)
+    harness.ParameterQuantizePass().optimize(graph)        # weights: per-channel min-max, left ACTIVATED
+    return graph, ex
+
+
+def run_pass(graph, ex, batches, steps, method):
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    p = RuntimeCalibrationPass(method=method, check_steps=False)
+    p.optimize(graph, dataloader=batches, executor=ex, calib_steps=steps)
+    return p
+
+
+def collect_prof():
+    from ppq_amd import _lib
+    arr = (_lib.ProfEntry * 32)()
+    n = _lib.lib.ppqhip_prof_collect(arr, 32)
+    return [{'name': arr[i].name.decode(), 'launches': int(arr[i].launches), 'total_ms': float(arr[i].total_ms),
+             'total_bytes': float(arr[i].total_bytes)} for i in range(n)]
+
+
+def cpu_baseline(bins, batch_samples=2, n_batches=2):
+    """The same two-phase KL calibration on the host cores, through the CPU oracle."""
+    from ppq_amd import harness
+    from oracle.cpu_calibration import timed_calibrate_cpu
+    graph = harness.resnet50_graph(seed=0)
+    harness.quantize_graph(graph, 'kl', hist_bins=bins)
+    g = torch.Generator().manual_seed(1)
+    batches = [torch.rand(batch_samples, 3, 224, 224, generator=g) for _ in range(n_batches)]
+    secs, _ = timed_calibrate_cpu(graph, batches, bins)
+    n = batch_samples * n_batches
+    return {'value': round(n / secs, 3), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': f'{n} samples ({n_batches} batches of {batch_samples}) of the same ResNet-50 KL calibration: '
+                      f'torch-CPU dense ops on {torch.get_num_threads()} threads + single-threaded C oracle kernels; '
+                      f'{secs:.1f} s'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=8)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--bins', type=int, default=2048)
+    ap.add_argument('--method', type=str, default='kl')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank, world, local = setup_dist(args.gpus)
+    dev = f'cuda:{local}'
+    import ppq_amd  # noqa: F401  (fails loudly without libppq_hip.so)
+    from ppq_amd import _lib
+
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    batches = [torch.rand(args.batch, 3, 224, 224, device=dev, generator=g) for _ in range(args.steps)]
+
+    # warm-up: W batches through a complete two-phase pass (MIOpen find, library load, allocator)
+    if args.warmup > 0:
+        graph, ex = build_workload(dev, args.bins, args.method)
+        run_pass(graph, ex, batches[: max(1, min(args.warmup, args.steps))] , max(1, min(args.warmup, args.steps)), args.method)
+        del graph, ex
+
+    # timed region
+    graph, ex = build_workload(dev, args.bins, args.method)
+    barrier(world)
+    t0 = time.perf_counter()
+    p = run_pass(graph, ex, batches, args.steps, args.method)
+    barrier(world)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    n_obs = sum(len(o.observers()) for o in p._observers.values())
+    scale_checksum = float(sum(float(c.scale.sum()) for op in graph.operations.values() if hasattr(op, 'config')
+                               for c, v in op.config_with_variable if not v.is_parameter and c.scale is not None
+                               and int(getattr(c.state, 'value', c.state)) == 4))
+
+    # roofline leg: the identical pass once more with hipEvent pairs around every library launch
+    roof = None
+    prof_rows = []
+    if rank == 0:
+        graph2, ex2 = build_workload(dev, args.bins, args.method)
+        torch.cuda.synchronize()
+        _lib.lib.ppqhip_prof_enable(1)
+        if world == 1:
+            run_pass(graph2, ex2, batches, args.steps, args.method)
+        else:   # collectives need every rank; profile the local (non-merged) statistics path only
+            from ppq_amd.calibration import RuntimeCalibrationPass
+            import torch.distributed as dist
+            solo = dist.new_group([0]) if False else None
+            pp = RuntimeCalibrationPass(method=args.method, check_steps=False)
+            pp._render = lambda: __import__('ppq_amd.observer', fromlist=['render_observers']).render_observers(pp._all_tensor_observers())
+            pp.optimize(graph2, dataloader=batches, executor=ex2, calib_steps=args.steps)
+        torch.cuda.synchronize()
+        _lib.lib.ppqhip_prof_enable(0)
+        prof_rows = collect_prof()
+        if prof_rows:
+            dom = max(prof_rows, key=lambda r: r['total_ms'])
+            avg_s = dom['total_ms'] * 1e-3 / dom['launches']
+            avg_b = dom['total_bytes'] / dom['launches']
+            ach = avg_b / avg_s / 1e9
+            roof = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS,
+                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': None,
+                    'launches': dom['launches'], 'avg_launch_us': round(avg_s * 1e6, 2),
+                    'algorithmic_bytes_per_launch': round(avg_b)}
+    if world > 1:
+        barrier(world)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.bins)
+
+    if rank == 0:
+        samples = world * args.steps * args.batch
+        out = {
+            'metric': 'calibration samples/sec (RuntimeCalibrationPass, KL 2048-bin, ResNet-50 INT8)',
+            'value': round(samples / elapsed, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'ResNet-50 topology (53 Conv + 1 Gemm, BN folded, seeded He init), '
+                                   f'RuntimeCalibrationPass {args.method} {args.bins} bins, per-tensor INT8 activations, '
+                                   f'per-channel INT8 weights, {args.steps} batches x {args.batch} x 3x224x224 per GPU',
+                       'samples': samples, 'batch': args.batch, 'observed_tensors': n_obs,
+                       'parallelism': f'dp{world} (batches sharded, 1 all-reduce per phase)'},
+            'roofline': roof, 'cpu_baseline': cpu,
+            'kernels': [{'name': r['name'], 'launches': r['launches'], 'total_ms': round(r['total_ms'], 3),
+                         'GBps': round(r['total_bytes'] / max(r['total_ms'], 1e-9) / 1e6, 1)} for r in prof_rows],
+            'scale_checksum': scale_checksum,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

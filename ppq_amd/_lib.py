@@ -70,6 +70,17 @@ if not os.path.exists(LIB_PATH):
         '`python -c "import __graft_entry__ as g; g.build()"` or `make -C ppq_amd/csrc` (needs hipcc, '
         'targets gfx950).  ppq_amd has no CPU / PyTorch fallback by design.')
 
+# One HIP runtime per process: libppq_hip.so must bind to the SAME libamdhip64 that PyTorch-ROCm
+# uses (its wheel bundles one, same SONAME as /opt/rocm's), otherwise stream handles and device
+# pointers handed over from torch mean nothing to our launches ("no ROCm-capable device").
+# Importing torch first and pre-loading its runtime makes the dynamic linker resolve our
+# DT_NEEDED libamdhip64.so.7 to the copy that is already mapped.
+import torch  # noqa: E402
+
+_torch_hip = os.path.join(os.path.dirname(torch.__file__), 'lib', 'libamdhip64.so')
+if os.path.exists(_torch_hip):
+    ctypes.CDLL(_torch_hip, mode=ctypes.RTLD_GLOBAL)
+
 try:
     lib = ctypes.CDLL(LIB_PATH)
 except OSError as e:   # pragma: no cover - broken ROCm install

@@ -1,0 +1,331 @@
+"""Measurement harness: the smallest caller that can drive the calibration hot path end to end
+when PPQ itself is not importable (the GPU box has no /root/reference).
+
+NOT a re-implementation of PPQ's graph IR / executor / quantizers (all out of scope, SURVEY
+section 2): it offers just the slice of their interfaces that ``RuntimeCalibrationPass`` and the
+observers touch, with the reference's names and call protocol --
+
+* ``Variable`` / ``Operation`` / ``QuantableOperation`` / ``BaseGraph``   ppq/IR/base/graph.py:15-260,
+                                                                           ppq/IR/quantize.py:15-140
+* ``TorchExecutor.forward(inputs, output_names, hooks)``                   ppq/executor/torch.py:365-577
+  (quantize inputs -> pre_forward_hook -> op -> quantize outputs -> post_forward_hook)
+* a TensorRT-style INT8 policy (``quantize_graph``)                        quantizer/TensorRTQuantizer.py
+  + the state edits of QuantizeFusionPass / QuantizeSimplifyPass           optim/refine.py
+* ``ParameterQuantizePass`` / ``ParameterBakingPass``                      optim/parameters.py:156-215,
+                                                                           optim/baking.py:11-47
+* ``resnet50_graph`` -- the ResNet-50 topology (53 Conv + 1 Gemm, BN pre-folded) with seeded
+  He-initialised weights, standing in for the ONNX model that cannot be loaded here (no `onnx`).
+
+The dense math (conv / gemm) is PyTorch-ROCm (MIOpen / rocBLAS), exactly as in the reference; only
+the quantization simulation goes through this package's kernels.
+"""
+from typing import Callable, Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from .core import (LinearQuantizationConfig, QuantizationPolicy, QuantizationStates, TensorQuantizationConfig,
+                   is_initial)
+from .core import QuantizationProperty as P
+from .observer import OperationObserver, TensorObserverFactroy
+from .qfunction import PPQuantFunction
+
+PASSIVE_OPERATIONS = {'MaxPool', 'GlobalMaxPool', 'Reshape', 'Flatten', 'Identity', 'Dropout', 'Slice', 'Pad',
+                      'Split', 'Transpose', 'Interp', 'Squeeze', 'Unsqueeze'}        # ppq/core/common.py:50-53
+COMPUTING_OP = {'Conv', 'Gemm', 'ConvTranspose', 'MatMul'}
+
+
+class Variable:
+    def __init__(self, name: str, value: torch.Tensor = None, is_parameter: bool = False):
+        self.name = name
+        self.value = value
+        self.is_parameter = is_parameter
+        self.dest_ops: List['Operation'] = []
+        self.source_op: Optional['Operation'] = None
+
+    def __hash__(self): return hash(self.name)
+    def __eq__(self, o): return isinstance(o, Variable) and o.name == self.name
+
+
+class OperationQuantizationConfig:
+    """ppq/core/quant.py:899-940."""
+    def __init__(self, input_quantization_configs, output_quantization_configs):
+        self.input_quantization_config: List[TensorQuantizationConfig] = input_quantization_configs
+        self.output_quantization_config: List[TensorQuantizationConfig] = output_quantization_configs
+
+
+class Operation:
+    def __init__(self, name: str, op_type: str, attributes: dict = None, inputs=None, outputs=None):
+        self.name, self.type = name, op_type
+        self.attributes = attributes or {}
+        self.inputs: List[Variable] = inputs or []
+        self.outputs: List[Variable] = outputs or []
+
+    @ property
+    def parameters(self) -> List[Variable]:
+        return [v for v in self.inputs if v.is_parameter]
+
+    def __str__(self): return f'{self.name}({self.type})'
+
+
+class QuantableOperation(Operation):
+    """ppq/IR/quantize.py:15-140."""
+    def __init__(self, op: Operation, config: OperationQuantizationConfig):
+        super().__init__(op.name, op.type, op.attributes, op.inputs, op.outputs)
+        self.config = config
+
+    @ property
+    def config_with_variable(self):
+        return list(zip(self.config.input_quantization_config, self.inputs)) + \
+            list(zip(self.config.output_quantization_config, self.outputs))
+
+    def baking_parameters(self, quant_func: Callable):
+        """IR/quantize.py:98-111."""
+        for config, var in self.config_with_variable:
+            if var.is_parameter and QuantizationStates.is_activated(config.state):
+                var.value = quant_func(var.value, config)
+                config.state = (QuantizationStates.BAKED if config.state == QuantizationStates.ACTIVATED
+                                else QuantizationStates.PASSIVE_BAKED)
+
+
+class BaseGraph:
+    def __init__(self, name: str):
+        self.name = name
+        self.operations: Dict[str, Operation] = {}
+        self.variables: Dict[str, Variable] = {}
+        self.inputs: Dict[str, Variable] = {}
+        self.outputs: Dict[str, Variable] = {}
+
+    def create_variable(self, name: str, value=None, is_parameter=False) -> Variable:
+        v = Variable(name, value, is_parameter)
+        self.variables[name] = v
+        return v
+
+    def create_operation(self, op_type: str, name: str, inputs: List[Variable], attributes: dict = None) -> Variable:
+        out = self.create_variable(name + '_out')
+        op = Operation(name, op_type, attributes, list(inputs), [out])
+        out.source_op = op
+        for v in inputs: v.dest_ops.append(op)
+        self.operations[name] = op
+        return out
+
+    def topological_sort(self) -> List[Operation]:
+        return list(self.operations.values())        # operations are created in execution order
+
+
+# ------------------------------------------------------------------------------------ op library
+def _forward(op: Operation, x: List[torch.Tensor]):
+    t, a = op.type, op.attributes
+    if t == 'Conv':
+        return F.conv2d(x[0], x[1], x[2] if len(x) > 2 else None, stride=a.get('strides', 1),
+                        padding=a.get('pads', 0), groups=a.get('group', 1))
+    if t == 'Gemm': return F.linear(x[0], x[1], x[2] if len(x) > 2 else None)
+    if t == 'MatMul': return torch.matmul(x[0], x[1])
+    if t == 'Relu': return F.relu(x[0])
+    if t == 'Gelu': return F.gelu(x[0])
+    if t == 'Add': return x[0] + x[1]
+    if t == 'MaxPool': return F.max_pool2d(x[0], a['kernel_shape'], a.get('strides', 1), a.get('pads', 0))
+    if t == 'GlobalAveragePool': return F.adaptive_avg_pool2d(x[0], 1)
+    if t == 'Flatten': return torch.flatten(x[0], 1)
+    if t == 'LayerNormalization': return F.layer_norm(x[0], x[0].shape[-1:], x[1], x[2])
+    if t == 'Softmax': return F.softmax(x[0], dim=a.get('axis', -1))
+    raise NotImplementedError(f'Graph op: {op.name}({op.type}) has no backend implementation')
+
+
+class TorchExecutor:
+    """The forward loop of ppq/executor/torch.py:457-577 (hook protocol of executor/base.py:44-102)."""
+    def __init__(self, graph: BaseGraph, device: str = 'cuda'):
+        self._graph = graph
+        self._device = device
+        self._default_quant_fn = PPQuantFunction
+        for v in graph.variables.values():
+            if v.is_parameter and v.value is not None: v.value = v.value.to(device)
+
+    def quantize_function(self, tensor: torch.Tensor, config=None) -> torch.Tensor:
+        return self._default_quant_fn(tensor, config)
+
+    @ torch.no_grad()
+    def forward(self, inputs, output_names: List[str] = None, hooks: Dict[str, object] = None) -> List[torch.Tensor]:
+        g = self._graph
+        if isinstance(inputs, torch.Tensor): inputs = {next(iter(g.inputs)): inputs}
+        elif isinstance(inputs, (list, tuple)): inputs = {k: v for k, v in zip(g.inputs, inputs)}
+        for name, value in inputs.items(): g.variables[name].value = value.to(self._device)
+        if output_names is None: output_names = list(g.outputs)
+        results = [None] * len(output_names)
+        visited = set()
+        for op in g.topological_sort():
+            hook = hooks.get(op.name) if hooks else None
+            raw_in = [v.value for v in op.inputs]
+            qin = raw_in
+            quantable = isinstance(op, QuantableOperation)
+            if quantable:
+                in_cfgs = list(op.config.input_quantization_config)
+                qin = [self.quantize_function(x, c) for x, c in zip(raw_in, in_cfgs)]
+            if hook is not None:
+                qin = hook.pre_forward_hook(inputs=raw_in, quant_inputs=qin, quant_configs=in_cfgs)
+            outs = _forward(op, qin)
+            outs = list(outs) if isinstance(outs, (list, tuple)) else [outs]
+            fp_outs = outs
+            if quantable:
+                out_cfgs = list(op.config.output_quantization_config)
+                outs = [self.quantize_function(y, c) for y, c in zip(outs, out_cfgs)]
+            if hook is not None:
+                outs = hook.post_forward_hook(outputs=fp_outs, quant_outputs=outs, quant_configs=out_cfgs)
+            for v, y in zip(op.outputs, outs):
+                v.value = y
+                if v.name in output_names: results[output_names.index(v.name)] = y
+            visited.add(op.name)
+            for v in op.inputs:                      # runtime clear, torch.py:564-568
+                if not v.is_parameter and all(d.name in visited for d in v.dest_ops): v.value = None
+        for v in g.variables.values():
+            if not v.is_parameter: v.value = None
+        return results
+
+
+# ------------------------------------------------------------------------------------ quantizer
+def quantize_graph(graph: BaseGraph, activation_algorithm: str = 'kl', per_channel_weight: bool = True,
+                   symmetrical: bool = True, weight_symmetrical: bool = True, num_of_bits: int = 8,
+                   hist_bins: int = None, fp8: bool = False) -> None:
+    """TensorRT-style INT8 policy (TensorRTQuantizer.py:12-107): per-tensor activations on every
+    operation, per-channel `minmax` weights on axis 0, FP32 bias; then the state edits of
+    QuantizeFusionPass (computing op -> activation, passive ops) and QuantizeSimplifyPass."""
+    qmin, qmax = (-(2 ** (num_of_bits - 1)), 2 ** (num_of_bits - 1) - 1) if symmetrical else (0, 2 ** num_of_bits - 1)
+    wmin, wmax = (-(2 ** (num_of_bits - 1)), 2 ** (num_of_bits - 1) - 1) if weight_symmetrical else (0, 2 ** num_of_bits - 1)
+
+    def act_cfg():
+        if fp8:
+            from .core import FloatingQuantizationConfig
+            return FloatingQuantizationConfig(calibration='floating')
+        c = LinearQuantizationConfig(symmetrical=symmetrical, quant_min=qmin, quant_max=qmax, num_of_bits=num_of_bits,
+                                     calibration=activation_algorithm)
+        if hist_bins is not None: c.detail['OBSERVER_KL_HIST_BINS_MANUL_OVERRIDE'] = hist_bins
+        return c
+
+    for name, op in list(graph.operations.items()):
+        in_cfgs = []
+        for i, v in enumerate(op.inputs):
+            if v.is_parameter and op.type in COMPUTING_OP and i == 1:
+                in_cfgs.append(LinearQuantizationConfig(symmetrical=weight_symmetrical, quant_min=wmin, quant_max=wmax,
+                                                        num_of_bits=num_of_bits, calibration='minmax',
+                                                        channel_axis=0 if per_channel_weight else None))
+            elif v.is_parameter:
+                c = act_cfg(); c.state = QuantizationStates.FP32      # bias / norm parameters stay FP32
+                in_cfgs.append(c)
+            else:
+                in_cfgs.append(act_cfg())
+        qop = QuantableOperation(op, OperationQuantizationConfig(in_cfgs, [act_cfg() for _ in op.outputs]))
+        for v in qop.inputs: v.dest_ops[v.dest_ops.index(op)] = qop
+        for v in qop.outputs: v.source_op = qop
+        graph.operations[name] = qop
+    ops = list(graph.operations.values())
+    # QuantizeFusionPass: computing op followed by a single activation -> the conv output is not
+    # quantised on its own; passive operations share their input's quantisation
+    for op in ops:
+        out = op.outputs[0]
+        if op.type in COMPUTING_OP | {'Add'} and len(out.dest_ops) == 1 and out.dest_ops[0].type in {'Relu', 'Gelu'}:
+            op.config.output_quantization_config[0].state = QuantizationStates.OVERLAPPED
+        if op.type in PASSIVE_OPERATIONS:
+            op.config.output_quantization_config[0].state = QuantizationStates.OVERLAPPED
+    # QuantizeSimplifyPass: an input produced by a quantable op is already quantised by its producer
+    for op in ops:
+        for v, c in zip(op.inputs, op.config.input_quantization_config):
+            if v.source_op is not None and is_initial(c):
+                c.state = QuantizationStates.OVERLAPPED
+
+
+class ParameterQuantizePass:
+    """optim/parameters.py:156-215: observe + render every INITIAL parameter config."""
+    def optimize(self, graph: BaseGraph, **kwargs) -> None:
+        observers = []
+        for op in graph.operations.values():
+            if not isinstance(op, QuantableOperation): continue
+            for config, var in op.config_with_variable:
+                if var.is_parameter and is_initial(config):
+                    ob = TensorObserverFactroy.build_observer(var, config)
+                    ob.observe(var.value)
+                    observers.append(ob)
+        from .observer import render_observers
+        render_observers(observers)
+
+
+class ParameterBakingPass:
+    """optim/baking.py:11-47: fake-quantise every activated parameter once and mark it BAKED."""
+    def __init__(self, quantize_function: Callable = PPQuantFunction):
+        self._quantize_function = quantize_function
+
+    def optimize(self, graph: BaseGraph, **kwargs) -> None:
+        for op in graph.operations.values():
+            if isinstance(op, QuantableOperation): op.baking_parameters(self._quantize_function)
+
+
+# ------------------------------------------------------------------------------------ topologies
+def _he(shape, gen) -> torch.Tensor:
+    fan_in = shape[1] * (shape[2] * shape[3] if len(shape) == 4 else 1)
+    return torch.randn(shape, generator=gen) * (2.0 / fan_in) ** 0.5
+
+
+def resnet50_graph(seed: int = 0, num_classes: int = 1000) -> BaseGraph:
+    """ResNet-50 v1.5 topology, BatchNorm folded into the convolutions (PPQ's FORMATTER_FUSE_BN,
+    ppq/core/common.py:40), seeded He-initialised weights, small random biases."""
+    gen = torch.Generator().manual_seed(seed)
+    g = BaseGraph('resnet50')
+    x = g.create_variable('input')
+    g.inputs['input'] = x
+    n = [0]
+
+    def conv(inp, cin, cout, k, stride=1, pad=0, relu=True, tag='conv'):
+        n[0] += 1
+        w = g.create_variable(f'{tag}{n[0]}_w', _he([cout, cin, k, k], gen), True)
+        b = g.create_variable(f'{tag}{n[0]}_b', torch.randn(cout, generator=gen) * 0.05, True)
+        y = g.create_operation('Conv', f'{tag}{n[0]}', [inp, w, b], {'strides': stride, 'pads': pad})
+        if relu: y = g.create_operation('Relu', f'relu{n[0]}', [y])
+        return y
+
+    y = conv(x, 3, 64, 7, 2, 3)
+    y = g.create_operation('MaxPool', 'maxpool', [y], {'kernel_shape': 3, 'strides': 2, 'pads': 1})
+    cin = 64
+    for stage, (blocks, width) in enumerate(zip([3, 4, 6, 3], [64, 128, 256, 512])):
+        for blk in range(blocks):
+            stride = 2 if (blk == 0 and stage > 0) else 1
+            identity = y
+            z = conv(y, cin, width, 1)
+            z = conv(z, width, width, 3, stride, 1)
+            z = conv(z, width, width * 4, 1, relu=False)
+            if blk == 0:
+                identity = conv(y, cin, width * 4, 1, stride, 0, relu=False, tag='down')
+            n[0] += 1
+            z = g.create_operation('Add', f'add{n[0]}', [z, identity])
+            y = g.create_operation('Relu', f'relu{n[0]}', [z])
+            cin = width * 4
+    y = g.create_operation('GlobalAveragePool', 'gap', [y])
+    y = g.create_operation('Flatten', 'flatten', [y])
+    w = g.create_variable('fc_w', torch.randn([num_classes, 2048], generator=gen) * (1.0 / 2048) ** 0.5, True)
+    b = g.create_variable('fc_b', torch.zeros(num_classes), True)
+    y = g.create_operation('Gemm', 'fc', [y, w, b])
+    g.outputs[y.name] = y
+    return g
+
+
+def small_cnn_graph(seed: int = 0, width: int = 16) -> BaseGraph:
+    """Conv-Relu-Conv-Add-Relu-GAP-Gemm: a tiny graph for smoke / parity tests."""
+    gen = torch.Generator().manual_seed(seed)
+    g = BaseGraph('small_cnn')
+    x = g.create_variable('input'); g.inputs['input'] = x
+
+    def conv(inp, cin, cout, name, relu):
+        w = g.create_variable(name + '_w', _he([cout, cin, 3, 3], gen), True)
+        b = g.create_variable(name + '_b', torch.randn(cout, generator=gen) * 0.1, True)
+        y = g.create_operation('Conv', name, [inp, w, b], {'strides': 1, 'pads': 1})
+        return g.create_operation('Relu', name + '_relu', [y]) if relu else y
+
+    a = conv(x, 3, width, 'c1', True)
+    b_ = conv(a, width, width, 'c2', False)
+    s = g.create_operation('Add', 'add', [b_, a])
+    s = g.create_operation('Relu', 'add_relu', [s])
+    p = g.create_operation('GlobalAveragePool', 'gap', [s])
+    f = g.create_operation('Flatten', 'flatten', [p])
+    w = g.create_variable('fc_w', torch.randn([10, width], generator=gen) * 0.3, True)
+    bb = g.create_variable('fc_b', torch.zeros(10), True)
+    y = g.create_operation('Gemm', 'fc', [f, w, bb])
+    g.outputs[y.name] = y
+    return g

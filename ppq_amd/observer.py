@@ -1,0 +1,606 @@
+"""Calibration observers over the HIP kernels.
+
+Mirror of ppq/quantization/observer/{base,range,floating,__init__}.py: same class names, same
+``observe(value)`` / ``render_quantization_config()`` protocol, same ``OBSERVER_TABLE`` keys, same
+two-phase behaviour of the histogram observers, and the same host arithmetic for turning ranges /
+histograms into ``scale`` / ``offset`` (``minmax_to_scale_offset`` is restated line by line).
+
+What is different is where the statistics live and how they are reduced (MI355X-first):
+
+* every observer keeps its running statistics in small DEVICE buffers that the kernels accumulate
+  into (``MinMax_T/C``, ``Histogram_T`` / ``Histogram_Asymmetric_T``, ``Quantile``): one streaming
+  pass per observed tensor, no transpose/flatten copies, no per-batch host synchronisation (the
+  reference appends a tensor per batch and synchronises in every render, range.py:86-98, 113-114);
+* the searches run on the device, batched over all observers of a graph
+  (:func:`render_observers`): one ``KLLosses`` / ``MseSearch`` launch and ONE device->host copy per
+  calibration phase instead of one per tensor (range.py:226, 465);
+* the buffers are flat and additive, so data-parallel calibration merges them with one all-reduce
+  per phase (ppq_amd/distributed.py).
+
+Each observer also works stand-alone (``render_quantization_config()`` with no batching), which is
+what PPQ's own ``RuntimeCalibrationPass`` does when these classes are registered in PPQ's
+``OBSERVER_TABLE``.
+"""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .core import (OBSERVER_FLOATING_MSE_FETCHES, OBSERVER_KL_HIST_BINS, OBSERVER_KL_HIST_BINS_MANUL_OVERRIDE,
+                   OBSERVER_MIN_SCALE, OBSERVER_MIN_SCALE_MANUL_OVERRIDE, OBSERVER_MSE_HIST_BINS,
+                   OBSERVER_PERCENTILE, OBSERVER_PERCENTILE_MANUL_OVERRIDE, is_initial, set_activated)
+from .core import QuantizationProperty as P
+from .core import RoundingPolicy
+from .ffi import CUDA
+from .round import ppq_numerical_round, ppq_round_to_power_of_2
+
+
+# ------------------------------------------------------------------------------- host arithmetic
+def minmax_to_scale_offset(min_val: float, max_val: float, config,
+                           scale_threshold: float = OBSERVER_MIN_SCALE) -> Tuple[float, float]:
+    """ppq/quantization/observer/range.py:22-75, line by line.
+
+    ``min_val`` / ``max_val`` may be Python floats (per-tensor render, ``.item()``) or numpy float32
+    scalars (per-channel render, ``.cpu().numpy()``); like the reference under numpy >= 2 the
+    subtraction and the offset division then happen in float32."""
+    if OBSERVER_MIN_SCALE_MANUL_OVERRIDE in config.detail:
+        scale_threshold = config.detail[OBSERVER_MIN_SCALE_MANUL_OVERRIDE]
+    scale, offset = 1, 0
+    if min_val > 0: min_val = 0
+    if max_val < 0: max_val = 0
+    if config.policy.has_property(P.ASYMMETRICAL):
+        range = float(max_val - min_val)
+        scale = range / (config.quant_max - config.quant_min)
+        scale = max(scale, scale_threshold)
+        offset = ppq_numerical_round(float(-min_val / scale))
+    elif config.policy.has_property(P.SYMMETRICAL):
+        range = 2 * float(max(abs(max_val), abs(min_val)))
+        scale = range / (config.quant_max - config.quant_min)
+        scale = max(scale, scale_threshold)
+        offset = 0
+    else:
+        raise TypeError('Tensor Min Max Observer Excepts either ASYMMETRICAL or SYMMETRICAL quantization config.')
+    if config.policy.has_property(P.POWER_OF_2):
+        scale = ppq_round_to_power_of_2(scale, policy=RoundingPolicy.ROUND_UP)
+    return scale, offset
+
+
+def _set_per_tensor(config, scale: float, offset: float, device) -> None:
+    config.scale = torch.tensor([scale], dtype=torch.float32, device=device).squeeze(0)
+    config.offset = torch.tensor([offset], dtype=torch.float32, device=device).squeeze(0)
+    set_activated(config)
+
+
+class BaseTensorObserver:
+    """ppq/quantization/observer/base.py:9-33."""
+    def __init__(self, watch_on, quant_cfg):
+        self._watch_on = watch_on
+        self._quant_cfg = quant_cfg
+
+    def observe(self, value):
+        raise NotImplementedError('Implement this function first.')
+
+    def render_quantization_config(self):
+        raise NotImplementedError('Implement this function first.')
+
+    def __str__(self) -> str:
+        return ('PPQ Tensor Observer (' + self.__class__.__name__ + ') mount on variable ' +
+                getattr(self._watch_on, 'name', str(self._watch_on)) + ' observing algorithm: ' +
+                str(self._quant_cfg.observer_algorithm))
+
+    def report(self) -> str:
+        return ''
+
+    # ---- batching / distributed hooks (no twin in the reference) --------------------------------
+    def pending_range(self) -> Optional[torch.Tensor]:
+        """Device buffer holding the running range this render needs on the host (or None)."""
+        return None
+
+    def take_range(self, host: np.ndarray) -> None:
+        """Receive the host copy of ``pending_range()`` (fetched for all observers at once)."""
+
+    def reducible(self) -> List[Tuple[torch.Tensor, str]]:
+        """Device buffers + reduction ('min' | 'max' | 'sum') that merge shards of a data-parallel
+        calibration; applied in place before rendering."""
+        return []
+
+
+class TorchMinMaxObserver(BaseTensorObserver):
+    """range.py:78-137.  Running min/max live on the device: float32[2] (per tensor) or
+    float32[C] x 2 (per channel), accumulated by the minmax kernels."""
+    def __init__(self, watch_on, quant_cfg):
+        super().__init__(watch_on, quant_cfg)
+        self._range: Optional[torch.Tensor] = None      # [2] = (min, max)   or   [2, C]
+        self._host_range: Optional[np.ndarray] = None
+        self._observed = False
+
+    @ torch.no_grad()
+    def observe(self, value: torch.Tensor):
+        assert isinstance(value, torch.Tensor), 'TorchMinMaxObserver can only deal with torch Tensor values'
+        assert value.numel() > 0, (f'You are observing an empty tensor({getattr(self._watch_on, "name", "")}).')
+        if not is_initial(self._quant_cfg): return
+        cfg = self._quant_cfg
+        if cfg.policy.has_property(P.PER_TENSOR):
+            if self._range is None:
+                self._range = torch.tensor([float('inf'), float('-inf')], dtype=torch.float32, device=value.device)
+            CUDA.MinMax_T(value, self._range)
+        elif cfg.policy.has_property(P.PER_CHANNEL):
+            if self._range is None:
+                C = value.shape[cfg.channel_axis]
+                self._range = torch.empty((2, C), dtype=torch.float32, device=value.device)
+                self._range[0].fill_(float('inf')); self._range[1].fill_(float('-inf'))
+            CUDA.MinMax_C(value, cfg.channel_axis, self._range[0], self._range[1])
+        else:
+            raise TypeError('Min-max Observer only work with per-tensor or per-channel quantize policy.')
+        self._observed = True
+        self._host_range = None
+
+    def pending_range(self):
+        return self._range if (is_initial(self._quant_cfg) and self._observed) else None
+
+    def take_range(self, host: np.ndarray) -> None:
+        self._host_range = host
+
+    def reducible(self):
+        if self._range is None: return []
+        if self._range.ndim == 1: return [(self._range[0:1], 'min'), (self._range[1:2], 'max')]
+        return [(self._range[0], 'min'), (self._range[1], 'max')]
+
+    def _range_on_host(self) -> np.ndarray:
+        if not self._observed:
+            raise ValueError('Can not render quantization config yet, Observer data collator is empty. '
+                             'Invoke observe() function before render config.')
+        if self._host_range is None:
+            self._host_range = self._range.cpu().numpy()
+        return self._host_range
+
+    def render_quantization_config(self):
+        if not is_initial(self._quant_cfg): return
+        cfg = self._quant_cfg
+        r = self._range_on_host()
+        device = self._range.device
+        if cfg.policy.has_property(P.PER_TENSOR):
+            scale, offset = minmax_to_scale_offset(min_val=float(r[0]), max_val=float(r[1]), config=cfg)
+            _set_per_tensor(cfg, scale, offset, device)
+        elif cfg.policy.has_property(P.PER_CHANNEL):
+            scales, offsets = [], []
+            for min_val, max_val in zip(r[0], r[1]):         # numpy float32 scalars, as in range.py:125-129
+                scale, offset = minmax_to_scale_offset(min_val=min_val, max_val=max_val, config=cfg)
+                scales.append(scale); offsets.append(offset)
+            cfg.scale = torch.tensor(scales, dtype=torch.float32, device=device)
+            cfg.offset = torch.tensor(offsets, dtype=torch.float32, device=device)
+            set_activated(cfg)
+        else:
+            raise TypeError('Min-max Observer only work with per-tensor or per-channel quantize policy.')
+
+
+class TorchHistObserver(TorchMinMaxObserver):
+    """range.py:140-309 (KL).  Phase 'Detecting Minmax' -> phase 'Collating Hist' -> KL search."""
+    def __init__(self, watch_on, quant_cfg, hist_bins: int = OBSERVER_KL_HIST_BINS):
+        self._phase = 'Detecting Minmax'
+        self._hist = None
+        self._hist_scale = None
+        self._min = None
+        self._max = None
+        self._losses: Optional[np.ndarray] = None
+        if OBSERVER_KL_HIST_BINS_MANUL_OVERRIDE in quant_cfg.detail:
+            hist_bins = quant_cfg.detail[OBSERVER_KL_HIST_BINS_MANUL_OVERRIDE]
+        self._hist_bins = hist_bins
+        super().__init__(watch_on, quant_cfg)
+
+    def observe(self, value: torch.Tensor):
+        if not is_initial(self._quant_cfg): return
+        assert value.numel() > 0, (f'You are observing an empty tensor({getattr(self._watch_on, "name", "")}).')
+        if self._phase == 'Detecting Minmax':
+            return super().observe(value)
+        elif self._phase == 'Collating Hist':
+            if self._hist is None:
+                self._hist = torch.zeros(size=(self._hist_bins,), dtype=torch.int32, device=value.device)
+            if self._quant_cfg.policy.has_property(P.ASYMMETRICAL):
+                CUDA.Histogram_Asymmetric_T(self._min, self._max, tensor=value, histogram=self._hist)
+            elif self._quant_cfg.policy.has_property(P.SYMMETRICAL):
+                CUDA.Histogram_T(tensor=value, histogram=self._hist, scale=self._hist_scale)
+            else:
+                raise TypeError('Quantization Property is invalid, expect either ASYMMETRICAL or SYMMETRICAL config here.')
+
+    def pending_range(self):
+        return super().pending_range() if self._phase == 'Detecting Minmax' else None
+
+    def reducible(self):
+        if self._phase == 'Detecting Minmax': return super().reducible()
+        return [(self._hist, 'sum')] if self._hist is not None else []
+
+    # ---- search ------------------------------------------------------------------------------
+    search_kind = 'kl'
+
+    def search_key(self):
+        """Observers with equal keys are searched by one batched launch."""
+        return ('kl', self._hist_bins, self._quant_cfg.num_of_bits)
+
+    def take_losses(self, losses: np.ndarray) -> None:
+        self._losses = losses
+
+    def hist_to_scale_offset(self, histogram: torch.Tensor, hist_bins: int, hist_scale: float, config,
+                             scale_threshold: float = OBSERVER_MIN_SCALE) -> Tuple[float, int]:
+        """range.py:190-282: the divergences come from the KLLosses kernel; selection, scale formula,
+        threshold and power-of-2 rounding are the reference's host code."""
+        if config.policy.has_property(P.ASYMMETRICAL):
+            raise PermissionError('KL observer is not designed for ASYMMETRICAL quantization')
+        if OBSERVER_MIN_SCALE_MANUL_OVERRIDE in config.detail:
+            scale_threshold = config.detail[OBSERVER_MIN_SCALE_MANUL_OVERRIDE]
+        quant_bins = 2 ** (config.num_of_bits - 1)
+        if self._losses is None:
+            self._losses = CUDA.KLLosses(histogram, config.num_of_bits).cpu().numpy()[0]
+        losses = [{'kl': float(kl), 'bin_range': (j + 1) * quant_bins} for j, kl in enumerate(self._losses)]
+        best_bin_range = sorted(losses, key=lambda x: x['kl'])[0]['bin_range']     # stable: first minimum
+        scale, offset = (best_bin_range / self._hist_bins) * hist_scale * (self._hist_bins / quant_bins), 0
+        scale = max(scale, scale_threshold)
+        if config.policy.has_property(P.POWER_OF_2):
+            scale = ppq_round_to_power_of_2(scale, policy=RoundingPolicy.ROUND_HALF_UP)
+        return scale, offset
+
+    def render_quantization_config(self):
+        if not is_initial(self._quant_cfg): return
+        if not self._quant_cfg.policy.has_property(P.PER_TENSOR):
+            raise ValueError('Hist observer can only apply with per-tensor quantization config.')
+        if self._phase == 'Detecting Minmax':
+            r = self._range_on_host()
+            min_val, max_val = float(r[0]), float(r[1])
+            if self._quant_cfg.policy.has_property(P.SYMMETRICAL):
+                hist_range = float(max(abs(max_val), abs(min_val)))
+            else:
+                hist_range = max_val - min_val
+            self._min = min_val
+            self._max = max_val
+            self._hist_scale = hist_range / self._hist_bins
+            self._phase = 'Collating Hist'
+        elif self._phase == 'Collating Hist':
+            if self._hist is None:
+                raise ValueError('Can not render quantization config yet, histogram is empty. '
+                                 'Invoke observe() function before render config.')
+            scale, offset = self.hist_to_scale_offset(histogram=self._hist, hist_bins=self._hist_bins,
+                                                      hist_scale=self._hist_scale, config=self._quant_cfg)
+            _set_per_tensor(self._quant_cfg, scale, offset, self._hist.device)
+
+
+class TorchPercentileObserver(BaseTensorObserver):
+    """range.py:312-403.  Per batch: the two order statistics of ``CUDA.Quantile`` (index rule of the
+    reference's CUDA path, sort.cu:13-19); render = mean over batches -> minmax_to_scale_offset."""
+    def __init__(self, watch_on, quant_cfg):
+        super().__init__(watch_on, quant_cfg)
+        if OBSERVER_PERCENTILE_MANUL_OVERRIDE not in quant_cfg.detail:
+            self._percentile = OBSERVER_PERCENTILE
+        else: self._percentile = quant_cfg.detail[OBSERVER_PERCENTILE_MANUL_OVERRIDE]
+        self._percentile_collector = []
+        self._sum: Optional[torch.Tensor] = None     # float32 [3] = (sum of max-quantiles, sum of min-quantiles, count)
+
+    @ torch.no_grad()
+    def observe(self, value: torch.Tensor):
+        if not is_initial(self._quant_cfg): return
+        assert value is not None, ('You are observing an Empty Tensor. '
+                                   '(This Error is usually due to you have a wrong Quantizer configuration.)')
+        assert value.numel() > 0, (f'You are observing an empty tensor({getattr(self._watch_on, "name", "")}).')
+        assert isinstance(value, torch.Tensor), 'TorchMinMaxObserver can only deal with torch Tensor values'
+        if self._quant_cfg.policy.has_property(P.PER_TENSOR):
+            self._percentile_collector.append(CUDA.Quantile(value, self._percentile).view(1, -1))
+        elif self._quant_cfg.policy.has_property(P.PER_CHANNEL):
+            raise PermissionError('Percentile observer can not deal with per channel quantization.')
+        else:
+            raise TypeError('Min-max Observer only work with per-tensor or per-channel quantize policy.')
+
+    def _fold(self):
+        if self._percentile_collector:
+            stacked = torch.cat(self._percentile_collector, dim=0).float()
+            part = torch.cat([stacked.sum(dim=0), stacked.new_tensor([float(stacked.shape[0])])])
+            self._sum = part if self._sum is None else self._sum + part
+            self._percentile_collector = []
+
+    def reducible(self):
+        self._fold()
+        return [(self._sum, 'sum')] if self._sum is not None else []
+
+    def render_quantization_config(self):
+        if not is_initial(self._quant_cfg): return
+        if self._quant_cfg.policy.has_property(P.PER_TENSOR):
+            single_shard = self._sum is None
+            if single_shard and len(self._percentile_collector) == 0:
+                raise ValueError('Can not render quantization config yet, Observer data collator is empty. '
+                                 'Invoke observe() function before render config.')
+            if single_shard:      # exactly the reference's expression, range.py:369
+                device = self._percentile_collector[-1].device
+                mean = torch.cat(self._percentile_collector, dim=0).float().mean(dim=0).cpu()
+            else:                 # merged shards: sum of per-batch quantiles / number of batches
+                self._fold()
+                device = self._sum.device
+                mean = (self._sum[:2] / self._sum[2]).cpu()
+            scale, offset = minmax_to_scale_offset(min_val=mean[1].item(), max_val=mean[0].item(),
+                                                   config=self._quant_cfg)
+            _set_per_tensor(self._quant_cfg, scale, offset, device)
+        elif self._quant_cfg.policy.has_property(P.PER_CHANNEL):
+            raise PermissionError('Percentile observer can not deal with per channel quantization.')
+        else:
+            raise TypeError('Min-max Observer only work with per-tensor or per-channel quantize policy.')
+
+
+class TorchMSEObserver(TorchHistObserver):
+    """range.py:406-520: histogram-accelerated MSE.  The candidate sweep runs in the MseSearch kernel
+    with the float32 loss of csrc/cpu/hist_mse.cc (the loss the reference uses when its kernels are
+    enabled, range.py:423-425); the winning (start, end) goes through minmax_to_scale_offset here."""
+    search_kind = 'mse'
+
+    def __init__(self, watch_on, quant_cfg, bins: int = OBSERVER_MSE_HIST_BINS):
+        super().__init__(watch_on, quant_cfg)
+        self._hist_bins = bins
+        self._best: Optional[np.ndarray] = None
+
+    def search_key(self):
+        cfg = self._quant_cfg
+        return ('mse', self._hist_bins, cfg.quant_min, cfg.quant_max, cfg.policy.has_property(P.SYMMETRICAL))
+
+    def take_best(self, best: np.ndarray) -> None:
+        self._best = best
+
+    def compute_mse_loss(self, histogram: list, start: int, step: int, end: int) -> float:
+        return CUDA.compute_mse_loss(histogram=histogram, start=start, step=step, end=end)
+
+    def hist_to_scale_offset(self, histogram: torch.Tensor, hist_bins: int, hist_scale: float, config,
+                             scale_threshold: float = OBSERVER_MIN_SCALE) -> Tuple[float, int]:
+        if OBSERVER_MIN_SCALE_MANUL_OVERRIDE in config.detail:
+            scale_threshold = config.detail[OBSERVER_MIN_SCALE_MANUL_OVERRIDE]
+        if config.policy.has_property(P.PER_CHANNEL):
+            raise PermissionError('Torch Mse observer do not support PER_CHANNEL policy now, please wait.')
+        symmetrical = config.policy.has_property(P.SYMMETRICAL)
+        if self._best is None:
+            dev = histogram.device
+            self._best = CUDA.MseSearch(histogram.reshape(1, -1),
+                                        torch.tensor([hist_scale], dtype=torch.float64, device=dev),
+                                        torch.tensor([self._min], dtype=torch.float64, device=dev),
+                                        config.quant_min, config.quant_max, symmetrical).cpu().numpy()[0]
+        best_start, best_end = int(self._best[0]), int(self._best[1])
+        if not symmetrical:
+            range_min, range_max = (best_start * hist_scale) + self._min, (best_end * hist_scale) + self._min
+        else:
+            range_min, range_max = -(best_end * hist_scale), (best_end * hist_scale)
+        return minmax_to_scale_offset(range_min, range_max, config, scale_threshold)
+
+
+class ConstantObserver(BaseTensorObserver):
+    """observer/floating.py:11-48: scale 1, offset 0."""
+    def __init__(self, watch_on, quant_cfg):
+        super().__init__(watch_on, quant_cfg)
+        self._value_shape = None
+        self._value_device = None
+
+    @ torch.no_grad()
+    def observe(self, value: torch.Tensor):
+        if not is_initial(self._quant_cfg): return
+        self._value_shape = value.shape
+        self._value_device = value.device
+
+    def render_quantization_config(self):
+        if not is_initial(self._quant_cfg): return
+        device = self._value_device
+        cfg = self._quant_cfg
+        if cfg.policy.has_property(P.FLOATING):
+            if cfg.policy.has_property(P.PER_TENSOR):
+                _set_per_tensor(cfg, 1.0, 0.0, device)
+            elif cfg.policy.has_property(P.PER_CHANNEL):
+                num = self._value_shape[cfg.channel_axis]
+                cfg.scale = torch.ones(num, dtype=torch.float32, device=device)
+                cfg.offset = torch.zeros(num, dtype=torch.float32, device=device)
+                set_activated(cfg)
+        else:
+            raise TypeError('This Observer is designed for floating quantization.')
+
+
+def tensor_random_fetch(tensor: torch.Tensor, num_of_fetches: int = 1024) -> torch.Tensor:
+    """ppq/utils/fetch.py:32-50 (unseeded variant, the one DirectMSEObserver uses)."""
+    tensor = tensor.flatten()
+    indexer = torch.randint(low=0, high=tensor.numel(), size=[num_of_fetches], device=tensor.device)
+    return tensor.index_select(dim=0, index=indexer)
+
+
+def channel_random_fetch(tensor: torch.Tensor, fetchs_per_channel: int = 1024, channel_axis: int = 0) -> torch.Tensor:
+    """ppq/utils/fetch.py:53-84."""
+    tensor = tensor.transpose(0, channel_axis).flatten(start_dim=1)
+    indexer = torch.randint(low=0, high=tensor.shape[-1], size=[fetchs_per_channel], device=tensor.device)
+    return tensor.index_select(dim=-1, index=indexer)
+
+
+class DirectMSEObserver(BaseTensorObserver):
+    """observer/floating.py:51-143 ('floating'): picks the FP8 scale among
+    {2^-7, 2^-5, 2^-3, 1, 4, 16, 64} by the MSE of the fake-quantised random fetches."""
+    SCALE_CANDIDATES = [.0078125, .03125, .125, 1.0, 4.0, 16.0, 64.0]
+
+    def __init__(self, watch_on, quant_cfg):
+        super().__init__(watch_on, quant_cfg)
+        if not quant_cfg.policy.has_property(P.FLOATING):
+            raise TypeError('MSE Floating Observer is designed for floating quantization.')
+        if not quant_cfg.policy.has_property(P.POWER_OF_2):
+            raise TypeError('MSE Floating Observer is designed for power-of-2 quantization.')
+        self._collector = []
+        self._fetches = OBSERVER_FLOATING_MSE_FETCHES
+
+    @ torch.no_grad()
+    def observe(self, value: torch.Tensor):
+        if not is_initial(self._quant_cfg): return
+        cfg = self._quant_cfg
+        if cfg.policy.has_property(P.PER_CHANNEL):
+            if getattr(self._watch_on, 'is_parameter', False):
+                value = torch.transpose(value, dim0=0, dim1=cfg.channel_axis)
+                self._collector.append(torch.flatten(value, start_dim=1))
+            else:
+                self._collector.append(channel_random_fetch(value, fetchs_per_channel=self._fetches,
+                                                            channel_axis=cfg.channel_axis))
+        if cfg.policy.has_property(P.PER_TENSOR):
+            self._collector.append(tensor_random_fetch(value, num_of_fetches=self._fetches))
+
+    def render_quantization_config(self):
+        if not is_initial(self._quant_cfg): return
+        if not self._collector:
+            raise PermissionError('Observer collector is empty, you should invoke observe function'
+                                  ' before render quantization config.')
+        cfg = self._quant_cfg
+        r = int(getattr(cfg.rounding, 'value', cfg.rounding))
+        e, m, lo, hi = cfg.exponent_bits, cfg.mantissa_bits, cfg.quant_min, cfg.quant_max
+        if cfg.policy.has_property(P.PER_CHANNEL):
+            fp = torch.cat(self._collector, dim=-1).contiguous()           # [C, fetches * batches]
+            C = fp.shape[0]
+            zeros = torch.zeros(C, dtype=torch.float32, device=fp.device)
+            losses = []
+            for scale in self.SCALE_CANDIDATES:
+                s = torch.full([C], scale, dtype=torch.float32, device=fp.device)
+                qt = CUDA.FloatingQuantize_C(fp, s, zeros, 0, e, m, lo, hi, r)
+                losses.append(torch.mean(torch.square(qt - fp), dim=-1, keepdim=True))
+            index = torch.argmin(torch.cat(losses, dim=-1), dim=-1).cpu().tolist()
+            cfg.scale = torch.tensor([self.SCALE_CANDIDATES[i] for i in index], dtype=torch.float32, device=fp.device)
+            cfg.offset = zeros
+        else:
+            fp = torch.cat(self._collector, dim=0).contiguous()
+            zero = torch.zeros(1, dtype=torch.float32, device=fp.device)
+            losses = []
+            for scale in self.SCALE_CANDIDATES:
+                s = torch.full([1], scale, dtype=torch.float32, device=fp.device)
+                qt = CUDA.FloatingQuantize_T(fp, s, zero, e, m, lo, hi, r)
+                losses.append(torch.mean(torch.square(qt - fp)).reshape(1))
+            host = torch.cat(losses).cpu().tolist()                        # one D2H for the 7 candidates
+            best_scale = sorted(zip(host, self.SCALE_CANDIDATES))[0][1]
+            cfg.scale = torch.tensor([best_scale], dtype=torch.float32, device=fp.device)
+            cfg.offset = zero
+        set_activated(cfg)
+
+
+# observer/__init__.py:15-23 ('isotone' is out of scope: SURVEY section 2)
+OBSERVER_TABLE = {
+    'minmax': TorchMinMaxObserver,
+    'kl': TorchHistObserver,
+    'percentile': TorchPercentileObserver,
+    'mse': TorchMSEObserver,
+    'constant': ConstantObserver,
+    'floating': DirectMSEObserver,
+}
+
+
+class TensorObserverFactroy:
+    """observer/__init__.py:25-37."""
+    def __init__(self) -> None:
+        raise NotImplementedError('Observer Factory can not be initialized, use TensorObserverFactroy.build_observer instead.')
+
+    @ classmethod
+    def build_observer(cls, variable, config) -> BaseTensorObserver:
+        algorithm = str(config.observer_algorithm.lower())
+        if algorithm not in OBSERVER_TABLE:
+            raise ValueError(f'Observer type not understand, Except one of {OBSERVER_TABLE.keys()}, '
+                             f'while {str(algorithm)} was given.')
+        return OBSERVER_TABLE[algorithm](watch_on=variable, quant_cfg=config)
+
+
+class CalibrationHook:
+    """observer/__init__.py:40-73 -- the QuantOPRuntimeHook the executor fires around every
+    quantable operation (executor/base.py:76-102)."""
+    def __init__(self, operation, observer_table: Dict[object, BaseTensorObserver]) -> None:
+        self._hook_to = operation
+        self._operation = operation
+        self._observer_table = observer_table
+
+    def pre_forward_hook(self, inputs: list, quant_inputs: list, quant_configs: list) -> list:
+        for input_var, quant_config in zip(inputs, quant_configs):
+            if quant_config in self._observer_table:
+                self._observer_table[quant_config].observe(input_var)
+        return quant_inputs
+
+    def post_forward_hook(self, outputs: list, quant_outputs: list, quant_configs: list) -> list:
+        for output_var, quant_config in zip(outputs, quant_configs):
+            if quant_config in self._observer_table:
+                self._observer_table[quant_config].observe(output_var)
+        return quant_outputs
+
+    def render_quantization_config(self):
+        for _, observer in self._observer_table.items():
+            observer.render_quantization_config()
+            observer.report()
+
+    def __str__(self) -> str:
+        return ''.join([observer.__str__() + '\n' for _, observer in self._observer_table.items()])
+
+
+class OperationObserver:
+    """observer/__init__.py:75-124."""
+    def __init__(self, operation, monitor_parameter: bool = True, monitor_outputs: bool = True,
+                 monitor_inputs: bool = True) -> None:
+        if not hasattr(operation, 'config'):
+            raise TypeError(f'Only QuantableOP instance can apply an Observer, while {type(operation)} was given.')
+        self._operation = operation
+        self._hook = self.build_hook(monitor_parameter=monitor_parameter, monitor_outputs=monitor_outputs,
+                                     monitor_inputs=monitor_inputs)
+
+    def render_quantization_config(self):
+        self.hook.render_quantization_config()
+
+    def build_hook(self, monitor_parameter: bool, monitor_outputs: bool, monitor_inputs: bool) -> CalibrationHook:
+        observer_table = {}
+        for var, config in zip(self._operation.inputs, self._operation.config.input_quantization_config):
+            if is_initial(config):
+                if var in self._operation.parameters and monitor_parameter:
+                    observer_table[config] = TensorObserverFactroy.build_observer(var, config)
+                elif monitor_inputs:
+                    observer_table[config] = TensorObserverFactroy.build_observer(var, config)
+        if monitor_outputs:
+            for var, config in zip(self._operation.outputs, self._operation.config.output_quantization_config):
+                if is_initial(config):
+                    observer_table[config] = TensorObserverFactroy.build_observer(var, config)
+        return CalibrationHook(operation=self._operation, observer_table=observer_table)
+
+    @ property
+    def hook(self) -> CalibrationHook:
+        return self._hook
+
+    def observers(self) -> List[BaseTensorObserver]:
+        return list(self._hook._observer_table.values())
+
+    def report(self) -> str:
+        return str(self._hook)
+
+
+# ------------------------------------------------------------------------------ batched render
+def render_observers(observers: Sequence[BaseTensorObserver]) -> None:
+    """Render many observers with a bounded number of kernel launches and host synchronisations:
+
+    1. every pending running range is fetched with ONE device->host copy;
+    2. histogram observers that are ready to search are grouped by (kind, bins, levels ...) and each
+       group is searched by ONE launch (KLLosses / MseSearch) and ONE device->host copy;
+    3. each observer's own ``render_quantization_config()`` then finishes on the host values.
+
+    Results are identical to rendering the observers one by one."""
+    observers = [ob for ob in observers if is_initial(ob._quant_cfg)]
+    # 1. ranges
+    pend = [(ob, ob.pending_range()) for ob in observers]
+    pend = [(ob, r) for ob, r in pend if r is not None]
+    if pend:
+        flat = torch.cat([r.reshape(-1) for _, r in pend]).cpu().numpy()
+        pos = 0
+        for ob, r in pend:
+            n = r.numel()
+            ob.take_range(flat[pos: pos + n].reshape(tuple(r.shape)))
+            pos += n
+    # 2. searches
+    groups: Dict[tuple, List[TorchHistObserver]] = {}
+    for ob in observers:
+        if isinstance(ob, TorchHistObserver) and ob._phase == 'Collating Hist' and ob._hist is not None:
+            if ob._quant_cfg.policy.has_property(P.PER_TENSOR):
+                groups.setdefault(ob.search_key(), []).append(ob)
+    for key, obs in groups.items():
+        hists = torch.stack([ob._hist for ob in obs])
+        if key[0] == 'kl':
+            if any(ob._quant_cfg.policy.has_property(P.ASYMMETRICAL) for ob in obs): continue   # raises at render
+            losses = CUDA.KLLosses(hists, key[2]).cpu().numpy()
+            for ob, l in zip(obs, losses): ob.take_losses(l)
+        else:
+            dev = hists.device
+            hs = torch.tensor([ob._hist_scale for ob in obs], dtype=torch.float64, device=dev)
+            mn = torch.tensor([ob._min for ob in obs], dtype=torch.float64, device=dev)
+            best = CUDA.MseSearch(hists, hs, mn, key[2], key[3], key[4]).cpu().numpy()
+            for ob, b in zip(obs, best): ob.take_best(b)
+    # 3. host finish
+    for ob in observers:
+        ob.render_quantization_config()
