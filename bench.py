@@ -97,9 +97,11 @@ def main():
     ap.add_argument('--bins', type=int, default=2048)
     ap.add_argument('--method', type=str, default='kl')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
     args = ap.parse_args()
 
     rank, world, local = setup_dist(args.gpus)
+    torch.backends.cudnn.benchmark = bool(args.miopen_find)
     dev = f'cuda:{local}'
     import ppq_amd  # noqa: F401  (fails loudly without libppq_hip.so)
     from ppq_amd import _lib

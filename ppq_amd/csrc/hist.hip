@@ -1,16 +1,27 @@
 // hist.hip -- calibration histograms for gfx950 (replaces the global-atomic kernels of
 // ppq/csrc/cuda/sort.cu:75-218).
 //
-// Design: the input is streamed once with 16-B loads; every wavefront owns a PRIVATE copy of the
-// histogram in LDS (ds_add_u32, no cross-wave contention; `copies` adapts so a workgroup stays
-// within 32 KiB of LDS), the copies are merged after a barrier and only NON-ZERO bins are flushed
-// with one global atomic each.  Heavily repeated values (ReLU zeros all land in bin 0) would
-// serialise the LDS atomic unit, so every wave keeps one "hot bin" in registers (see WaveHist).
-// The number of workgroups is bounded (kHistBlocksPerCU per CU) because every workgroup pays a
-// flush of up to `bins` global atomics.
+// Bin rule == reference, bit for bit: b = floor(|x| / hist_scale) [sym] or
+// floor((x - min) / hist_scale) [asym] with the IEEE quotient and a saturating float->int
+// conversion (NaN -> bin 0); b > bins-1 (asym: or b < 0) is dropped (clip_outliers) or clamped.
 //
-// Bin rule == reference: b = floor(|x| / hist_scale) [sym] or floor((x - min) / hist_scale)
-// [asym] with IEEE division and a saturating float->int conversion (NaN -> bin 0).
+// Design (the kernel is VALU-issue bound on gfx950, not LDS- or HBM-bound: every wave64 VALU
+// instruction occupies its SIMD for ~4 cycles, so the instruction count per element is what is
+// optimised):
+//   * one streaming pass, 16-B loads, software pipelined: the next trip's kHistU loads per lane are
+//     in flight while the current trip is binned (and while the LDS histogram is zeroed);
+//   * the quotient comes from a reciprocal multiply with a provable exactness test and a rare
+//     true-division fallback (quotient_is_safe), ONE divergent region per float4;
+//   * every wavefront group owns a private LDS copy of the histogram (ds_add_u32); nothing is
+//     predicated: clipped / out-of-range / hot values are redirected to a per-lane "trash" slot
+//     behind the histogram, so the ds_add is unconditional and conflict free;
+//   * heavily repeated values (ReLU zeros, saturated or already-quantised activations) would
+//     serialise the LDS atomic unit (a k-way same-address ds_add costs ~k cycles): each wave keeps
+//     one wave-uniform "hot bin" whose hits are counted in a VGPR instead (WaveAcc);
+//   * no global atomics on the hot path: every workgroup stores its merged histogram to a scratch
+//     row with plain coalesced stores and hist_reduce_kernel adds the column sums into the caller's
+//     histogram (hundreds of workgroups x thousands of bins of same-line device atomics serialise
+//     at ~12 ns each and would cost more than the streaming pass).
 #include <cstdlib>
 
 #include "common.hpp"
@@ -20,60 +31,107 @@ namespace ppqhip {
 constexpr int kMaxLdsBins = 16384;     // 64 KiB of int32 per copy at most
 constexpr int kLdsBudgetInts = 8192;   // target: copies * bins <= 8192 ints (32 KiB) per workgroup
 constexpr int kHistU = 4;              // float4 loads in flight per lane
+constexpr int kHistMaxBlock = 1024;    // histogram workgroups: 256 .. 1024 threads (runtime)
+constexpr int kTrash = 64;             // per-lane trash slots behind every histogram copy
+constexpr int kHotMin = 12;            // lanes that must share the candidate bin to make it hot
 
 static int env_int(const char* name, int dflt) {
     const char* v = getenv(name);
     return v ? atoi(v) : dflt;
 }
-static int hist_blocks_per_cu() { static int v = env_int("PPQHIP_HIST_BLOCKS_PER_CU", 4); return v; }
-static int hist_peel() { static int v = env_int("PPQHIP_HIST_HOT", 1); return v; }
+static int hist_blocks_per_cu() { static int v = env_int("PPQHIP_HIST_BLOCKS_PER_CU", 1); return v; }
+static int hist_block() { static int v = env_int("PPQHIP_HIST_BLOCK", 1024); return v; }
+static int hist_hot() { static int v = env_int("PPQHIP_HIST_HOT", 1); return v; }
 static int hist_copies() { static int v = env_int("PPQHIP_HIST_COPIES", 0); return v; }
 
 struct BinRule {
     float a;      // sym: unused; asym: min
     float hs;     // hist_scale
+    float rcp;    // RN(1 / hs), see quotient_is_safe
     int bins;
     int clip;     // clip_outliers
     int asym;
 };
-
-// branch-free bin rule; `valid` is cleared for values the reference skips (clip_outliers)
-template <bool ASYM>
-__device__ __forceinline__ int bin_index(float v, const BinRule& r, bool& valid) {
-    const float t = ASYM ? (v - r.a) / r.hs : __builtin_fabsf(v) / r.hs;
-    int b = f2i_sat(__builtin_floorf(t));
-    const int last = r.bins - 1;
-    bool out = b > last;
-    if (ASYM) out = out || (b < 0);
-    valid = valid && !(out && r.clip);
-    b = b > last ? last : b;
-    if (ASYM) b = b < 0 ? 0 : b;
-    return b;
+static BinRule make_rule(float a, float hs, int bins, int clip, int asym) {
+    BinRule r; r.a = a; r.hs = hs; r.rcp = 1.0f / hs; r.bins = bins; r.clip = clip; r.asym = asym;
+    return r;
 }
 
-__device__ __forceinline__ bool bin_of(float v, const BinRule& r, int* b_out) {
-    bool valid = true;
-    *b_out = r.asym ? bin_index<true>(v, r, valid) : bin_index<false>(v, r, valid);
-    return valid;
+// floor(RN(a / hs)) without the 11-instruction IEEE division on the common path.
+//   t = RN(a * RN(1/hs)) differs from q = RN(a / hs) by less than |t| * 0.8 * 2^-22 (two roundings of
+//   2^-24 relative for t, one for q), so floor(t) != floor(q) requires an integer within that distance
+//   of t -- necessarily rint(t).  When |t - rint(t)| >= |t| * 2^-22 (an exact float test: the
+//   difference is exact and the bound is a power-of-two scaling) the floors are provably equal;
+//   otherwise (a few lanes in 10^4, plus every inf / NaN / huge outlier / degenerate hs) the lane
+//   takes the true division.  The result is therefore ALWAYS the reference's floor(a / hs).
+__device__ __forceinline__ bool quotient_is_safe(float t) {
+    return __builtin_fabsf(t - __builtin_rintf(t)) >= __builtin_fabsf(t) * 0x1p-22f;
 }
 
-// Per-wavefront accumulation into the wave's private LDS histogram.
-// HOT enables the hot-bin register: a value that many lanes share (ReLU zeros, saturated or
-// already-quantised activations) would serialise the LDS atomic unit (a k-way same-address
-// ds_add costs ~k cycles).  Each wave therefore keeps ONE wave-uniform "hot bin" in an SGPR and
-// every lane counts its hits on that bin in a VGPR instead of touching LDS; the counter is
-// flushed with a single wave reduction when the hot bin changes and at the end.  The hot bin is
-// re-elected once per trip (16 elements per lane) from the first element of the trip: the bin of
-// the first lane becomes hot when at least kHotMin lanes share it.
-constexpr int kHotMin = 12;
-
-template <bool HOT>
-struct WaveHist {
+// Per-wavefront accumulator.  h points at this wave's histogram copy: bins counters followed by
+// kTrash per-lane trash slots.  ASYM / CLIP specialise the bin rule, HOT enables the hot-bin register.
+template <bool ASYM, bool CLIP, bool HOT>
+struct WaveAcc {
     int* h;
-    int hot_bin;     // wave-uniform
+    float a0, hs, rcp;
+    int last;        // bins - 1
+    int trash;       // bins + lane
+    int hot_bin;     // wave-uniform, -1 = none
     int hot_cnt;     // per lane
 
-    __device__ __forceinline__ void init(int* hist) { h = hist; hot_bin = -1; hot_cnt = 0; }
+    __device__ __forceinline__ void init(int* copy, const BinRule& r) {
+        h = copy; a0 = r.a; hs = r.hs; rcp = r.rcp; last = r.bins - 1;
+        trash = r.bins + (int)(threadIdx.x & 63);
+        hot_bin = -1; hot_cnt = 0;
+    }
+
+    __device__ __forceinline__ float arg(float v) const { return ASYM ? (v - a0) : __builtin_fabsf(v); }
+
+    // quotient -> effective slot (bin, or the lane's trash slot when the reference skips the value)
+    __device__ __forceinline__ int slot_of(float t) const {
+        const int b = f2i_sat(__builtin_floorf(t));
+        if (CLIP) return ((unsigned)b > (unsigned)last) ? trash : b;      // b < 0 wraps above `last`
+        if (ASYM) return b < 0 ? 0 : (b > last ? last : b);
+        return b > last ? last : b;
+    }
+
+    __device__ __forceinline__ void commit(int slot) {
+        if (HOT) {
+            const bool hit = slot == hot_bin;
+            hot_cnt += hit ? 1 : 0;
+            slot = hit ? trash : slot;
+        }
+        atomicAdd(&h[slot], 1);
+    }
+
+    __device__ __forceinline__ void add4(const float4& v, bool in) {
+        const float ax = arg(v.x), ay = arg(v.y), az = arg(v.z), aw = arg(v.w);
+        float tx = ax * rcp, ty = ay * rcp, tz = az * rcp, tw = aw * rcp;
+        const bool sx = quotient_is_safe(tx), sy = quotient_is_safe(ty), sz = quotient_is_safe(tz),
+                   sw = quotient_is_safe(tw);
+        if (!(sx && sy && sz && sw)) {          // rare: some lane sits next to a bin boundary
+            if (!sx) tx = ax / hs;
+            if (!sy) ty = ay / hs;
+            if (!sz) tz = az / hs;
+            if (!sw) tw = aw / hs;
+        }
+        int bx = slot_of(tx), by = slot_of(ty), bz = slot_of(tz), bw = slot_of(tw);
+        if (!in) { bx = trash; by = trash; bz = trash; bw = trash; }
+        commit(bx); commit(by); commit(bz); commit(bw);
+    }
+
+    __device__ __forceinline__ int slot1(float v) const {
+        const float a = arg(v);
+        float t = a * rcp;
+        if (!quotient_is_safe(t)) t = a / hs;
+        return slot_of(t);
+    }
+
+    __device__ __forceinline__ void add1(float v, bool in) {
+        int b = slot1(v);
+        if (!in) b = trash;
+        commit(b);
+    }
 
     __device__ __forceinline__ void flush_hot() {
         if (!HOT) return;
@@ -84,9 +142,12 @@ struct WaveHist {
         hot_cnt = 0;
     }
 
-    // all lanes of the wave must call this together (uniform control flow)
-    __device__ __forceinline__ void elect(int b, bool valid) {
+    // Re-elect the hot bin from one sample value per lane; all lanes of the wave call this together.
+    // The bin of the first in-range lane becomes hot when at least kHotMin lanes share it.
+    __device__ __forceinline__ void elect(float v, bool in) {
         if (!HOT) return;
+        const int b = slot1(v);
+        const bool valid = in && b <= last;
         const unsigned long long act = __ballot(valid);
         if (act == 0ull) return;
         const int leader = __ffsll((long long)act) - 1;
@@ -94,15 +155,6 @@ struct WaveHist {
         if (cand == hot_bin) return;
         const int cnt = __popcll(__ballot(valid && b == cand));
         if (cnt >= kHotMin) { flush_hot(); hot_bin = cand; }
-    }
-
-    __device__ __forceinline__ void add(int b, bool valid) {
-        if (HOT) {
-            const bool is_hot = b == hot_bin;
-            hot_cnt += (valid && is_hot) ? 1 : 0;
-            valid = valid && !is_hot;
-        }
-        if (valid) atomicAdd(&h[b], 1);
     }
 };
 
@@ -112,17 +164,15 @@ __device__ __forceinline__ void lds_hist_zero(int* lds, int total) {
 }
 
 // partial == nullptr: merge the copies and flush the non-zero bins with global atomics (few
-// workgroups).  Otherwise store this workgroup's merged histogram to partial[blockIdx.x][bins] with
-// plain coalesced stores; hist_reduce_kernel adds the column sums into the caller's histogram.
-// (Hundreds of workgroups x thousands of bins of device-scope atomics on a few KiB of addresses
-// serialise in the L2 atomic units and would cost more than the streaming pass itself.)
+// workgroups).  Otherwise store this workgroup's merged histogram to partial[blockIdx.x][bins].
 __device__ __forceinline__ void lds_hist_flush(const int* lds, int bins, int copies, int* __restrict__ hist,
                                                int* __restrict__ partial = nullptr) {
     __syncthreads();
+    const int pitch = bins + kTrash;
     int* dst = partial ? partial + (size_t)blockIdx.x * bins : nullptr;
     for (int b = threadIdx.x; b < bins; b += blockDim.x) {
         int s = 0;
-        for (int c = 0; c < copies; c++) s += lds[c * bins + b];
+        for (int c = 0; c < copies; c++) s += lds[c * pitch + b];
         if (dst) dst[b] = s;
         else if (s) atomicAdd(&hist[b], s);
     }
@@ -150,78 +200,117 @@ __global__ __launch_bounds__(kBlock) void hist_reduce_kernel(const int* __restri
     if (s) atomicAdd(&hist[b], s);
 }
 
-template <bool PEEL, bool ASYM>
-__global__ __launch_bounds__(kBlock) void hist_t_lds_kernel(const float* __restrict__ x, uint32_t n, int vec_ok,
-                                                            BinRule rule, int copies, int* __restrict__ hist,
-                                                            int* __restrict__ partial) {
-    extern __shared__ int lds[];
-    lds_hist_zero(lds, copies * rule.bins);
-    WaveHist<PEEL> wh;
-    wh.init(lds + ((threadIdx.x >> 6) % copies) * rule.bins);
-    const uint32_t stride = gridDim.x * kBlock;
-    uint32_t done = 0;
-    if (vec_ok) {
-        const uint32_t nvec = n >> 2;
-        const float4* xv = reinterpret_cast<const float4*>(x);
-        // kHistU independent 16-B loads in flight per lane (the loop is otherwise bound by one HBM
-        // round trip per trip); uniform trip count so the ballots always see whole wavefronts
-        const uint32_t trips = (nvec + stride * kHistU - 1) / (stride * kHistU);
-        uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-        for (uint32_t t = 0; t < trips; t++, v += stride * kHistU) {
-            float4 a[kHistU];
+// Shared streaming loop.  FQ = true additionally writes out = fake_quant(x) (fused calibration step).
+template <bool ASYM, bool CLIP, bool HOT, bool FQ, int R>
+__device__ __forceinline__ void hist_stream(const float* __restrict__ x, uint32_t n, int vec_ok, const BinRule& rule,
+                                            int copies, int* lds, float* __restrict__ out, float s, int o, int qmin,
+                                            int qmax, int rounding) {
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t nvec = vec_ok ? (n >> 2) : 0u;
+    const float4* xv = reinterpret_cast<const float4*>(x);
+    float4* ov = reinterpret_cast<float4*>(out);
+    // the trip count is wave-uniform, so the ballots of WaveAcc::elect always see whole wavefronts
+    const uint32_t trips = (nvec + stride * kHistU - 1) / (stride * kHistU);
+    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    float4 cur[kHistU], nxt[kHistU];
 #pragma unroll
-            for (int k = 0; k < kHistU; k++)
-                a[k] = (v + k * stride < nvec) ? xv[v + k * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < kHistU; k++)
+        cur[k] = (trips > 0 && v + k * stride < nvec) ? xv[v + k * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int pitch = rule.bins + kTrash;
+    lds_hist_zero(lds, copies * pitch);          // first trip's loads are in flight meanwhile
+    WaveAcc<ASYM, CLIP, HOT> acc;
+    acc.init(lds + ((threadIdx.x >> 6) % copies) * pitch, rule);
+    for (uint32_t t = 0; t < trips; t++, v += stride * kHistU) {
+        const uint32_t vn = v + stride * kHistU;
+        const bool more = t + 1 < trips;
 #pragma unroll
-            for (int k = 0; k < kHistU; k++) {
-                const bool in = v + k * stride < nvec;
-                bool o0 = in, o1 = in, o2 = in, o3 = in;
-                const int b0 = bin_index<ASYM>(a[k].x, rule, o0);
-                const int b1 = bin_index<ASYM>(a[k].y, rule, o1);
-                const int b2 = bin_index<ASYM>(a[k].z, rule, o2);
-                const int b3 = bin_index<ASYM>(a[k].w, rule, o3);
-                if (k == 0) wh.elect(b0, o0);
-                wh.add(b0, o0);
-                wh.add(b1, o1);
-                wh.add(b2, o2);
-                wh.add(b3, o3);
+        for (int k = 0; k < kHistU; k++)
+            nxt[k] = (more && vn + k * stride < nvec) ? xv[vn + k * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc.elect(cur[0].x, v < nvec);
+#pragma unroll
+        for (int k = 0; k < kHistU; k++) {
+            const bool in = v + k * stride < nvec;
+            if (FQ && in) {
+                float4 r;
+                r.x = fq_linear_scalar<R>(cur[k].x, s, o, qmin, qmax, rounding);
+                r.y = fq_linear_scalar<R>(cur[k].y, s, o, qmin, qmax, rounding);
+                r.z = fq_linear_scalar<R>(cur[k].z, s, o, qmin, qmax, rounding);
+                r.w = fq_linear_scalar<R>(cur[k].w, s, o, qmin, qmax, rounding);
+                ov[v + k * stride] = r;
             }
+            acc.add4(cur[k], in);
         }
-        done = nvec << 2;
+#pragma unroll
+        for (int k = 0; k < kHistU; k++) cur[k] = nxt[k];
     }
-    {   // scalar remainder (whole tensor when unaligned)
+    {   // scalar remainder (the whole tensor when it is not 16-B aligned)
+        const uint32_t done = nvec << 2;
         const uint32_t rem = n - done;
-        const uint32_t trips = (rem + stride - 1) / stride;
-        uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-        for (uint32_t t = 0; t < trips; t++, i += stride) {
-            bool ok = i < rem;
-            const int b = bin_index<ASYM>(ok ? x[done + i] : 0.f, rule, ok);
-            wh.add(b, ok);
+        const uint32_t rtrips = (rem + stride - 1) / stride;
+        uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+        for (uint32_t t = 0; t < rtrips; t++, i += stride) {
+            const bool in = i < rem;
+            const float a = in ? x[done + i] : 0.f;
+            if (FQ && in) out[done + i] = fq_linear_scalar<R>(a, s, o, qmin, qmax, rounding);
+            if ((t & 15u) == 0) acc.elect(a, in);
+            acc.add1(a, in);
         }
     }
-    wh.flush_hot();
+    acc.flush_hot();
+}
+
+template <bool ASYM, bool CLIP, bool HOT>
+__global__ __launch_bounds__(kHistMaxBlock) void hist_t_lds_kernel(const float* __restrict__ x, uint32_t n, int vec_ok,
+                                                                   BinRule rule, int copies, int* __restrict__ hist,
+                                                                   int* __restrict__ partial) {
+    extern __shared__ int lds[];
+    hist_stream<ASYM, CLIP, HOT, false, 0>(x, n, vec_ok, rule, copies, lds, nullptr, 0.f, 0, 0, 0, 0);
+    lds_hist_flush(lds, rule.bins, copies, hist, partial);
+}
+
+// fused: out = fake_quant(x) (== fq_linear_t) and hist += histogram(x) (== hist_sym_t), one read
+template <int R, bool CLIP, bool HOT>
+__global__ __launch_bounds__(kHistMaxBlock) void fq_linear_t_hist_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
+    float* __restrict__ out, uint32_t n, int vec_ok, int qmin, int qmax, int rounding, BinRule rule, int copies,
+    int* __restrict__ hist, int* __restrict__ partial) {
+    extern __shared__ int lds[];
+    const float s = scale[0];
+    const int o = round_offset(offset[0]);
+    hist_stream<false, CLIP, HOT, true, R>(x, n, vec_ok, rule, copies, lds, out, s, o, qmin, qmax, rounding);
     lds_hist_flush(lds, rule.bins, copies, hist, partial);
 }
 
 // histograms too large for LDS: global atomics (the reference's strategy)
+__device__ __forceinline__ bool bin_of(float v, const BinRule& r, int* b_out) {
+    const float a = r.asym ? (v - r.a) : __builtin_fabsf(v);
+    int b = f2i_sat(__builtin_floorf(a / r.hs));
+    const int last = r.bins - 1;
+    bool out = b > last;
+    if (r.asym) out = out || (b < 0);
+    *b_out = b < 0 ? 0 : (b > last ? last : b);
+    return !(out && r.clip);
+}
+
 __global__ __launch_bounds__(kBlock) void hist_t_global_kernel(const float* __restrict__ x, uint32_t n, BinRule rule,
                                                                int* __restrict__ hist) {
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        int b = 0;
+        int b;
         if (bin_of(x[i], rule, &b)) atomicAdd(&hist[b], 1);
     }
 }
 
 // per channel, long rows: workgroup = (row, chunk); one channel per workgroup -> LDS histogram
-template <bool PEEL>
+template <bool CLIP>
 __global__ __launch_bounds__(kBlock) void hist_c_row_kernel(const float* __restrict__ x, uint32_t epc, FastDiv chunks,
                                                             FastDiv num_channel, uint32_t chunk_elems, BinRule rule,
                                                             int copies, int* __restrict__ hist) {
     extern __shared__ int lds[];
-    lds_hist_zero(lds, copies * rule.bins);
-    WaveHist<PEEL> wh;
-    wh.init(lds + ((threadIdx.x >> 6) % copies) * rule.bins);
+    const int pitch = rule.bins + kTrash;
+    lds_hist_zero(lds, copies * pitch);
+    WaveAcc<false, CLIP, true> acc;
+    acc.init(lds + ((threadIdx.x >> 6) % copies) * pitch, rule);
     const uint32_t row = fdiv(blockIdx.x, chunks);
     const uint32_t chunk = blockIdx.x - row * chunks.d;
     const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
@@ -232,12 +321,11 @@ __global__ __launch_bounds__(kBlock) void hist_c_row_kernel(const float* __restr
     uint32_t j = lo + threadIdx.x;
     for (uint32_t t = 0; t < trips; t++, j += kBlock) {
         const bool in = j < hi;
-        int b = 0;
-        const bool ok = in && bin_of(in ? xr[j] : 0.f, rule, &b);
-        if ((t & 15u) == 0) wh.elect(b, ok);
-        wh.add(b, ok);
+        const float a = in ? xr[j] : 0.f;
+        if ((t & 15u) == 0) acc.elect(a, in);
+        acc.add1(a, in);
     }
-    wh.flush_hot();
+    acc.flush_hot();
     lds_hist_flush(lds, rule.bins, copies, hist + (size_t)c * rule.bins);
 }
 
@@ -246,80 +334,13 @@ __global__ __launch_bounds__(kBlock) void hist_c_global_kernel(const float* __re
                                                                BinRule rule, int* __restrict__ hist) {
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
-        int b = 0;
+        int b;
         if (bin_of(x[i], rule, &b)) {
             const uint32_t row = fdiv(i, elem_per_channel);
             const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
             atomicAdd(&hist[(size_t)c * rule.bins + b], 1);
         }
     }
-}
-
-// fused: out = fake_quant(x) (== fq_linear_t) and hist += histogram(x) (== hist_sym_t), one read
-template <int R, bool PEEL>
-__global__ __launch_bounds__(kBlock) void fq_linear_t_hist_kernel(
-    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
-    float* __restrict__ out, uint32_t n, int vec_ok, int qmin, int qmax, int rounding, BinRule rule, int copies,
-    int* __restrict__ hist, int* __restrict__ partial) {
-    extern __shared__ int lds[];
-    lds_hist_zero(lds, copies * rule.bins);
-    WaveHist<PEEL> wh;
-    wh.init(lds + ((threadIdx.x >> 6) % copies) * rule.bins);
-    const float s = scale[0];
-    const int o = round_offset(offset[0]);
-    const uint32_t stride = gridDim.x * kBlock;
-    uint32_t done = 0;
-    if (vec_ok) {
-        const uint32_t nvec = n >> 2;
-        const float4* xv = reinterpret_cast<const float4*>(x);
-        float4* ov = reinterpret_cast<float4*>(out);
-        const uint32_t trips = (nvec + stride * kHistU - 1) / (stride * kHistU);
-        uint32_t v = blockIdx.x * kBlock + threadIdx.x;
-        for (uint32_t t = 0; t < trips; t++, v += stride * kHistU) {
-            float4 a[kHistU];
-#pragma unroll
-            for (int k = 0; k < kHistU; k++)
-                a[k] = (v + k * stride < nvec) ? xv[v + k * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-            for (int k = 0; k < kHistU; k++) {
-                const bool in = v + k * stride < nvec;
-                if (in) {
-                    float4 r;
-                    r.x = fq_linear_scalar<R>(a[k].x, s, o, qmin, qmax, rounding);
-                    r.y = fq_linear_scalar<R>(a[k].y, s, o, qmin, qmax, rounding);
-                    r.z = fq_linear_scalar<R>(a[k].z, s, o, qmin, qmax, rounding);
-                    r.w = fq_linear_scalar<R>(a[k].w, s, o, qmin, qmax, rounding);
-                    ov[v + k * stride] = r;
-                }
-                bool o0 = in, o1 = in, o2 = in, o3 = in;
-                const int b0 = bin_index<false>(a[k].x, rule, o0);
-                const int b1 = bin_index<false>(a[k].y, rule, o1);
-                const int b2 = bin_index<false>(a[k].z, rule, o2);
-                const int b3 = bin_index<false>(a[k].w, rule, o3);
-                if (k == 0) wh.elect(b0, o0);
-                wh.add(b0, o0);
-                wh.add(b1, o1);
-                wh.add(b2, o2);
-                wh.add(b3, o3);
-            }
-        }
-        done = nvec << 2;
-    }
-    {
-        const uint32_t rem = n - done;
-        const uint32_t trips = (rem + stride - 1) / stride;
-        uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-        for (uint32_t t = 0; t < trips; t++, i += stride) {
-            const bool in = i < rem;
-            const float a = in ? x[done + i] : 0.f;
-            if (in) out[done + i] = fq_linear_scalar<R>(a, s, o, qmin, qmax, rounding);
-            bool ok = in;
-            const int b = bin_index<false>(a, rule, ok);
-            wh.add(b, ok);
-        }
-    }
-    wh.flush_hot();
-    lds_hist_flush(lds, rule.bins, copies, hist, partial);
 }
 
 static int validate(int64_t n, int64_t bins, const char* what) {
@@ -331,17 +352,20 @@ static int validate(int64_t n, int64_t bins, const char* what) {
     return PPQHIP_OK;
 }
 
-static int pick_copies(int bins) {
+static int pick_copies(int bins, int block) {
     int c = kLdsBudgetInts / bins;
     if (hist_copies() > 0) c = hist_copies();
     if (c < 1) c = 1;
-    if (c > kBlock / kWave) c = kBlock / kWave;
+    if (c > block / kWave) c = block / kWave;
     return c;
 }
 
+static size_t lds_bytes(int bins, int copies) { return sizeof(int) * (size_t)copies * (bins + kTrash); }
+
 static int hist_grid(int64_t n) {
-    // >= 4096 elements per workgroup so the flush (<= bins atomics) stays a minor term
-    return stream_grid(n, 4096, kNumCU * hist_blocks_per_cu());
+    // one trip (kHistU float4 per lane) per workgroup at least; bounded workgroup count: every
+    // workgroup pays LDS zeroing + a flush of `bins` counters
+    return stream_grid(n, (int64_t)hist_block() * 4 * kHistU, kNumCU * hist_blocks_per_cu());
 }
 
 constexpr int kAtomicFlushMaxBlocks = 8;
@@ -355,28 +379,41 @@ static int* partial_for(int grid, int bins, hipStream_t s, bool* failed) {
     return p;
 }
 
+static void launch_reduce(const int* partial, int grid, int bins, int32_t* hist, hipStream_t s) {
+    hipLaunchKernelGGL(hist_reduce_kernel, dim3((bins + kBlock - 1) / kBlock, kReduceSlices), dim3(kBlock), 0, s,
+                       partial, grid, bins, hist);
+}
+
 static int launch_hist_t(const float* x, int64_t n, BinRule rule, int32_t* hist, hipStream_t s) {
-    if (rule.bins <= kMaxLdsBins) {
-        const int copies = pick_copies(rule.bins);
-        const size_t lds = sizeof(int) * (size_t)copies * rule.bins;
-        const int vec_ok = aligned16(x) ? 1 : 0;
-        const int grid = hist_grid(n);
-        bool failed;
-        int* partial = partial_for(grid, rule.bins, s, &failed);
-        if (failed) return PPQHIP_ERR_HIP;
-#define PPQ_LAUNCH_HIST(P, A)                                                                                  \
-    hipLaunchKernelGGL((hist_t_lds_kernel<P, A>), dim3(grid), dim3(kBlock), lds, s, x, (uint32_t)n, vec_ok, rule, \
-                       copies, hist, partial)
-        if (hist_peel()) { if (rule.asym) PPQ_LAUNCH_HIST(true, true); else PPQ_LAUNCH_HIST(true, false); }
-        else { if (rule.asym) PPQ_LAUNCH_HIST(false, true); else PPQ_LAUNCH_HIST(false, false); }
-#undef PPQ_LAUNCH_HIST
-        if (partial)
-            hipLaunchKernelGGL(hist_reduce_kernel, dim3((rule.bins + kBlock - 1) / kBlock, kReduceSlices), dim3(kBlock), 0, s,
-                               (const int*)partial, grid, rule.bins, hist);
-    } else {
+    if (rule.bins > kMaxLdsBins) {
         hipLaunchKernelGGL(hist_t_global_kernel, dim3(stream_grid(n, kBlock * 4)), dim3(kBlock), 0, s, x, (uint32_t)n,
                            rule, hist);
+        return PPQHIP_OK;
     }
+    const int block = hist_block();
+    const int copies = pick_copies(rule.bins, block);
+    const size_t lds = lds_bytes(rule.bins, copies);
+    const int vec_ok = aligned16(x) ? 1 : 0;
+    const int grid = hist_grid(n);
+    bool failed;
+    int* partial = partial_for(grid, rule.bins, s, &failed);
+    if (failed) return PPQHIP_ERR_HIP;
+#define PPQ_LAUNCH_HIST(A, C, H)                                                                               \
+    hipLaunchKernelGGL((hist_t_lds_kernel<A, C, H>), dim3(grid), dim3(block), lds, s, x, (uint32_t)n, vec_ok, \
+                       rule, copies, hist, partial)
+    const int sel = (rule.asym ? 4 : 0) | (rule.clip ? 2 : 0) | (hist_hot() ? 1 : 0);
+    switch (sel) {
+        case 0: PPQ_LAUNCH_HIST(false, false, false); break;
+        case 1: PPQ_LAUNCH_HIST(false, false, true); break;
+        case 2: PPQ_LAUNCH_HIST(false, true, false); break;
+        case 3: PPQ_LAUNCH_HIST(false, true, true); break;
+        case 4: PPQ_LAUNCH_HIST(true, false, false); break;
+        case 5: PPQ_LAUNCH_HIST(true, false, true); break;
+        case 6: PPQ_LAUNCH_HIST(true, true, false); break;
+        default: PPQ_LAUNCH_HIST(true, true, true); break;
+    }
+#undef PPQ_LAUNCH_HIST
+    if (partial) launch_reduce(partial, grid, rule.bins, hist, s);
     return PPQHIP_OK;
 }
 
@@ -391,7 +428,7 @@ int ppqhip_hist_sym_t(const float* x, int64_t n, float hist_scale, int clip_outl
     if (int st = validate(n, num_bins, "hist_sym_t")) return st;
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_HIST_SYM_T, 4.0 * (double)n, s);
-    BinRule rule{0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, 0};
+    BinRule rule = make_rule(0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, 0);
     if (int st = launch_hist_t(x, n, rule, hist, s)) return st;
     return finish_launch("hist_sym_t");
 }
@@ -403,7 +440,7 @@ int ppqhip_hist_asym_t(const float* x, int64_t n, float min_value, float max_val
     LaunchScope scope(K_HIST_ASYM_T, 4.0 * (double)n, s);
     // float hist_scale = (max - min) / num_of_bins: sort.cu:123 (float / int64 -> float)
     const float hs = (max_value - min_value) / (float)num_bins;
-    BinRule rule{min_value, hs, (int)num_bins, clip_outliers ? 1 : 0, 1};
+    BinRule rule = make_rule(min_value, hs, (int)num_bins, clip_outliers ? 1 : 0, 1);
     if (int st = launch_hist_t(x, n, rule, hist, s)) return st;
     return finish_launch("hist_asym_t");
 }
@@ -416,16 +453,21 @@ int ppqhip_hist_sym_c(const float* x, int64_t n, int64_t num_channel, int64_t el
     }
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_HIST_SYM_C, 4.0 * (double)n, s);
-    BinRule rule{0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, 0};
+    BinRule rule = make_rule(0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, 0);
     const FastDiv nc = make_fastdiv((uint32_t)num_channel);
     if (elem_per_channel >= 1024 && num_bins <= kMaxLdsBins) {
-        const int copies = pick_copies(rule.bins);
-        const size_t lds = sizeof(int) * (size_t)copies * rule.bins;
+        const int copies = pick_copies(rule.bins, kBlock);
         const uint32_t chunk_elems = 16384;
         const uint32_t chunks = (uint32_t)((elem_per_channel + chunk_elems - 1) / chunk_elems);
         const int64_t rows = n / elem_per_channel;
-        hipLaunchKernelGGL((hist_c_row_kernel<true>), dim3((uint32_t)(rows * chunks)), dim3(kBlock), lds, s, x,
-                           (uint32_t)elem_per_channel, make_fastdiv(chunks), nc, chunk_elems, rule, copies, hist);
+        if (rule.clip)
+            hipLaunchKernelGGL((hist_c_row_kernel<true>), dim3((uint32_t)(rows * chunks)), dim3(kBlock),
+                               lds_bytes(rule.bins, copies), s, x, (uint32_t)elem_per_channel, make_fastdiv(chunks), nc,
+                               chunk_elems, rule, copies, hist);
+        else
+            hipLaunchKernelGGL((hist_c_row_kernel<false>), dim3((uint32_t)(rows * chunks)), dim3(kBlock),
+                               lds_bytes(rule.bins, copies), s, x, (uint32_t)elem_per_channel, make_fastdiv(chunks), nc,
+                               chunk_elems, rule, copies, hist);
     } else {
         hipLaunchKernelGGL(hist_c_global_kernel, dim3(stream_grid(n, kBlock * 4)), dim3(kBlock), 0, s, x, (uint32_t)n,
                            make_fastdiv((uint32_t)elem_per_channel), nc, rule, hist);
@@ -442,23 +484,31 @@ int ppqhip_fq_linear_t_hist_sym(const float* x, const float* scale, const float*
     }
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_FQ_HIST_FUSED, 8.0 * (double)n, s);
-    BinRule rule{0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, 0};
-    const int copies = pick_copies(rule.bins);
-    const size_t lds = sizeof(int) * (size_t)copies * rule.bins;
+    BinRule rule = make_rule(0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, 0);
+    const int block = hist_block();
+    const int copies = pick_copies(rule.bins, block);
+    const size_t lds = lds_bytes(rule.bins, copies);
     const int vec_ok = (aligned16(x) && aligned16(out)) ? 1 : 0;
     const int grid = hist_grid(n);
     bool failed;
     int* partial = partial_for(grid, rule.bins, s, &failed);
     if (failed) return PPQHIP_ERR_HIP;
-#define PPQ_LAUNCH_FUSED(R, H)                                                                                      \
-    hipLaunchKernelGGL((fq_linear_t_hist_kernel<R, H>), dim3(grid), dim3(kBlock), lds, s, x, scale, offset, out,    \
+#define PPQ_LAUNCH_FUSED(R, C, H)                                                                                   \
+    hipLaunchKernelGGL((fq_linear_t_hist_kernel<R, C, H>), dim3(grid), dim3(block), lds, s, x, scale, offset, out,  \
                        (uint32_t)n, vec_ok, clip_min, clip_max, rounding, rule, copies, hist, partial)
-    if (rounding == ROUND_HALF_EVEN) { if (hist_peel()) PPQ_LAUNCH_FUSED(ROUND_HALF_EVEN, true); else PPQ_LAUNCH_FUSED(ROUND_HALF_EVEN, false); }
-    else { if (hist_peel()) PPQ_LAUNCH_FUSED(-1, true); else PPQ_LAUNCH_FUSED(-1, false); }
+    const int sel = (rounding == ROUND_HALF_EVEN ? 4 : 0) | (rule.clip ? 2 : 0) | (hist_hot() ? 1 : 0);
+    switch (sel) {
+        case 0: PPQ_LAUNCH_FUSED(-1, false, false); break;
+        case 1: PPQ_LAUNCH_FUSED(-1, false, true); break;
+        case 2: PPQ_LAUNCH_FUSED(-1, true, false); break;
+        case 3: PPQ_LAUNCH_FUSED(-1, true, true); break;
+        case 4: PPQ_LAUNCH_FUSED(ROUND_HALF_EVEN, false, false); break;
+        case 5: PPQ_LAUNCH_FUSED(ROUND_HALF_EVEN, false, true); break;
+        case 6: PPQ_LAUNCH_FUSED(ROUND_HALF_EVEN, true, false); break;
+        default: PPQ_LAUNCH_FUSED(ROUND_HALF_EVEN, true, true); break;
+    }
 #undef PPQ_LAUNCH_FUSED
-    if (partial)
-        hipLaunchKernelGGL(hist_reduce_kernel, dim3((rule.bins + kBlock - 1) / kBlock, kReduceSlices), dim3(kBlock), 0, s,
-                           (const int*)partial, grid, rule.bins, hist);
+    if (partial) launch_reduce(partial, grid, rule.bins, hist, s);
     return finish_launch("fq_linear_t_hist_sym");
 }
 
