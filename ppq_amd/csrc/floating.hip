@@ -4,7 +4,7 @@
 // (ppq/csrc/cuda/common.cuh:154-226) bit for bit, including its quirk that an exact mantissa tie
 // under ROUND_HALF_EVEN rounds toward zero (nearbyint(0.5) == 0), which is NOT IEEE / OCP RNE --
 // so the hardware v_cvt_pk_fp8_f32 conversions are deliberately not used here.
-// Same streaming structure as linear.hip (float4 per lane, chip-sized grid-stride launch).
+// Same streaming structure as linear.hip (one contiguous tile of float4s per workgroup).
 #include "common.hpp"
 
 namespace ppqhip {
@@ -65,28 +65,27 @@ __device__ __forceinline__ float quant_float_scalar(float value, float scale, co
     return v > fmt.clip_max ? fmt.clip_max : (v < fmt.clip_min ? fmt.clip_min : v);
 }
 
-template <int R, int U>
-__global__ __launch_bounds__(kBlock) void fq_float_t_vec_kernel(
+// one contiguous tile of kBlock * U float4 per workgroup (see linear.hip)
+template <int R, int U, bool NT>
+__global__ __launch_bounds__(kBlock) void fq_float_t_tile_kernel(
     const float4* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
     float4* __restrict__ out, uint32_t nvec, const float* __restrict__ xtail, float* __restrict__ otail,
     int ntail, FloatFmt fmt, int rounding) {
     const float s = scale[0], o = offset[0];
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride * U) {
-        float4 a[U];
+    const uint32_t base = blockIdx.x * (kBlock * U) + threadIdx.x;
+    float4 a[U];
 #pragma unroll
-        for (int k = 0; k < U; k++)
-            if (v + k * stride < nvec) a[k] = x[v + k * stride];
+    for (int k = 0; k < U; k++)
+        if (base + k * kBlock < nvec) a[k] = load4<NT>(&x[base + k * kBlock]);
 #pragma unroll
-        for (int k = 0; k < U; k++) {
-            if (v + k * stride < nvec) {
-                float4 r;
-                r.x = (quant_float_scalar<R>(a[k].x, s, fmt, rounding) - o) * s;
-                r.y = (quant_float_scalar<R>(a[k].y, s, fmt, rounding) - o) * s;
-                r.z = (quant_float_scalar<R>(a[k].z, s, fmt, rounding) - o) * s;
-                r.w = (quant_float_scalar<R>(a[k].w, s, fmt, rounding) - o) * s;
-                out[v + k * stride] = r;
-            }
+    for (int k = 0; k < U; k++) {
+        if (base + k * kBlock < nvec) {
+            float4 r;
+            r.x = (quant_float_scalar<R>(a[k].x, s, fmt, rounding) - o) * s;
+            r.y = (quant_float_scalar<R>(a[k].y, s, fmt, rounding) - o) * s;
+            r.z = (quant_float_scalar<R>(a[k].z, s, fmt, rounding) - o) * s;
+            r.w = (quant_float_scalar<R>(a[k].w, s, fmt, rounding) - o) * s;
+            out[base + k * kBlock] = r;
         }
     }
     if (blockIdx.x == 0 && (int)threadIdx.x < ntail)
@@ -111,37 +110,35 @@ __global__ __launch_bounds__(kBlock) void fq_float_scalar_kernel(
     }
 }
 
-template <int R, int U>
-__global__ __launch_bounds__(kBlock) void fq_float_c_vec_kernel(
+template <int R, int U, bool NT>
+__global__ __launch_bounds__(kBlock) void fq_float_c_tile_kernel(
     const float4* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
     float4* __restrict__ out, uint32_t nvec, FastDiv vec_per_channel, FastDiv num_channel, FloatFmt fmt,
     int rounding) {
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t v = blockIdx.x * kBlock + threadIdx.x; v < nvec; v += stride * U) {
-        float4 a[U];
-        float s[U], o[U];
+    const uint32_t base = blockIdx.x * (kBlock * U) + threadIdx.x;
+    float4 a[U];
+    float s[U], o[U];
 #pragma unroll
-        for (int k = 0; k < U; k++) {
-            const uint32_t vv = v + k * stride;
-            if (vv < nvec) {
-                a[k] = x[vv];
-                const uint32_t row = fdiv(vv, vec_per_channel);
-                const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
-                s[k] = scale[c];
-                o[k] = offset[c];
-            }
+    for (int k = 0; k < U; k++) {
+        const uint32_t vv = base + k * kBlock;
+        if (vv < nvec) {
+            a[k] = load4<NT>(&x[vv]);
+            const uint32_t row = fdiv(vv, vec_per_channel);
+            const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
+            s[k] = scale[c];
+            o[k] = offset[c];
         }
+    }
 #pragma unroll
-        for (int k = 0; k < U; k++) {
-            const uint32_t vv = v + k * stride;
-            if (vv < nvec) {
-                float4 r;
-                r.x = (quant_float_scalar<R>(a[k].x, s[k], fmt, rounding) - o[k]) * s[k];
-                r.y = (quant_float_scalar<R>(a[k].y, s[k], fmt, rounding) - o[k]) * s[k];
-                r.z = (quant_float_scalar<R>(a[k].z, s[k], fmt, rounding) - o[k]) * s[k];
-                r.w = (quant_float_scalar<R>(a[k].w, s[k], fmt, rounding) - o[k]) * s[k];
-                out[vv] = r;
-            }
+    for (int k = 0; k < U; k++) {
+        const uint32_t vv = base + k * kBlock;
+        if (vv < nvec) {
+            float4 r;
+            r.x = (quant_float_scalar<R>(a[k].x, s[k], fmt, rounding) - o[k]) * s[k];
+            r.y = (quant_float_scalar<R>(a[k].y, s[k], fmt, rounding) - o[k]) * s[k];
+            r.z = (quant_float_scalar<R>(a[k].z, s[k], fmt, rounding) - o[k]) * s[k];
+            r.w = (quant_float_scalar<R>(a[k].w, s[k], fmt, rounding) - o[k]) * s[k];
+            out[vv] = r;
         }
     }
 }
@@ -177,7 +174,8 @@ static int validate(int64_t n, const char* what) {
     return PPQHIP_OK;
 }
 
-constexpr uint32_t kSmallVec = (uint32_t)kNumCU * 8 * kBlock;
+constexpr int64_t kStreamElems = 48ll << 20;   // >= 192 MiB: streaming loads (see linear.hip)
+constexpr int kTileU = 2;
 
 template <int R>
 static void launch_ft(const float* x, const float* scale, const float* offset, float* out, int64_t n,
@@ -187,13 +185,13 @@ static void launch_ft(const float* x, const float* scale, const float* offset, f
         const int ntail = (int)(n & 3);
         const float* xt = x + (size_t)nvec * 4;
         float* ot = out + (size_t)nvec * 4;
-        if (nvec <= kSmallVec)
-            hipLaunchKernelGGL((fq_float_t_vec_kernel<R, 1>), dim3(stream_grid(nvec, kBlock)), dim3(kBlock), 0, st,
-                               (const float4*)x, scale, offset, (float4*)out, nvec, xt, ot, ntail, fmt, rounding);
+        const dim3 grid((nvec + kBlock * kTileU - 1) / (kBlock * kTileU));
+        if (n >= kStreamElems)
+            hipLaunchKernelGGL((fq_float_t_tile_kernel<R, kTileU, true>), grid, dim3(kBlock), 0, st, (const float4*)x,
+                               scale, offset, (float4*)out, nvec, xt, ot, ntail, fmt, rounding);
         else
-            hipLaunchKernelGGL((fq_float_t_vec_kernel<R, 4>), dim3(stream_grid(nvec, kBlock * 4)), dim3(kBlock), 0,
-                               st, (const float4*)x, scale, offset, (float4*)out, nvec, xt, ot, ntail, fmt,
-                               rounding);
+            hipLaunchKernelGGL((fq_float_t_tile_kernel<R, kTileU, false>), grid, dim3(kBlock), 0, st, (const float4*)x,
+                               scale, offset, (float4*)out, nvec, xt, ot, ntail, fmt, rounding);
     } else {
         hipLaunchKernelGGL((fq_float_scalar_kernel<R>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, x, scale,
                            offset, out, (uint32_t)n, make_fastdiv(1), make_fastdiv(1), 0, fmt, rounding);
@@ -206,12 +204,13 @@ static void launch_fc(const float* x, const float* scale, const float* offset, f
     if (aligned16(x) && aligned16(out) && epc % 4 == 0) {
         const uint32_t nvec = (uint32_t)(n >> 2);
         const FastDiv vpc = make_fastdiv((uint32_t)(epc / 4)), nc = make_fastdiv((uint32_t)C);
-        if (nvec <= kSmallVec)
-            hipLaunchKernelGGL((fq_float_c_vec_kernel<R, 1>), dim3(stream_grid(nvec, kBlock)), dim3(kBlock), 0, st,
-                               (const float4*)x, scale, offset, (float4*)out, nvec, vpc, nc, fmt, rounding);
+        const dim3 grid((nvec + kBlock * kTileU - 1) / (kBlock * kTileU));
+        if (n >= kStreamElems)
+            hipLaunchKernelGGL((fq_float_c_tile_kernel<R, kTileU, true>), grid, dim3(kBlock), 0, st, (const float4*)x,
+                               scale, offset, (float4*)out, nvec, vpc, nc, fmt, rounding);
         else
-            hipLaunchKernelGGL((fq_float_c_vec_kernel<R, 4>), dim3(stream_grid(nvec, kBlock * 4)), dim3(kBlock), 0,
-                               st, (const float4*)x, scale, offset, (float4*)out, nvec, vpc, nc, fmt, rounding);
+            hipLaunchKernelGGL((fq_float_c_tile_kernel<R, kTileU, false>), grid, dim3(kBlock), 0, st, (const float4*)x,
+                               scale, offset, (float4*)out, nvec, vpc, nc, fmt, rounding);
     } else {
         hipLaunchKernelGGL((fq_float_scalar_kernel<R>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, x, scale,
                            offset, out, (uint32_t)n, make_fastdiv((uint32_t)epc), make_fastdiv((uint32_t)C), 1, fmt,

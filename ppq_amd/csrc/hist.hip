@@ -201,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void hist_reduce_kernel(const int* __restri
 }
 
 // Shared streaming loop.  FQ = true additionally writes out = fake_quant(x) (fused calibration step).
-template <bool ASYM, bool CLIP, bool HOT, bool FQ, int R>
+template <bool ASYM, bool CLIP, bool HOT, bool FQ, int R, bool NT>
 __device__ __forceinline__ void hist_stream(const float* __restrict__ x, uint32_t n, int vec_ok, const BinRule& rule,
                                             int copies, int* lds, float* __restrict__ out, float s, int o, int qmin,
                                             int qmax, int rounding) {
@@ -209,34 +209,38 @@ __device__ __forceinline__ void hist_stream(const float* __restrict__ x, uint32_
     const uint32_t nvec = vec_ok ? (n >> 2) : 0u;
     const float4* xv = reinterpret_cast<const float4*>(x);
     float4* ov = reinterpret_cast<float4*>(out);
-    // the trip count is wave-uniform, so the ballots of WaveAcc::elect always see whole wavefronts
-    const uint32_t trips = (nvec + stride * kHistU - 1) / (stride * kHistU);
-    uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    // Every workgroup owns one contiguous chunk of `trips` tiles (blockDim * kHistU float4 each): better
+    // DRAM-page / TLB locality than a grid-strided interleave.  The trip count is uniform over the
+    // whole grid, so the ballots of WaveAcc::elect always see whole wavefronts.
+    const uint32_t bd = blockDim.x;
+    const uint32_t tile = bd * kHistU;
+    const uint32_t trips = ((nvec + tile - 1) / tile + gridDim.x - 1) / gridDim.x;
+    const uint32_t hi = min((blockIdx.x + 1) * trips * tile, nvec);
+    uint32_t v = blockIdx.x * trips * tile + threadIdx.x;
     float4 cur[kHistU], nxt[kHistU];
 #pragma unroll
     for (int k = 0; k < kHistU; k++)
-        cur[k] = (trips > 0 && v + k * stride < nvec) ? xv[v + k * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+        cur[k] = (v + k * bd < hi) ? load4<NT>(&xv[v + k * bd]) : make_float4(0.f, 0.f, 0.f, 0.f);
     const int pitch = rule.bins + kTrash;
     lds_hist_zero(lds, copies * pitch);          // first trip's loads are in flight meanwhile
     WaveAcc<ASYM, CLIP, HOT> acc;
     acc.init(lds + ((threadIdx.x >> 6) % copies) * pitch, rule);
-    for (uint32_t t = 0; t < trips; t++, v += stride * kHistU) {
-        const uint32_t vn = v + stride * kHistU;
-        const bool more = t + 1 < trips;
+    for (uint32_t t = 0; t < trips; t++, v += tile) {
+        const uint32_t vn = v + tile;
 #pragma unroll
         for (int k = 0; k < kHistU; k++)
-            nxt[k] = (more && vn + k * stride < nvec) ? xv[vn + k * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
-        acc.elect(cur[0].x, v < nvec);
+            nxt[k] = (vn + k * bd < hi) ? load4<NT>(&xv[vn + k * bd]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc.elect(cur[0].x, v < hi);
 #pragma unroll
         for (int k = 0; k < kHistU; k++) {
-            const bool in = v + k * stride < nvec;
+            const bool in = v + k * bd < hi;
             if (FQ && in) {
                 float4 r;
                 r.x = fq_linear_scalar<R>(cur[k].x, s, o, qmin, qmax, rounding);
                 r.y = fq_linear_scalar<R>(cur[k].y, s, o, qmin, qmax, rounding);
                 r.z = fq_linear_scalar<R>(cur[k].z, s, o, qmin, qmax, rounding);
                 r.w = fq_linear_scalar<R>(cur[k].w, s, o, qmin, qmax, rounding);
-                ov[v + k * stride] = r;
+                ov[v + k * bd] = r;
             }
             acc.add4(cur[k], in);
         }
@@ -259,12 +263,12 @@ __device__ __forceinline__ void hist_stream(const float* __restrict__ x, uint32_
     acc.flush_hot();
 }
 
-template <bool ASYM, bool CLIP, bool HOT>
+template <bool ASYM, bool CLIP, bool HOT, bool NT>
 __global__ __launch_bounds__(kHistMaxBlock) void hist_t_lds_kernel(const float* __restrict__ x, uint32_t n, int vec_ok,
                                                                    BinRule rule, int copies, int* __restrict__ hist,
                                                                    int* __restrict__ partial) {
     extern __shared__ int lds[];
-    hist_stream<ASYM, CLIP, HOT, false, 0>(x, n, vec_ok, rule, copies, lds, nullptr, 0.f, 0, 0, 0, 0);
+    hist_stream<ASYM, CLIP, HOT, false, 0, NT>(x, n, vec_ok, rule, copies, lds, nullptr, 0.f, 0, 0, 0, 0);
     lds_hist_flush(lds, rule.bins, copies, hist, partial);
 }
 
@@ -277,7 +281,7 @@ __global__ __launch_bounds__(kHistMaxBlock) void fq_linear_t_hist_kernel(
     extern __shared__ int lds[];
     const float s = scale[0];
     const int o = round_offset(offset[0]);
-    hist_stream<false, CLIP, HOT, true, R>(x, n, vec_ok, rule, copies, lds, out, s, o, qmin, qmax, rounding);
+    hist_stream<false, CLIP, HOT, true, R, false>(x, n, vec_ok, rule, copies, lds, out, s, o, qmin, qmax, rounding);
     lds_hist_flush(lds, rule.bins, copies, hist, partial);
 }
 
@@ -398,9 +402,15 @@ static int launch_hist_t(const float* x, int64_t n, BinRule rule, int32_t* hist,
     bool failed;
     int* partial = partial_for(grid, rule.bins, s, &failed);
     if (failed) return PPQHIP_ERR_HIP;
-#define PPQ_LAUNCH_HIST(A, C, H)                                                                               \
-    hipLaunchKernelGGL((hist_t_lds_kernel<A, C, H>), dim3(grid), dim3(block), lds, s, x, (uint32_t)n, vec_ok, \
-                       rule, copies, hist, partial)
+#define PPQ_LAUNCH_HIST(A, C, H)                                                                                  \
+    do {                                                                                                          \
+        if (nt) hipLaunchKernelGGL((hist_t_lds_kernel<A, C, H, true>), dim3(grid), dim3(block), lds, s, x,       \
+                                   (uint32_t)n, vec_ok, rule, copies, hist, partial);                            \
+        else hipLaunchKernelGGL((hist_t_lds_kernel<A, C, H, false>), dim3(grid), dim3(block), lds, s, x,         \
+                                (uint32_t)n, vec_ok, rule, copies, hist, partial);                               \
+    } while (0)
+    static const int nt_env = env_int("PPQHIP_HIST_NT", -1);
+    const bool nt = nt_env >= 0 ? nt_env != 0 : n >= (48ll << 20);    // streaming loads beyond cache residency
     const int sel = (rule.asym ? 4 : 0) | (rule.clip ? 2 : 0) | (hist_hot() ? 1 : 0);
     switch (sel) {
         case 0: PPQ_LAUNCH_HIST(false, false, false); break;

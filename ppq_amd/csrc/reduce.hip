@@ -11,6 +11,7 @@
 //                        (12 + 12 + 8 bits, LDS histograms), no data movement.
 //   isotone_t            replaces Isotone_T (sort.cu:61-73): top-2 / bottom-2 reduction.
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -35,11 +36,12 @@ __device__ __forceinline__ void block_minmax_commit(float mn, float mx, float* g
 // partial == nullptr: commit with one pair of global atomics per workgroup (few workgroups);
 // otherwise write this workgroup's (min, max) to partial[2*blockIdx.x ..] for minmax_finish_kernel:
 // same-address device atomics serialise at ~12 ns each, which would dominate a 2048-workgroup launch.
+template <int U, bool NT>
 __global__ __launch_bounds__(kBlock) void minmax_t_kernel(const float* __restrict__ x, uint32_t n, int vec_ok,
                                                           float* __restrict__ minmax, float* __restrict__ partial) {
     __shared__ float lds[16];
     float mn = INFINITY, mx = -INFINITY;
-    stream_elems<4>(x, n, vec_ok != 0, [&](float a) { mn = fminf(mn, a); mx = fmaxf(mx, a); });
+    stream_elems<U, NT>(x, n, vec_ok != 0, [&](float a) { mn = fminf(mn, a); mx = fmaxf(mx, a); });
     if (partial == nullptr) { block_minmax_commit(mn, mx, &minmax[0], &minmax[1], lds); return; }
     mn = wave_min(mn);
     mx = wave_max(mx);
@@ -344,18 +346,24 @@ int ppqhip_minmax_t(const float* x, int64_t n, float* minmax, void* stream) {
     if (int st = validate(n, "minmax_t")) return st;
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_MINMAX_T, 4.0 * (double)n, s);
+    // 8 workgroups per CU, each streaming one contiguous chunk; streaming (nontemporal) loads once the
+    // tensor cannot be cache resident (sweep on MI355X, 205 MB: 5.7 TB/s vs 5.1 with plain loads)
+    const bool nt = n >= (48ll << 20);
     const int grid = stream_grid(n, kBlock * 4 * 4, kNumCU * 8);
-    if (grid <= 32) {
-        hipLaunchKernelGGL(minmax_t_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, aligned16(x) ? 1 : 0,
-                           minmax, (float*)nullptr);
-    } else {
-        float* partial = (float*)scratch(s, sizeof(float) * 2 * (size_t)grid);
+    float* partial = nullptr;
+    if (grid > 32) {
+        partial = (float*)scratch(s, sizeof(float) * 2 * (size_t)grid);
         if (partial == nullptr) return PPQHIP_ERR_HIP;
-        hipLaunchKernelGGL(minmax_t_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, aligned16(x) ? 1 : 0,
-                           minmax, partial);
+    }
+    if (nt)
+        hipLaunchKernelGGL((minmax_t_kernel<4, true>), dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n,
+                           aligned16(x) ? 1 : 0, minmax, partial);
+    else
+        hipLaunchKernelGGL((minmax_t_kernel<4, false>), dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n,
+                           aligned16(x) ? 1 : 0, minmax, partial);
+    if (partial)
         hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(kBlock), 0, s, (const float*)partial, (uint32_t)grid,
                            minmax);
-    }
     return finish_launch("minmax_t");
 }
 

@@ -27,6 +27,7 @@ def main():
     ap.add_argument('--relu', action='store_true')
     ap.add_argument('--bins', type=int, default=2048)
     ap.add_argument('--only', type=str, default='')
+    ap.add_argument('--rotate', type=int, default=1, help='cycle through this many distinct input tensors (defeats the 256 MiB Infinity Cache)')
     ap.add_argument('--tensors', type=str, default='A,B,Bx8,Bx32')
     args = ap.parse_args()
     dev = 'cuda'
@@ -35,8 +36,14 @@ def main():
     rows = []
     for name, shp in shapes.items():
         if name not in args.tensors.split(','): continue
-        x = torch.randn(*shp, device=dev)
-        if args.relu: x = torch.relu(x)
+        xs = [torch.randn(*shp, device=dev) for _ in range(args.rotate)]
+        if args.relu: xs = [torch.relu(t) for t in xs]
+        x = xs[0]
+        counter = [0]
+
+        def X():
+            counter[0] += 1
+            return xs[counter[0] % len(xs)]
         n = x.numel()
         C = shp[1]
         s1 = torch.tensor([0.03], device=dev); o1 = torch.zeros(1, device=dev)
@@ -47,17 +54,17 @@ def main():
         hs = float(x.abs().max()) / args.bins
         lo, hi = float(x.min()), float(x.max())
         cases = {
-            'fq_linear_t': (8, lambda: CUDA.LinearQuantize_T(x, s1, o1, -128, 127, 0)),
-            'fq_linear_c': (8, lambda: CUDA.LinearQuantize_C(x, sc, oc, 1, 0, 255, 0)),
-            'fq_float_t': (8, lambda: CUDA.FloatingQuantize_T(x, s1, o1)),
-            'hist_sym_t': (4, lambda: CUDA.Histogram_T(x, hist, hs)),
-            'hist_asym_t': (4, lambda: CUDA.Histogram_Asymmetric_T(lo, hi, x, hist)),
-            'minmax_t': (4, lambda: CUDA.MinMax_T(x, mm)),
-            'minmax_c': (4, lambda: CUDA.MinMax_C(x, 1, mins, maxs)),
-            'quantile_t': (4, lambda: CUDA.Quantile(x, 0.9999)),
-            'fq_t+hist fused': (8, lambda: CUDA.LinearQuantize_T_Histogram(x, s1, o1, hist, hs)),
-            'torch copy (ref)': (8, lambda: x.clone()),
-            'torch abs().max (ref)': (4, lambda: x.abs().max()),
+            'fq_linear_t': (8, lambda: CUDA.LinearQuantize_T(X(), s1, o1, -128, 127, 0)),
+            'fq_linear_c': (8, lambda: CUDA.LinearQuantize_C(X(), sc, oc, 1, 0, 255, 0)),
+            'fq_float_t': (8, lambda: CUDA.FloatingQuantize_T(X(), s1, o1)),
+            'hist_sym_t': (4, lambda: CUDA.Histogram_T(X(), hist, hs)),
+            'hist_asym_t': (4, lambda: CUDA.Histogram_Asymmetric_T(lo, hi, X(), hist)),
+            'minmax_t': (4, lambda: CUDA.MinMax_T(X(), mm)),
+            'minmax_c': (4, lambda: CUDA.MinMax_C(X(), 1, mins, maxs)),
+            'quantile_t': (4, lambda: CUDA.Quantile(X(), 0.9999)),
+            'fq_t+hist fused': (8, lambda: CUDA.LinearQuantize_T_Histogram(X(), s1, o1, hist, hs)),
+            'torch copy (ref)': (8, lambda: X().clone()),
+            'torch abs().max (ref)': (4, lambda: X().abs().max()),
         }
         for k, (bpe, fn) in cases.items():
             if args.only and not any(o in k for o in args.only.split(',')): continue
