@@ -48,18 +48,19 @@ def barrier(world):
     torch.cuda.synchronize()
 
 
-def build_workload(dev, bins, method):
+def build_workload(dev, bins, method, cache_params=False):
     from ppq_amd import harness
     graph = harness.resnet50_graph(seed=0)
     harness.quantize_graph(graph, method, hist_bins=bins)
     ex = harness.TorchExecutor(graph, dev)
+    ex.cache_parameter_quantization = bool(cache_params)
     harness.ParameterQuantizePass().optimize(graph)        # weights: per-channel min-max, left ACTIVATED
     return graph, ex
 
 
-def run_pass(graph, ex, batches, steps, method):
+def run_pass(graph, ex, batches, steps, method, async_observe=False, hip_graph=False):
     from ppq_amd.calibration import RuntimeCalibrationPass
-    p = RuntimeCalibrationPass(method=method, check_steps=False)
+    p = RuntimeCalibrationPass(method=method, check_steps=False, async_observe=async_observe, use_hip_graph=hip_graph)
     p.optimize(graph, dataloader=batches, executor=ex, calib_steps=steps)
     return p
 
@@ -97,6 +98,9 @@ def main():
     ap.add_argument('--bins', type=int, default=2048)
     ap.add_argument('--method', type=str, default='kl')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--hip-graph', type=int, default=0, help='capture each phase forward into a HIP graph')
+    ap.add_argument('--async-observe', type=int, default=0, help='observer kernels on a side HIP stream')
+    ap.add_argument('--cache-params', type=int, default=0, help='keep fake-quantised weights resident between forwards')
     ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
     args = ap.parse_args()
 
@@ -111,15 +115,16 @@ def main():
 
     # warm-up: W batches through a complete two-phase pass (MIOpen find, library load, allocator)
     if args.warmup > 0:
-        graph, ex = build_workload(dev, args.bins, args.method)
-        run_pass(graph, ex, batches[: max(1, min(args.warmup, args.steps))] , max(1, min(args.warmup, args.steps)), args.method)
+        graph, ex = build_workload(dev, args.bins, args.method, args.cache_params)
+        run_pass(graph, ex, batches[: max(1, min(args.warmup, args.steps))], max(1, min(args.warmup, args.steps)), args.method,
+                 bool(args.async_observe), False)
         del graph, ex
 
     # timed region
-    graph, ex = build_workload(dev, args.bins, args.method)
+    graph, ex = build_workload(dev, args.bins, args.method, args.cache_params)
     barrier(world)
     t0 = time.perf_counter()
-    p = run_pass(graph, ex, batches, args.steps, args.method)
+    p = run_pass(graph, ex, batches, args.steps, args.method, bool(args.async_observe), bool(args.hip_graph))
     barrier(world)
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -136,16 +141,16 @@ def main():
     roof = None
     prof_rows = []
     if rank == 0:
-        graph2, ex2 = build_workload(dev, args.bins, args.method)
+        graph2, ex2 = build_workload(dev, args.bins, args.method, args.cache_params)
         torch.cuda.synchronize()
         _lib.lib.ppqhip_prof_enable(1)
         if world == 1:
-            run_pass(graph2, ex2, batches, args.steps, args.method)
+            run_pass(graph2, ex2, batches, args.steps, args.method, False, False)   # eager, one stream -> clean event pairs
         else:   # collectives need every rank; profile the local (non-merged) statistics path only
             from ppq_amd.calibration import RuntimeCalibrationPass
             import torch.distributed as dist
             solo = dist.new_group([0]) if False else None
-            pp = RuntimeCalibrationPass(method=args.method, check_steps=False)
+            pp = RuntimeCalibrationPass(method=args.method, check_steps=False, async_observe=False, use_hip_graph=False)
             pp._render = lambda: __import__('ppq_amd.observer', fromlist=['render_observers']).render_observers(pp._all_tensor_observers())
             pp.optimize(graph2, dataloader=batches, executor=ex2, calib_steps=args.steps)
         torch.cuda.synchronize()
@@ -178,7 +183,9 @@ def main():
                                    f'RuntimeCalibrationPass {args.method} {args.bins} bins, per-tensor INT8 activations, '
                                    f'per-channel INT8 weights, {args.steps} batches x {args.batch} x 3x224x224 per GPU',
                        'samples': samples, 'batch': args.batch, 'observed_tensors': n_obs,
-                       'parallelism': f'dp{world} (batches sharded, 1 all-reduce per phase)'},
+                       'parallelism': f'dp{world} (batches sharded, 1 all-reduce per phase)',
+                       'async_observe': bool(args.async_observe), 'cache_params': bool(args.cache_params),
+                       'hip_graph': bool(args.hip_graph), 'graph_replays': p.graph_replays},
             'roofline': roof, 'cpu_baseline': cpu,
             'kernels': [{'name': r['name'], 'launches': r['launches'], 'total_ms': round(r['total_ms'], 3),
                          'GBps': round(r['total_bytes'] / max(r['total_ms'], 1e-9) / 1e6, 1)} for r in prof_rows],

@@ -94,14 +94,19 @@ int ppqhip_fq_float_c_bwd(const float* x, const float* scale, const float* offse
 /* histograms --------------------------------------------------------------------------------- */
 /* replaces Histogram_T, sort.cu:91-111 (CUDA.Histogram_T ffi.py:136-145).
  * b = floor(|x| / hist_scale); b > bins-1 is dropped (clip_outliers) or clamped; hist[b] += 1.
- * ACCUMULATES into the caller's int32 hist[num_bins]. */
+ * ACCUMULATES into the caller's int32 hist[num_bins].
+ * `workspace`: device scratch of ppqhip_hist_workspace_bytes(n, num_bins) bytes for the two-stage
+ * (atomic-free) flush, or NULL to let the library use its own per-stream arena (which allocates on
+ * first use and therefore cannot be used while the stream is being captured into a hipGraph). */
+int64_t ppqhip_hist_workspace_bytes(int64_t n, int64_t num_bins);
 int ppqhip_hist_sym_t(const float* x, int64_t n, float hist_scale, int clip_outliers,
-                      int32_t* hist, int64_t num_bins, void* stream);
+                      int32_t* hist, int64_t num_bins, void* workspace, void* stream);
 
 /* replaces Histogram_Asymmetric_T, sort.cu:141-165 (CUDA.Histogram_Asymmetric_T ffi.py:147-157).
  * hist_scale = (max - min) / bins; b = floor((x - min) / hist_scale). */
 int ppqhip_hist_asym_t(const float* x, int64_t n, float min_value, float max_value,
-                       int clip_outliers, int32_t* hist, int64_t num_bins, void* stream);
+                       int clip_outliers, int32_t* hist, int64_t num_bins, void* workspace,
+                       void* stream);
 
 /* replaces Histogram_C, sort.cu:187-218 (CUDA.Histogram_C ffi.py:159-169); hist is
  * [num_channel, num_bins]. */
@@ -124,12 +129,31 @@ int ppqhip_isotone_t(const float* x, int64_t n, float* dest, void* workspace, vo
 /* range reductions (what TorchMinMaxObserver.observe computes with torch.min/torch.max,
  * ppq/quantization/observer/range.py:86-98; no native twin in the reference) ---------------- */
 /* minmax[0] = min(minmax[0], min x), minmax[1] = max(minmax[1], max x): ACCUMULATES, so the
- * caller seeds minmax with {+inf, -inf}.  NaNs are ignored. */
-int ppqhip_minmax_t(const float* x, int64_t n, float* minmax, void* stream);
+ * caller seeds minmax with {+inf, -inf}.  NaNs are ignored.  `workspace`: device scratch of
+ * ppqhip_minmax_workspace_bytes(n) bytes, or NULL (library arena; see ppqhip_hist_sym_t). */
+int64_t ppqhip_minmax_workspace_bytes(int64_t n);
+int ppqhip_minmax_t(const float* x, int64_t n, float* minmax, void* workspace, void* stream);
 
 /* per channel: mins[c], maxs[c] ACCUMULATE (seed with +inf / -inf). */
 int ppqhip_minmax_c(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
                     float* mins, float* maxs, void* stream);
+
+/* persistent accumulators for repeated observation (MI355X-native; no twin in the reference) -----
+ * An observer that sees many batches keeps one accumulator ROW per workgroup resident in HBM:
+ *   rows  : int32 [ppqhip_hist_rows()][num_bins], zero-initialised by the caller
+ *   slots : float [ppqhip_minmax_slots()][2],     seeded with {+inf, -inf}
+ * Each launch adds into its own row / slot with plain stream-ordered read-modify-writes (no atomics,
+ * no per-launch reduction kernel); *_finish folds them into hist[num_bins] (+=) / minmax[2]
+ * (running min / max) once, when the statistic is needed.  Bin / range rules as above. */
+int64_t ppqhip_hist_rows(void);
+int ppqhip_hist_sym_t_rows(const float* x, int64_t n, float hist_scale, int clip_outliers,
+                           int32_t* rows, int64_t num_bins, void* stream);
+int ppqhip_hist_asym_t_rows(const float* x, int64_t n, float min_value, float max_value,
+                            int clip_outliers, int32_t* rows, int64_t num_bins, void* stream);
+int ppqhip_hist_rows_finish(const int32_t* rows, int64_t num_bins, int32_t* hist, void* stream);
+int64_t ppqhip_minmax_slots(void);
+int ppqhip_minmax_t_slots(const float* x, int64_t n, float* slots, void* stream);
+int ppqhip_minmax_slots_finish(const float* slots, float* minmax, void* stream);
 
 /* clipping searches -------------------------------------------------------------------------- */
 /* replaces compute_mse_loss, ppq/csrc/cpu/hist_mse.cc:3-28 (CUDA.compute_mse_loss ffi.py:263-270).
@@ -183,7 +207,7 @@ int ppqhip_rounding_loss_bwd(const float* x, const float* dy, const float* scale
 int ppqhip_fq_linear_t_hist_sym(const float* x, const float* scale, const float* offset,
                                 float* out, int64_t n, int clip_min, int clip_max, int rounding,
                                 float hist_scale, int clip_outliers, int32_t* hist,
-                                int64_t num_bins, void* stream);
+                                int64_t num_bins, void* workspace, void* stream);
 
 /* profiling aid used by bench.py: when enabled, every kernel launch made through this library
  * on this thread is bracketed by hipEvents on its own stream; ppqhip_prof_collect() synchronises

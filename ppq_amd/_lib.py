@@ -40,14 +40,23 @@ PROTOTYPES = {
                                   c_int, c_vp]),
     'ppqhip_fq_float_c_bwd': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_int,
                                       c_int, c_flt, c_flt, c_int, c_vp]),
-    'ppqhip_hist_sym_t': (c_int, [c_f32p, c_i64, c_flt, c_int, c_i32p, c_i64, c_vp]),
-    'ppqhip_hist_asym_t': (c_int, [c_f32p, c_i64, c_flt, c_flt, c_int, c_i32p, c_i64, c_vp]),
+    'ppqhip_hist_workspace_bytes': (c_i64, [c_i64, c_i64]),
+    'ppqhip_hist_sym_t': (c_int, [c_f32p, c_i64, c_flt, c_int, c_i32p, c_i64, c_vp, c_vp]),
+    'ppqhip_hist_asym_t': (c_int, [c_f32p, c_i64, c_flt, c_flt, c_int, c_i32p, c_i64, c_vp, c_vp]),
     'ppqhip_hist_sym_c': (c_int, [c_f32p, c_i64, c_i64, c_i64, c_flt, c_int, c_i32p, c_i64, c_vp]),
     'ppqhip_quantile_workspace_bytes': (c_i64, [c_i64]),
     'ppqhip_quantile_t': (c_int, [c_f32p, c_i64, c_flt, c_f32p, c_vp, c_vp]),
     'ppqhip_isotone_t': (c_int, [c_f32p, c_i64, c_f32p, c_vp, c_vp]),
-    'ppqhip_minmax_t': (c_int, [c_f32p, c_i64, c_f32p, c_vp]),
+    'ppqhip_minmax_workspace_bytes': (c_i64, [c_i64]),
+    'ppqhip_minmax_t': (c_int, [c_f32p, c_i64, c_f32p, c_vp, c_vp]),
     'ppqhip_minmax_c': (c_int, [c_f32p, c_i64, c_i64, c_i64, c_f32p, c_f32p, c_vp]),
+    'ppqhip_hist_rows': (c_i64, []),
+    'ppqhip_hist_sym_t_rows': (c_int, [c_f32p, c_i64, c_flt, c_int, c_i32p, c_i64, c_vp]),
+    'ppqhip_hist_asym_t_rows': (c_int, [c_f32p, c_i64, c_flt, c_flt, c_int, c_i32p, c_i64, c_vp]),
+    'ppqhip_hist_rows_finish': (c_int, [c_i32p, c_i64, c_i32p, c_vp]),
+    'ppqhip_minmax_slots': (c_i64, []),
+    'ppqhip_minmax_t_slots': (c_int, [c_f32p, c_i64, c_f32p, c_vp]),
+    'ppqhip_minmax_slots_finish': (c_int, [c_f32p, c_f32p, c_vp]),
     'ppqhip_mse_loss_host': (c_flt, [ctypes.POINTER(ctypes.c_int64), c_i64, c_int, c_int, c_int]),
     'ppqhip_mse_search_workspace_bytes': (c_i64, [c_i64]),
     'ppqhip_mse_search': (c_int, [c_i32p, c_i64, c_i64, c_f64p, c_f64p, c_int, c_int, c_int, c_i32p, c_vp, c_vp]),
@@ -59,7 +68,7 @@ PROTOTYPES = {
     'ppqhip_rounding_loss_bwd': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_int, c_int,
                                          c_int, c_vp]),
     'ppqhip_fq_linear_t_hist_sym': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int, c_flt, c_int,
-                                            c_i32p, c_i64, c_vp]),
+                                            c_i32p, c_i64, c_vp, c_vp]),
     'ppqhip_prof_enable': (c_int, [c_int]),
     'ppqhip_prof_collect': (c_int, [ctypes.POINTER(ProfEntry), c_int]),
 }

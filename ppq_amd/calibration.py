@@ -8,6 +8,8 @@ collate_fn, **kwargs)``, same two-phase structure, same assertions on ``calib_st
 MI355X-first differences (results unchanged):
 
 * observers accumulate into device buffers through the HIP kernels (ppq_amd/observer.py);
+* optionally (``async_observe``) the observer kernels run on a side HIP stream (they only read);
+* optionally (``use_hip_graph``) each phase's forward is captured once into a HIP graph and replayed;
 * both render steps go through :func:`ppq_amd.observer.render_observers`: one device->host copy
   for all running ranges, one batched KL / MSE search launch per group of histograms;
 * data-parallel calibration: with ``torch.distributed`` initialised (one process per GPU, RCCL over
@@ -40,7 +42,8 @@ class QuantizationOptimizationPass:
 
 class RuntimeCalibrationPass(QuantizationOptimizationPass):
     def __init__(self, method: str = None, override: bool = False, calib_steps: int = 32,
-                 process_group=None, check_steps: bool = True) -> None:
+                 process_group=None, check_steps: bool = True, async_observe: bool = False,
+                 use_hip_graph: bool = False) -> None:
         super().__init__(name='PPQ Runtime Calibration Pass')
         self._method = method
         self._observers: Dict[str, OperationObserver] = {}
@@ -49,24 +52,71 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         self._override = override
         self._process_group = process_group
         self._check_steps = check_steps
+        self._async_observe = async_observe
+        self._use_hip_graph = use_hip_graph
+        self.graph_replays = 0
+        self._side_stream = None
 
-    def calibrate(self, desc: str, dataloader: Iterable, executor, hooks: Dict[str, object],
-                  output_names: List[str] = None):
-        """calibration.py:105-121 (progress bar omitted)."""
-        calib_step = 0
+    def _batches(self, dataloader: Iterable) -> list:
+        """The sequence of batches the reference loop (calibration.py:108-121) would feed."""
+        out = []
         for calib_epoch in range(ceil(self._calib_steps / len(dataloader))):
             for data in dataloader:
                 if self._collate_fn is not None:
                     data = self._collate_fn(data)
+                out.append(data)
+                if len(out) >= self._calib_steps: return out
+        return out
+
+    def _graph_replayable(self, batches: list, hooks: Dict[str, object]) -> bool:
+        """A calibration forward can be captured into a HIP graph when it is a fixed kernel sequence:
+        same-shaped CUDA batches and observers whose whole state lives in device buffers."""
+        import torch
+        from .observer import ConstantObserver, TorchHistObserver, TorchMinMaxObserver, TorchMSEObserver
+        if not self._use_hip_graph or len(batches) < 3: return False
+        if not all(isinstance(b, torch.Tensor) and b.is_cuda and b.shape == batches[0].shape
+                   and b.dtype == batches[0].dtype for b in batches): return False
+        safe = (TorchMinMaxObserver, TorchHistObserver, TorchMSEObserver, ConstantObserver)
+        return all(type(ob) in safe for hook in hooks.values() for ob in hook._observer_table.values())
+
+    def calibrate(self, desc: str, dataloader: Iterable, executor, hooks: Dict[str, object],
+                  output_names: List[str] = None):
+        """calibration.py:105-121 (progress bar omitted).
+
+        Optional (``use_hip_graph``): when the batches have a fixed shape the forward (dense ops +
+        observer kernels, incl. the side-stream fork) is captured ONCE per phase into a HIP graph and
+        replayed for the remaining batches, which takes the Python / launch overhead off the critical
+        path.  Batch 0 runs eagerly (it allocates the observer buffers and lets MIOpen pick its
+        kernels), batch 1 is captured, batches 1.. replay.  Measured on MI355X (ResNet-50, batch 32) the
+        eager loop is already GPU-bound, and capture + instantiation of ~3500 nodes costs more than it
+        saves below ~100 steps, so this is off by default."""
+        import torch
+        batches = self._batches(dataloader)
+        if not self._graph_replayable(batches, hooks):
+            for data in batches:
                 executor.forward(inputs=data, hooks=hooks, output_names=output_names)
-                calib_step += 1
-                if calib_step >= self._calib_steps: break
+            return
+        executor.forward(inputs=batches[0], hooks=hooks, output_names=output_names)
+        static_in = torch.empty_like(batches[0])
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            executor.forward(inputs=static_in, hooks=hooks, output_names=output_names)
+            if self._side_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._side_stream)
+        for data in batches[1:]:
+            static_in.copy_(data, non_blocking=True)
+            graph.replay()
+            self.graph_replays += 1
 
     def _all_tensor_observers(self):
         return [ob for op_ob in self._observers.values() for ob in op_ob.observers()]
 
     def _render(self):
         observers = self._all_tensor_observers()
+        if self._side_stream is not None:          # join the observer stream before reading statistics
+            import torch
+            torch.cuda.current_stream().wait_stream(self._side_stream)
         merge_observers(observers, group=self._process_group)
         render_observers(observers)
 
@@ -96,12 +146,16 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         # build observer and hook for each quantable operation (calibration.py:157-172)
         self._observers = {}
         hooks = {}
+        import torch
+        if self._async_observe and torch.cuda.is_available():
+            self._side_stream = torch.cuda.Stream()
         for op_name, operation in graph.operations.items():
             if not hasattr(operation, 'config'): continue
             for config, var in operation.config_with_variable:
                 if not var.is_parameter and self._method is not None:
                     config.observer_algorithm = self._method
             observer = OperationObserver(operation=executor._graph.operations[op_name], monitor_parameter=False)
+            observer.hook.stream = self._side_stream
             self._observers[op_name] = observer
             hooks[op_name] = observer.hook
 

@@ -30,7 +30,8 @@ namespace ppqhip {
 
 constexpr int kMaxLdsBins = 16384;     // 64 KiB of int32 per copy at most
 constexpr int kLdsBudgetInts = 8192;   // target: copies * bins <= 8192 ints (32 KiB) per workgroup
-constexpr int kHistU = 4;              // float4 loads in flight per lane
+constexpr int kHistUBig = 4;           // float4 loads in flight per lane (large tensors)
+constexpr int kHistUSmall = 1;         // small tensors: less code to fetch, more workgroups
 constexpr int kHistMaxBlock = 1024;    // histogram workgroups: 256 .. 1024 threads (runtime)
 constexpr int kTrash = 64;             // per-lane trash slots behind every histogram copy
 constexpr int kHotMin = 12;            // lanes that must share the candidate bin to make it hot
@@ -165,15 +166,18 @@ __device__ __forceinline__ void lds_hist_zero(int* lds, int total) {
 
 // partial == nullptr: merge the copies and flush the non-zero bins with global atomics (few
 // workgroups).  Otherwise store this workgroup's merged histogram to partial[blockIdx.x][bins].
+// accumulate == true: partial is a persistent [workgroups][bins] accumulator owned by the caller
+// (one row per workgroup, so a plain read-modify-write is race free and stream ordered): nothing is
+// reduced per launch, ppqhip_hist_rows_finish sums the rows once, when the histogram is needed.
 __device__ __forceinline__ void lds_hist_flush(const int* lds, int bins, int copies, int* __restrict__ hist,
-                                               int* __restrict__ partial = nullptr) {
+                                               int* __restrict__ partial = nullptr, bool accumulate = false) {
     __syncthreads();
     const int pitch = bins + kTrash;
     int* dst = partial ? partial + (size_t)blockIdx.x * bins : nullptr;
     for (int b = threadIdx.x; b < bins; b += blockDim.x) {
         int s = 0;
         for (int c = 0; c < copies; c++) s += lds[c * pitch + b];
-        if (dst) dst[b] = s;
+        if (dst) { if (accumulate) { if (s) dst[b] += s; } else dst[b] = s; }
         else if (s) atomicAdd(&hist[b], s);
     }
 }
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(kBlock) void hist_reduce_kernel(const int* __restri
 }
 
 // Shared streaming loop.  FQ = true additionally writes out = fake_quant(x) (fused calibration step).
-template <bool ASYM, bool CLIP, bool HOT, bool FQ, int R, bool NT>
+template <bool ASYM, bool CLIP, bool HOT, bool FQ, int R, bool NT, int kHistU>
 __device__ __forceinline__ void hist_stream(const float* __restrict__ x, uint32_t n, int vec_ok, const BinRule& rule,
                                             int copies, int* lds, float* __restrict__ out, float s, int o, int qmin,
                                             int qmax, int rounding) {
@@ -263,13 +267,13 @@ __device__ __forceinline__ void hist_stream(const float* __restrict__ x, uint32_
     acc.flush_hot();
 }
 
-template <bool ASYM, bool CLIP, bool HOT, bool NT>
+template <bool ASYM, bool CLIP, bool HOT, bool NT, int U>
 __global__ __launch_bounds__(kHistMaxBlock) void hist_t_lds_kernel(const float* __restrict__ x, uint32_t n, int vec_ok,
                                                                    BinRule rule, int copies, int* __restrict__ hist,
-                                                                   int* __restrict__ partial) {
+                                                                   int* __restrict__ partial, int accumulate) {
     extern __shared__ int lds[];
-    hist_stream<ASYM, CLIP, HOT, false, 0, NT>(x, n, vec_ok, rule, copies, lds, nullptr, 0.f, 0, 0, 0, 0);
-    lds_hist_flush(lds, rule.bins, copies, hist, partial);
+    hist_stream<ASYM, CLIP, HOT, false, 0, NT, U>(x, n, vec_ok, rule, copies, lds, nullptr, 0.f, 0, 0, 0, 0);
+    lds_hist_flush(lds, rule.bins, copies, hist, partial, accumulate != 0);
 }
 
 // fused: out = fake_quant(x) (== fq_linear_t) and hist += histogram(x) (== hist_sym_t), one read
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(kHistMaxBlock) void fq_linear_t_hist_kernel(
     extern __shared__ int lds[];
     const float s = scale[0];
     const int o = round_offset(offset[0]);
-    hist_stream<false, CLIP, HOT, true, R, false>(x, n, vec_ok, rule, copies, lds, out, s, o, qmin, qmax, rounding);
+    hist_stream<false, CLIP, HOT, true, R, false, kHistUBig>(x, n, vec_ok, rule, copies, lds, out, s, o, qmin, qmax, rounding);
     lds_hist_flush(lds, rule.bins, copies, hist, partial);
 }
 
@@ -366,18 +370,19 @@ static int pick_copies(int bins, int block) {
 
 static size_t lds_bytes(int bins, int copies) { return sizeof(int) * (size_t)copies * (bins + kTrash); }
 
-static int hist_grid(int64_t n) {
-    // one trip (kHistU float4 per lane) per workgroup at least; bounded workgroup count: every
+static int hist_grid(int64_t n, int u) {
+    // one trip (u float4 per lane) per workgroup at least; bounded workgroup count: every
     // workgroup pays LDS zeroing + a flush of `bins` counters
-    return stream_grid(n, (int64_t)hist_block() * 4 * kHistU, kNumCU * hist_blocks_per_cu());
+    return stream_grid(n, (int64_t)hist_block() * 4 * u, kNumCU * hist_blocks_per_cu());
 }
 
 constexpr int kAtomicFlushMaxBlocks = 8;
 
 // scratch for the two-stage flush, or nullptr when the launch is small enough for atomics
-static int* partial_for(int grid, int bins, hipStream_t s, bool* failed) {
+static int* partial_for(int grid, int bins, hipStream_t s, bool* failed, void* workspace) {
     *failed = false;
     if (grid <= kAtomicFlushMaxBlocks) return nullptr;
+    if (workspace) return (int*)workspace;
     int* p = (int*)scratch(s, sizeof(int) * (size_t)grid * bins);
     if (p == nullptr) *failed = true;
     return p;
@@ -388,7 +393,8 @@ static void launch_reduce(const int* partial, int grid, int bins, int32_t* hist,
                        partial, grid, bins, hist);
 }
 
-static int launch_hist_t(const float* x, int64_t n, BinRule rule, int32_t* hist, hipStream_t s) {
+static int launch_hist_t(const float* x, int64_t n, BinRule rule, int32_t* hist, void* workspace, hipStream_t s,
+                         int32_t* rows = nullptr) {
     if (rule.bins > kMaxLdsBins) {
         hipLaunchKernelGGL(hist_t_global_kernel, dim3(stream_grid(n, kBlock * 4)), dim3(kBlock), 0, s, x, (uint32_t)n,
                            rule, hist);
@@ -398,16 +404,21 @@ static int launch_hist_t(const float* x, int64_t n, BinRule rule, int32_t* hist,
     const int copies = pick_copies(rule.bins, block);
     const size_t lds = lds_bytes(rule.bins, copies);
     const int vec_ok = aligned16(x) ? 1 : 0;
-    const int grid = hist_grid(n);
-    bool failed;
-    int* partial = partial_for(grid, rule.bins, s, &failed);
+    static const int small_elems = env_int("PPQHIP_HIST_SMALL_ELEMS", 16 << 20);
+    const bool small = n < small_elems;
+    const int grid = hist_grid(n, small ? kHistUSmall : kHistUBig);
+    bool failed = false;
+    const int accumulate = rows != nullptr;
+    int* partial = rows ? rows : partial_for(grid, rule.bins, s, &failed, workspace);
     if (failed) return PPQHIP_ERR_HIP;
 #define PPQ_LAUNCH_HIST(A, C, H)                                                                                  \
     do {                                                                                                          \
-        if (nt) hipLaunchKernelGGL((hist_t_lds_kernel<A, C, H, true>), dim3(grid), dim3(block), lds, s, x,       \
-                                   (uint32_t)n, vec_ok, rule, copies, hist, partial);                            \
-        else hipLaunchKernelGGL((hist_t_lds_kernel<A, C, H, false>), dim3(grid), dim3(block), lds, s, x,         \
-                                (uint32_t)n, vec_ok, rule, copies, hist, partial);                               \
+        if (small) hipLaunchKernelGGL((hist_t_lds_kernel<A, C, H, false, kHistUSmall>), dim3(grid), dim3(block), \
+                                      lds, s, x, (uint32_t)n, vec_ok, rule, copies, hist, partial, accumulate);  \
+        else if (nt) hipLaunchKernelGGL((hist_t_lds_kernel<A, C, H, true, kHistUBig>), dim3(grid), dim3(block),  \
+                                        lds, s, x, (uint32_t)n, vec_ok, rule, copies, hist, partial, accumulate);\
+        else hipLaunchKernelGGL((hist_t_lds_kernel<A, C, H, false, kHistUBig>), dim3(grid), dim3(block), lds, s, \
+                                x, (uint32_t)n, vec_ok, rule, copies, hist, partial, accumulate);                \
     } while (0)
     static const int nt_env = env_int("PPQHIP_HIST_NT", -1);
     const bool nt = nt_env >= 0 ? nt_env != 0 : n >= (48ll << 20);    // streaming loads beyond cache residency
@@ -423,7 +434,7 @@ static int launch_hist_t(const float* x, int64_t n, BinRule rule, int32_t* hist,
         default: PPQ_LAUNCH_HIST(true, true, true); break;
     }
 #undef PPQ_LAUNCH_HIST
-    if (partial) launch_reduce(partial, grid, rule.bins, hist, s);
+    if (partial && !accumulate) launch_reduce(partial, grid, rule.bins, hist, s);
     return PPQHIP_OK;
 }
 
@@ -433,26 +444,65 @@ using namespace ppqhip;
 
 extern "C" {
 
+int64_t ppqhip_hist_workspace_bytes(int64_t n, int64_t num_bins) {
+    (void)n;
+    if (num_bins <= 0 || num_bins > kMaxLdsBins) return 0;
+    return (int64_t)sizeof(int) * kNumCU * hist_blocks_per_cu() * num_bins;
+}
+
 int ppqhip_hist_sym_t(const float* x, int64_t n, float hist_scale, int clip_outliers, int32_t* hist,
-                      int64_t num_bins, void* stream) {
+                      int64_t num_bins, void* workspace, void* stream) {
     if (int st = validate(n, num_bins, "hist_sym_t")) return st;
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_HIST_SYM_T, 4.0 * (double)n, s);
     BinRule rule = make_rule(0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, 0);
-    if (int st = launch_hist_t(x, n, rule, hist, s)) return st;
+    if (int st = launch_hist_t(x, n, rule, hist, workspace, s)) return st;
     return finish_launch("hist_sym_t");
 }
 
 int ppqhip_hist_asym_t(const float* x, int64_t n, float min_value, float max_value, int clip_outliers,
-                       int32_t* hist, int64_t num_bins, void* stream) {
+                       int32_t* hist, int64_t num_bins, void* workspace, void* stream) {
     if (int st = validate(n, num_bins, "hist_asym_t")) return st;
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_HIST_ASYM_T, 4.0 * (double)n, s);
     // float hist_scale = (max - min) / num_of_bins: sort.cu:123 (float / int64 -> float)
     const float hs = (max_value - min_value) / (float)num_bins;
     BinRule rule = make_rule(min_value, hs, (int)num_bins, clip_outliers ? 1 : 0, 1);
-    if (int st = launch_hist_t(x, n, rule, hist, s)) return st;
+    if (int st = launch_hist_t(x, n, rule, hist, workspace, s)) return st;
     return finish_launch("hist_asym_t");
+}
+
+/* ---- persistent-row variants (MI355X-native: the observer keeps [rows][bins] resident) ---- */
+int64_t ppqhip_hist_rows(void) { return (int64_t)kNumCU * hist_blocks_per_cu(); }
+
+int ppqhip_hist_sym_t_rows(const float* x, int64_t n, float hist_scale, int clip_outliers, int32_t* rows,
+                           int64_t num_bins, void* stream) {
+    if (int st = validate(n, num_bins, "hist_sym_t_rows")) return st;
+    if (num_bins > kMaxLdsBins) { set_error("hist_sym_t_rows: at most %d bins", kMaxLdsBins); return PPQHIP_ERR_UNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_HIST_SYM_T, 4.0 * (double)n, s);
+    BinRule rule = make_rule(0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, 0);
+    if (int st = launch_hist_t(x, n, rule, nullptr, nullptr, s, rows)) return st;
+    return finish_launch("hist_sym_t_rows");
+}
+
+int ppqhip_hist_asym_t_rows(const float* x, int64_t n, float min_value, float max_value, int clip_outliers,
+                            int32_t* rows, int64_t num_bins, void* stream) {
+    if (int st = validate(n, num_bins, "hist_asym_t_rows")) return st;
+    if (num_bins > kMaxLdsBins) { set_error("hist_asym_t_rows: at most %d bins", kMaxLdsBins); return PPQHIP_ERR_UNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_HIST_ASYM_T, 4.0 * (double)n, s);
+    const float hs = (max_value - min_value) / (float)num_bins;
+    BinRule rule = make_rule(min_value, hs, (int)num_bins, clip_outliers ? 1 : 0, 1);
+    if (int st = launch_hist_t(x, n, rule, nullptr, nullptr, s, rows)) return st;
+    return finish_launch("hist_asym_t_rows");
+}
+
+int ppqhip_hist_rows_finish(const int32_t* rows, int64_t num_bins, int32_t* hist, void* stream) {
+    if (num_bins <= 0 || num_bins > kMaxLdsBins) { set_error("hist_rows_finish: bad bins"); return PPQHIP_ERR_INVALID_VALUE; }
+    hipStream_t s = (hipStream_t)stream;
+    launch_reduce((const int*)rows, (int)ppqhip_hist_rows(), (int)num_bins, hist, s);
+    return finish_launch("hist_rows_finish");
 }
 
 int ppqhip_hist_sym_c(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
@@ -487,7 +537,7 @@ int ppqhip_hist_sym_c(const float* x, int64_t n, int64_t num_channel, int64_t el
 
 int ppqhip_fq_linear_t_hist_sym(const float* x, const float* scale, const float* offset, float* out, int64_t n,
                                 int clip_min, int clip_max, int rounding, float hist_scale, int clip_outliers,
-                                int32_t* hist, int64_t num_bins, void* stream) {
+                                int32_t* hist, int64_t num_bins, void* workspace, void* stream) {
     if (int st = validate(n, num_bins, "fq_linear_t_hist_sym")) return st;
     if (num_bins > kMaxLdsBins) {
         set_error("fq_linear_t_hist_sym: at most %d bins", kMaxLdsBins); return PPQHIP_ERR_UNSUPPORTED;
@@ -499,9 +549,9 @@ int ppqhip_fq_linear_t_hist_sym(const float* x, const float* scale, const float*
     const int copies = pick_copies(rule.bins, block);
     const size_t lds = lds_bytes(rule.bins, copies);
     const int vec_ok = (aligned16(x) && aligned16(out)) ? 1 : 0;
-    const int grid = hist_grid(n);
+    const int grid = hist_grid(n, kHistUBig);
     bool failed;
-    int* partial = partial_for(grid, rule.bins, s, &failed);
+    int* partial = partial_for(grid, rule.bins, s, &failed, workspace);
     if (failed) return PPQHIP_ERR_HIP;
 #define PPQ_LAUNCH_FUSED(R, C, H)                                                                                   \
     hipLaunchKernelGGL((fq_linear_t_hist_kernel<R, C, H>), dim3(grid), dim3(block), lds, s, x, scale, offset, out,  \

@@ -38,7 +38,8 @@ __device__ __forceinline__ void block_minmax_commit(float mn, float mx, float* g
 // same-address device atomics serialise at ~12 ns each, which would dominate a 2048-workgroup launch.
 template <int U, bool NT>
 __global__ __launch_bounds__(kBlock) void minmax_t_kernel(const float* __restrict__ x, uint32_t n, int vec_ok,
-                                                          float* __restrict__ minmax, float* __restrict__ partial) {
+                                                          float* __restrict__ minmax, float* __restrict__ partial,
+                                                          int accumulate) {
     __shared__ float lds[16];
     float mn = INFINITY, mx = -INFINITY;
     stream_elems<U, NT>(x, n, vec_ok != 0, [&](float a) { mn = fminf(mn, a); mx = fmaxf(mx, a); });
@@ -50,6 +51,10 @@ __global__ __launch_bounds__(kBlock) void minmax_t_kernel(const float* __restric
     __syncthreads();
     if (threadIdx.x == 0) {
         for (int w = 1; w < kBlock / kWave; w++) { mn = fminf(mn, lds[w]); mx = fmaxf(mx, lds[8 + w]); }
+        if (accumulate) {   // persistent per-workgroup slot: race-free, stream-ordered read-modify-write
+            mn = fminf(mn, partial[2 * blockIdx.x]);
+            mx = fmaxf(mx, partial[2 * blockIdx.x + 1]);
+        }
         partial[2 * blockIdx.x] = mn;
         partial[2 * blockIdx.x + 1] = mx;
     }
@@ -342,7 +347,9 @@ using namespace ppqhip;
 
 extern "C" {
 
-int ppqhip_minmax_t(const float* x, int64_t n, float* minmax, void* stream) {
+int64_t ppqhip_minmax_workspace_bytes(int64_t n) { (void)n; return (int64_t)sizeof(float) * 2 * kNumCU * 8; }
+
+static int minmax_t_impl(const float* x, int64_t n, float* minmax, void* workspace, float* slots, void* stream) {
     if (int st = validate(n, "minmax_t")) return st;
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_MINMAX_T, 4.0 * (double)n, s);
@@ -350,21 +357,40 @@ int ppqhip_minmax_t(const float* x, int64_t n, float* minmax, void* stream) {
     // tensor cannot be cache resident (sweep on MI355X, 205 MB: 5.7 TB/s vs 5.1 with plain loads)
     const bool nt = n >= (48ll << 20);
     const int grid = stream_grid(n, kBlock * 4 * 4, kNumCU * 8);
-    float* partial = nullptr;
-    if (grid > 32) {
-        partial = (float*)scratch(s, sizeof(float) * 2 * (size_t)grid);
+    float* partial = slots;
+    const int accumulate = slots != nullptr;
+    if (!slots && grid > 32) {
+        partial = workspace ? (float*)workspace : (float*)scratch(s, sizeof(float) * 2 * (size_t)grid);
         if (partial == nullptr) return PPQHIP_ERR_HIP;
     }
     if (nt)
         hipLaunchKernelGGL((minmax_t_kernel<4, true>), dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n,
-                           aligned16(x) ? 1 : 0, minmax, partial);
+                           aligned16(x) ? 1 : 0, minmax, partial, accumulate);
     else
         hipLaunchKernelGGL((minmax_t_kernel<4, false>), dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n,
-                           aligned16(x) ? 1 : 0, minmax, partial);
-    if (partial)
+                           aligned16(x) ? 1 : 0, minmax, partial, accumulate);
+    if (partial && !accumulate)
         hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(kBlock), 0, s, (const float*)partial, (uint32_t)grid,
                            minmax);
     return finish_launch("minmax_t");
+}
+
+int ppqhip_minmax_t(const float* x, int64_t n, float* minmax, void* workspace, void* stream) {
+    return minmax_t_impl(x, n, minmax, workspace, nullptr, stream);
+}
+
+/* persistent-slot variant: slots is float[ppqhip_minmax_slots()][2], seeded with {+inf, -inf} */
+int64_t ppqhip_minmax_slots(void) { return (int64_t)kNumCU * 8; }
+
+int ppqhip_minmax_t_slots(const float* x, int64_t n, float* slots, void* stream) {
+    if (slots == nullptr) { set_error("minmax_t_slots: slots is null"); return PPQHIP_ERR_INVALID_VALUE; }
+    return minmax_t_impl(x, n, nullptr, nullptr, slots, stream);
+}
+
+int ppqhip_minmax_slots_finish(const float* slots, float* minmax, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(minmax_finish_kernel, dim3(1), dim3(kBlock), 0, s, slots, (uint32_t)ppqhip_minmax_slots(), minmax);
+    return finish_launch("minmax_slots_finish");
 }
 
 int ppqhip_minmax_c(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel, float* mins,

@@ -85,8 +85,10 @@ _workspaces = {}
 
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
-    """Small per-device scratch buffer (quantile / isotone / mse search), grown on demand.  Launches
-    that use it are ordered on the current stream, like the reference's temporaries."""
+    """Per-(device, stream) scratch buffer for the kernels' two-stage reductions, grown on demand and
+    allocated by torch's caching allocator -- so it is also valid while the current stream is being
+    captured into a HIP graph (it then comes from the graph's private pool and lives as long as this
+    cache holds it).  Launches that use it are ordered on the current stream."""
     key = (device.index, _stream())
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
@@ -216,16 +218,19 @@ class _HipExtension:
         _f32(value, 'Value'); _HipExtension._check_hist(hist)
         v = value.contiguous()
         with _DeviceOf(v):
+            ws = _workspace(v.device, lib.ppqhip_hist_workspace_bytes(v.numel(), hist.numel()))
             _raise(lib.ppqhip_hist_sym_t(v.data_ptr(), v.numel(), float(hist_scale), int(bool(clip_outliers)),
-                                         hist.data_ptr(), hist.numel(), _stream()))
+                                         hist.data_ptr(), hist.numel(), ws.data_ptr(), _stream()))
 
     @ staticmethod
     def Histogram_Asymmetric_T(min: float, max: float, value, clip_outliers: bool, hist) -> None:
         _f32(value, 'Value'); _HipExtension._check_hist(hist)
         v = value.contiguous()
         with _DeviceOf(v):
+            ws = _workspace(v.device, lib.ppqhip_hist_workspace_bytes(v.numel(), hist.numel()))
             _raise(lib.ppqhip_hist_asym_t(v.data_ptr(), v.numel(), float(min), float(max),
-                                          int(bool(clip_outliers)), hist.data_ptr(), hist.numel(), _stream()))
+                                          int(bool(clip_outliers)), hist.data_ptr(), hist.numel(), ws.data_ptr(),
+                                          _stream()))
 
     @ staticmethod
     def Histogram_C(value, channel_axis: int, hist_scale: float, clip_outliers: bool, hist) -> None:
@@ -341,7 +346,54 @@ class _HipExtension:
         _f32(value, 'Value'); _f32(minmax, 'MinMax')
         v = value.contiguous()
         with _DeviceOf(v):
-            _raise(lib.ppqhip_minmax_t(v.data_ptr(), v.numel(), minmax.data_ptr(), _stream()))
+            ws = _workspace(v.device, lib.ppqhip_minmax_workspace_bytes(v.numel()))
+            _raise(lib.ppqhip_minmax_t(v.data_ptr(), v.numel(), minmax.data_ptr(), ws.data_ptr(), _stream()))
+
+    @ staticmethod
+    def MinMax_T_Slots(value, slots) -> None:
+        """slots: float32 [minmax_slots(), 2] seeded with (+inf, -inf); one slot per workgroup, no
+        per-launch reduction.  Fold with MinMax_Slots_Finish when the range is needed."""
+        _f32(value, 'Value'); _f32(slots, 'Slots')
+        if slots.numel() != 2 * lib.ppqhip_minmax_slots() or not slots.is_contiguous():
+            raise RuntimeError(_KERNEL_FAILURE + f'slots must be a contiguous [{lib.ppqhip_minmax_slots()}, 2] tensor')
+        v = value.contiguous()
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_minmax_t_slots(v.data_ptr(), v.numel(), slots.data_ptr(), _stream()))
+
+    @ staticmethod
+    def MinMax_Slots_Finish(slots, minmax) -> None:
+        _f32(slots, 'Slots'); _f32(minmax, 'MinMax')
+        with _DeviceOf(slots):
+            _raise(lib.ppqhip_minmax_slots_finish(slots.data_ptr(), minmax.data_ptr(), _stream()))
+
+    @ staticmethod
+    def Histogram_T_Rows(value, hist_scale: float, clip_outliers: bool, rows) -> None:
+        """rows: int32 [hist_rows(), bins], zero-initialised; see include/ppq_hip.h."""
+        _f32(value, 'Value'); _check(rows, torch.int32, 'Rows(Expect to be INT32)')
+        R = lib.ppqhip_hist_rows()
+        if rows.ndim != 2 or rows.shape[0] != R or not rows.is_contiguous():
+            raise RuntimeError(_KERNEL_FAILURE + f'rows must be a contiguous [{R}, bins] tensor')
+        v = value.contiguous()
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_hist_sym_t_rows(v.data_ptr(), v.numel(), float(hist_scale), int(bool(clip_outliers)),
+                                              rows.data_ptr(), rows.shape[1], _stream()))
+
+    @ staticmethod
+    def Histogram_Asymmetric_T_Rows(min: float, max: float, value, clip_outliers: bool, rows) -> None:
+        _f32(value, 'Value'); _check(rows, torch.int32, 'Rows(Expect to be INT32)')
+        R = lib.ppqhip_hist_rows()
+        if rows.ndim != 2 or rows.shape[0] != R or not rows.is_contiguous():
+            raise RuntimeError(_KERNEL_FAILURE + f'rows must be a contiguous [{R}, bins] tensor')
+        v = value.contiguous()
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_hist_asym_t_rows(v.data_ptr(), v.numel(), float(min), float(max),
+                                               int(bool(clip_outliers)), rows.data_ptr(), rows.shape[1], _stream()))
+
+    @ staticmethod
+    def Histogram_Rows_Finish(rows, hist) -> None:
+        _check(rows, torch.int32, 'Rows(Expect to be INT32)'); _HipExtension._check_hist(hist)
+        with _DeviceOf(rows):
+            _raise(lib.ppqhip_hist_rows_finish(rows.data_ptr(), rows.shape[1], hist.data_ptr(), _stream()))
 
     @ staticmethod
     def MinMax_C(value, channel_axis: int, mins, maxs) -> None:
@@ -391,10 +443,11 @@ class _HipExtension:
         v = value.contiguous()
         out = torch.empty_like(v)
         with _DeviceOf(v):
+            ws = _workspace(v.device, lib.ppqhip_hist_workspace_bytes(v.numel(), hist.numel()))
             _raise(lib.ppqhip_fq_linear_t_hist_sym(v.data_ptr(), scale.data_ptr(), offset.data_ptr(), out.data_ptr(),
                                                    v.numel(), int(clip_min), int(clip_max), int(rounding),
                                                    float(hist_scale), int(bool(clip_outliers)), hist.data_ptr(),
-                                                   hist.numel(), _stream()))
+                                                   hist.numel(), ws.data_ptr(), _stream()))
         return out
 
 
@@ -535,6 +588,38 @@ class CUDA:
     def MinMax_C(tensor, channel_axis: int, mins, maxs):
         HIP_EXTENSION.MinMax_C(tensor, channel_axis, mins, maxs)
         return mins, maxs
+
+    # persistent accumulators (one row / slot per workgroup, folded on demand) ---------------------
+    @ staticmethod
+    def minmax_slots() -> int: return int(lib.ppqhip_minmax_slots())
+
+    @ staticmethod
+    def hist_rows() -> int: return int(lib.ppqhip_hist_rows())
+
+    @ staticmethod
+    def MinMax_T_Slots(tensor, slots):
+        HIP_EXTENSION.MinMax_T_Slots(tensor, slots)
+        return slots
+
+    @ staticmethod
+    def MinMax_Slots_Finish(slots, minmax):
+        HIP_EXTENSION.MinMax_Slots_Finish(slots, minmax)
+        return minmax
+
+    @ staticmethod
+    def Histogram_T_Rows(tensor, rows, scale: float, clip_outliers: bool = True):
+        HIP_EXTENSION.Histogram_T_Rows(tensor, scale, clip_outliers, rows)
+        return rows
+
+    @ staticmethod
+    def Histogram_Asymmetric_T_Rows(min_value: float, max_value: float, tensor, rows, clip_outliers: bool = True):
+        HIP_EXTENSION.Histogram_Asymmetric_T_Rows(min_value, max_value, tensor, clip_outliers, rows)
+        return rows
+
+    @ staticmethod
+    def Histogram_Rows_Finish(rows, histogram):
+        HIP_EXTENSION.Histogram_Rows_Finish(rows, histogram)
+        return histogram
 
     @ staticmethod
     def KLLosses(histogram, num_of_bits: int = 8):

@@ -138,11 +138,28 @@ class TorchExecutor:
         self._graph = graph
         self._device = device
         self._default_quant_fn = PPQuantFunction
+        self.cache_parameter_quantization = False     # opt-in: see _quantize_parameter
+        self._param_cache: Dict[str, tuple] = {}
         for v in graph.variables.values():
             if v.is_parameter and v.value is not None: v.value = v.value.to(device)
 
     def quantize_function(self, tensor: torch.Tensor, config=None) -> torch.Tensor:
         return self._default_quant_fn(tensor, config)
+
+    def _quantize_parameter(self, var: Variable, config) -> torch.Tensor:
+        """A parameter and its scale do not change between calibration forwards, so its fake-quantised
+        value is computed once and kept resident (the reference recomputes it every forward until
+        ParameterBakingPass; same values, ppq/executor/torch.py:516-518).  The cache entry is keyed on
+        the identity + version of value, scale and offset and on the config state."""
+        if not self.cache_parameter_quantization or not QuantizationStates.is_activated(config.state):
+            return self.quantize_function(var.value, config)
+        key = (var.value.data_ptr(), var.value._version, id(config.scale), config.scale._version,
+               id(config.offset), config.offset._version, int(getattr(config.state, 'value', config.state)))
+        hit = self._param_cache.get(var.name)
+        if hit is not None and hit[0] == key: return hit[1]
+        q = self.quantize_function(var.value, config)
+        self._param_cache[var.name] = (key, q)
+        return q
 
     @ torch.no_grad()
     def forward(self, inputs, output_names: List[str] = None, hooks: Dict[str, object] = None) -> List[torch.Tensor]:
@@ -160,7 +177,8 @@ class TorchExecutor:
             quantable = isinstance(op, QuantableOperation)
             if quantable:
                 in_cfgs = list(op.config.input_quantization_config)
-                qin = [self.quantize_function(x, c) for x, c in zip(raw_in, in_cfgs)]
+                qin = [self._quantize_parameter(v, c) if v.is_parameter else self.quantize_function(x, c)
+                       for v, x, c in zip(op.inputs, raw_in, in_cfgs)]
             if hook is not None:
                 qin = hook.pre_forward_hook(inputs=raw_in, quant_inputs=qin, quant_configs=in_cfgs)
             outs = _forward(op, qin)

@@ -111,6 +111,8 @@ class TorchMinMaxObserver(BaseTensorObserver):
     def __init__(self, watch_on, quant_cfg):
         super().__init__(watch_on, quant_cfg)
         self._range: Optional[torch.Tensor] = None      # [2] = (min, max)   or   [2, C]
+        self._slots: Optional[torch.Tensor] = None      # per-tensor: [minmax_slots, 2], one slot per workgroup
+        self._slots_dirty = False
         self._host_range: Optional[np.ndarray] = None
         self._observed = False
 
@@ -123,7 +125,9 @@ class TorchMinMaxObserver(BaseTensorObserver):
         if cfg.policy.has_property(P.PER_TENSOR):
             if self._range is None:
                 self._range = torch.tensor([float('inf'), float('-inf')], dtype=torch.float32, device=value.device)
-            CUDA.MinMax_T(value, self._range)
+                self._slots = self._range.repeat(CUDA.minmax_slots(), 1).contiguous()
+            CUDA.MinMax_T_Slots(value, self._slots)          # no per-batch reduction kernel
+            self._slots_dirty = True
         elif cfg.policy.has_property(P.PER_CHANNEL):
             if self._range is None:
                 C = value.shape[cfg.channel_axis]
@@ -135,14 +139,23 @@ class TorchMinMaxObserver(BaseTensorObserver):
         self._observed = True
         self._host_range = None
 
+    def _fold(self) -> None:
+        """Fold the per-workgroup slots into the running [min, max] (one tiny launch, at render)."""
+        if self._slots_dirty:
+            CUDA.MinMax_Slots_Finish(self._slots, self._range)
+            self._slots_dirty = False
+
     def pending_range(self):
-        return self._range if (is_initial(self._quant_cfg) and self._observed) else None
+        if not (is_initial(self._quant_cfg) and self._observed): return None
+        self._fold()
+        return self._range
 
     def take_range(self, host: np.ndarray) -> None:
         self._host_range = host
 
     def reducible(self):
         if self._range is None: return []
+        self._fold()
         if self._range.ndim == 1: return [(self._range[0:1], 'min'), (self._range[1:2], 'max')]
         return [(self._range[0], 'min'), (self._range[1], 'max')]
 
@@ -151,6 +164,7 @@ class TorchMinMaxObserver(BaseTensorObserver):
             raise ValueError('Can not render quantization config yet, Observer data collator is empty. '
                              'Invoke observe() function before render config.')
         if self._host_range is None:
+            self._fold()
             self._host_range = self._range.cpu().numpy()
         return self._host_range
 
@@ -179,6 +193,8 @@ class TorchHistObserver(TorchMinMaxObserver):
     def __init__(self, watch_on, quant_cfg, hist_bins: int = OBSERVER_KL_HIST_BINS):
         self._phase = 'Detecting Minmax'
         self._hist = None
+        self._rows = None            # [hist_rows, bins]: one accumulator row per workgroup, folded at render
+        self._rows_dirty = False
         self._hist_scale = None
         self._min = None
         self._max = None
@@ -196,19 +212,41 @@ class TorchHistObserver(TorchMinMaxObserver):
         elif self._phase == 'Collating Hist':
             if self._hist is None:
                 self._hist = torch.zeros(size=(self._hist_bins,), dtype=torch.int32, device=value.device)
+                if self._hist_bins <= 16384:
+                    self._rows = torch.zeros(size=(CUDA.hist_rows(), self._hist_bins), dtype=torch.int32,
+                                             device=value.device)
             if self._quant_cfg.policy.has_property(P.ASYMMETRICAL):
-                CUDA.Histogram_Asymmetric_T(self._min, self._max, tensor=value, histogram=self._hist)
+                if self._rows is not None:
+                    CUDA.Histogram_Asymmetric_T_Rows(self._min, self._max, tensor=value, rows=self._rows)
+                    self._rows_dirty = True
+                else:
+                    CUDA.Histogram_Asymmetric_T(self._min, self._max, tensor=value, histogram=self._hist)
             elif self._quant_cfg.policy.has_property(P.SYMMETRICAL):
-                CUDA.Histogram_T(tensor=value, histogram=self._hist, scale=self._hist_scale)
+                if self._rows is not None:
+                    CUDA.Histogram_T_Rows(tensor=value, rows=self._rows, scale=self._hist_scale)
+                    self._rows_dirty = True
+                else:
+                    CUDA.Histogram_T(tensor=value, histogram=self._hist, scale=self._hist_scale)
             else:
                 raise TypeError('Quantization Property is invalid, expect either ASYMMETRICAL or SYMMETRICAL config here.')
 
     def pending_range(self):
         return super().pending_range() if self._phase == 'Detecting Minmax' else None
 
+    def _fold_hist(self) -> None:
+        """Sum the per-workgroup rows into the histogram (one launch, at render) and release them."""
+        if self._rows_dirty:
+            CUDA.Histogram_Rows_Finish(self._rows, self._hist)
+            self._rows_dirty = False
+            self._rows = None
+
+    def histogram(self) -> Optional[torch.Tensor]:
+        self._fold_hist()
+        return self._hist
+
     def reducible(self):
         if self._phase == 'Detecting Minmax': return super().reducible()
-        return [(self._hist, 'sum')] if self._hist is not None else []
+        return [(self.histogram(), 'sum')] if self._hist is not None else []
 
     # ---- search ------------------------------------------------------------------------------
     search_kind = 'kl'
@@ -258,7 +296,7 @@ class TorchHistObserver(TorchMinMaxObserver):
             if self._hist is None:
                 raise ValueError('Can not render quantization config yet, histogram is empty. '
                                  'Invoke observe() function before render config.')
-            scale, offset = self.hist_to_scale_offset(histogram=self._hist, hist_bins=self._hist_bins,
+            scale, offset = self.hist_to_scale_offset(histogram=self.histogram(), hist_bins=self._hist_bins,
                                                       hist_scale=self._hist_scale, config=self._quant_cfg)
             _set_per_tensor(self._quant_cfg, scale, offset, self._hist.device)
 
@@ -497,25 +535,42 @@ class TensorObserverFactroy:
 
 class CalibrationHook:
     """observer/__init__.py:40-73 -- the QuantOPRuntimeHook the executor fires around every
-    quantable operation (executor/base.py:76-102)."""
-    def __init__(self, operation, observer_table: Dict[object, BaseTensorObserver]) -> None:
+    quantable operation (executor/base.py:76-102).
+
+    ``stream`` (optional, set by RuntimeCalibrationPass) moves the observer kernels to a side HIP
+    stream: observing only READS the tensor, so the statistics kernels (HBM/latency bound, a few
+    microseconds each) overlap with the next convolution of the graph (compute bound) instead of
+    sitting on the critical path.  The side stream waits for the producer, the caching allocator is
+    told about the cross-stream use (record_stream), and rendering joins the streams."""
+    def __init__(self, operation, observer_table: Dict[object, BaseTensorObserver], stream=None) -> None:
         self._hook_to = operation
         self._operation = operation
         self._observer_table = observer_table
+        self.stream = stream
+
+    def _observe_all(self, values: list, quant_configs: list) -> None:
+        todo = [(v, self._observer_table[c]) for v, c in zip(values, quant_configs) if c in self._observer_table]
+        if not todo: return
+        if self.stream is None or not todo[0][0].is_cuda:
+            for v, ob in todo: ob.observe(v)
+            return
+        self.stream.wait_stream(torch.cuda.current_stream(todo[0][0].device))
+        with torch.cuda.stream(self.stream):
+            capturing = torch.cuda.is_current_stream_capturing()
+            for v, ob in todo:
+                ob.observe(v)
+                if not capturing: v.record_stream(self.stream)     # inside a graph the fork/join orders it
 
     def pre_forward_hook(self, inputs: list, quant_inputs: list, quant_configs: list) -> list:
-        for input_var, quant_config in zip(inputs, quant_configs):
-            if quant_config in self._observer_table:
-                self._observer_table[quant_config].observe(input_var)
+        self._observe_all(inputs, quant_configs)
         return quant_inputs
 
     def post_forward_hook(self, outputs: list, quant_outputs: list, quant_configs: list) -> list:
-        for output_var, quant_config in zip(outputs, quant_configs):
-            if quant_config in self._observer_table:
-                self._observer_table[quant_config].observe(output_var)
+        self._observe_all(outputs, quant_configs)
         return quant_outputs
 
     def render_quantization_config(self):
+        if self.stream is not None: torch.cuda.current_stream().wait_stream(self.stream)
         for _, observer in self._observer_table.items():
             observer.render_quantization_config()
             observer.report()
@@ -590,7 +645,7 @@ def render_observers(observers: Sequence[BaseTensorObserver]) -> None:
             if ob._quant_cfg.policy.has_property(P.PER_TENSOR):
                 groups.setdefault(ob.search_key(), []).append(ob)
     for key, obs in groups.items():
-        hists = torch.stack([ob._hist for ob in obs])
+        hists = torch.stack([ob.histogram() for ob in obs])
         if key[0] == 'kl':
             if any(ob._quant_cfg.policy.has_property(P.ASYMMETRICAL) for ob in obs): continue   # raises at render
             losses = CUDA.KLLosses(hists, key[2]).cpu().numpy()

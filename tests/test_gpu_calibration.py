@@ -266,3 +266,54 @@ def test_batched_render_single_sync_equals_individual():
     for ca, cb in zip(cfgs_a, cfgs_b):
         assert ca.state.value == 4 and cb.state.value == 4
         assert torch.equal(ca.scale, cb.scale) and torch.equal(ca.offset, cb.offset)
+
+
+def test_rows_and_slots_accumulators_match_oracle():
+    """The persistent per-workgroup accumulators (hist rows / minmax slots) fold to exactly the
+    histogram / range of the one-shot entry points."""
+    from ppq_amd import CUDA
+    g = torch.Generator().manual_seed(13)
+    batches = [torch.randn(n, generator=g) * 2 + 0.3 for n in (7, 4099, 1605632, 300000)]
+    slots = torch.tensor([float('inf'), float('-inf')], device=DEV).repeat(CUDA.minmax_slots(), 1).contiguous()
+    for b in batches: CUDA.MinMax_T_Slots(b.to(DEV), slots)
+    mm = torch.tensor([float('inf'), float('-inf')], device=DEV)
+    CUDA.MinMax_Slots_Finish(slots, mm)
+    allv = torch.cat(batches)
+    assert mm.cpu().tolist() == [allv.min().item(), allv.max().item()]
+    for asym in (False, True):
+        rows = torch.zeros(CUDA.hist_rows(), 2048, dtype=torch.int32, device=DEV)
+        want = np.zeros(2048, np.int32)
+        lo, hi = float(allv.min()) * 0.9, float(allv.max()) * 0.9
+        hs = float(allv.abs().max()) / 2048 * 0.9
+        for b in batches:
+            if asym:
+                CUDA.Histogram_Asymmetric_T_Rows(lo, hi, b.to(DEV), rows); O.hist_asym_t(b.numpy(), lo, hi, want)
+            else:
+                CUDA.Histogram_T_Rows(b.to(DEV), rows, hs); O.hist_sym_t(b.numpy(), hs, want)
+        hist = torch.full([2048], 5, dtype=torch.int32, device=DEV)          # finish ADDS into hist
+        CUDA.Histogram_Rows_Finish(rows, hist)
+        assert np.array_equal(hist.cpu().numpy(), want + 5)
+
+
+@pytest.mark.parametrize('mode', ['hip_graph', 'async', 'graph+async'])
+def test_graph_and_async_modes_equal_eager(mode):
+    """HIP-graph replay and side-stream observation change scheduling only: identical scales."""
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    g = torch.Generator().manual_seed(4)
+    batches = [torch.rand(4, 3, 24, 24, generator=g).to(DEV) for _ in range(8)]
+
+    def run(**kw):
+        graph = harness.small_cnn_graph(seed=3)
+        harness.quantize_graph(graph, 'kl', hist_bins=2048)
+        ex = harness.TorchExecutor(graph, DEV)
+        harness.ParameterQuantizePass().optimize(graph)
+        p = RuntimeCalibrationPass(method='kl', **kw)
+        p.optimize(graph, dataloader=batches, executor=ex, calib_steps=8)
+        torch.cuda.synchronize()
+        return p, [float(c.scale) for op in graph.operations.values() for c, v in op.config_with_variable
+                   if not v.is_parameter and c.state.value == 4]
+    _, eager = run(use_hip_graph=False, async_observe=False)
+    p, other = run(use_hip_graph='graph' in mode, async_observe='async' in mode)
+    assert len(eager) == 6 and eager == other
+    assert (p.graph_replays == 14) == ('graph' in mode)                   # 7 replays per phase
