@@ -30,13 +30,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def setup_dist(n_gpus: int):
+def setup_dist(n_gpus: int, backend: str = 'nccl', single_device: bool = False):
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
+    local = 0 if single_device else int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':     # RCCL over xGMI
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:                     # debugging aid: several ranks on one GPU (RCCL refuses duplicate devices)
+            dist.init_process_group(backend)
     return rank, world, local
 
 
@@ -98,13 +101,15 @@ def main():
     ap.add_argument('--bins', type=int, default=2048)
     ap.add_argument('--method', type=str, default='kl')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--backend', type=str, default='nccl')
+    ap.add_argument('--single-device', type=int, default=0, help='debug: put every rank on cuda:0 (use with --backend gloo)')
     ap.add_argument('--hip-graph', type=int, default=0, help='capture each phase forward into a HIP graph')
     ap.add_argument('--async-observe', type=int, default=0, help='observer kernels on a side HIP stream')
     ap.add_argument('--cache-params', type=int, default=0, help='keep fake-quantised weights resident between forwards')
     ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
     args = ap.parse_args()
 
-    rank, world, local = setup_dist(args.gpus)
+    rank, world, local = setup_dist(args.gpus, args.backend, bool(args.single_device))
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     dev = f'cuda:{local}'
     import ppq_amd  # noqa: F401  (fails loudly without libppq_hip.so)
@@ -148,8 +153,6 @@ def main():
             run_pass(graph2, ex2, batches, args.steps, args.method, False, False)   # eager, one stream -> clean event pairs
         else:   # collectives need every rank; profile the local (non-merged) statistics path only
             from ppq_amd.calibration import RuntimeCalibrationPass
-            import torch.distributed as dist
-            solo = dist.new_group([0]) if False else None
             pp = RuntimeCalibrationPass(method=args.method, check_steps=False, async_observe=False, use_hip_graph=False)
             pp._render = lambda: __import__('ppq_amd.observer', fromlist=['render_observers']).render_observers(pp._all_tensor_observers())
             pp.optimize(graph2, dataloader=batches, executor=ex2, calib_steps=args.steps)
