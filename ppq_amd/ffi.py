@@ -26,8 +26,12 @@ from ._lib import lib
 _KERNEL_FAILURE = 'Kernel Failure, '
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream     # hipStream_t of torch's current stream, no Stream object
+_get_device = torch._C._cuda_getDevice
+
+
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    return _raw_stream(_get_device())
 
 
 def _check(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
@@ -42,7 +46,16 @@ def _check(t: torch.Tensor, dtype: torch.dtype, name: str) -> None:
         raise RuntimeError(_KERNEL_FAILURE + f'{name} is not on the GPU (ppq_amd has no CPU path)')
 
 
-def _f32(t, name): _check(t, torch.float32, name + '(Expect to be FP32)')
+_F32 = torch.float32
+
+
+def _f32(t, name):
+    # fast path of _check: one expression when everything is in order (the common case)
+    try:
+        if t.dtype is _F32 and t.is_cuda and t.numel() > 0: return
+    except AttributeError:
+        pass
+    _check(t, torch.float32, name + '(Expect to be FP32)')
 
 
 def _raise(status: int) -> None:
@@ -72,8 +85,8 @@ class _DeviceOf:
         self.prev = None
 
     def __enter__(self):
-        if self.idx is not None and self.idx != torch.cuda.current_device():
-            self.prev = torch.cuda.current_device()
+        if self.idx is not None and self.idx != _get_device():
+            self.prev = _get_device()
             torch.cuda.set_device(self.idx)
 
     def __exit__(self, *a):

@@ -1,0 +1,112 @@
+"""LSQ (learned step size) fake-quant with gradients for scale -- the "next" row of the scope table.
+
+Mirror of ppq/quantization/algorithm/training.py:17-90 (``CuLSQ_LT`` / ``CuLSQ_LC``) and :318-421
+(``LSQDelegator``): forward = the fake-quant kernels, backward = ``CUDA.LinearQuantize_T_B / _C_B``
+(``dx = dy * 1[in range]``, ``ds = sum(...) * rsqrt(n * (qmax - qmin))`` per tensor,
+``rsqrt(n * qmax)`` per channel -- ppq/csrc/cuda/linear.cu:284-433).  A delegator instance can be
+registered on PPQ's executor with ``TorchExecutor.register_quantize_delegate(config, delegator)``
+(ppq/executor/torch.py:296-323); ``BlockwiseFinetune``-style passes then train scales through these
+kernels.  HIP path only: a CPU tensor raises.
+"""
+from typing import List
+
+import torch
+from torch.autograd import Function
+
+from .core import QuantizationProperty as P
+from .core import QuantizationStates, rounding_value, state_value
+from .ffi import CUDA
+from .qfunction import PPQuantFunction, _as_1d
+
+
+class CuLSQ_LT(Function):
+    @ staticmethod
+    def forward(ctx, tensor, scales, offsets, quant_min: int, quant_max: int, rounding) -> torch.Tensor:
+        r = rounding_value(rounding)
+        quantized = CUDA.LinearQuantize_T(tensor=tensor, scales=scales, offsets=offsets, minimum=quant_min,
+                                          maximum=quant_max, rounding=r)
+        ctx.save_for_backward(tensor, scales, offsets)
+        ctx._quant_params = [quant_min, quant_max, r]
+        return quantized
+
+    @ staticmethod
+    def backward(ctx, dy: torch.Tensor):
+        dy = dy.contiguous()
+        tensor, scales, offsets = ctx.saved_tensors
+        quant_min, quant_max, rounding = ctx._quant_params
+        dx, ds = CUDA.LinearQuantize_T_B(tensor, scales, offsets, dy, quant_min, quant_max, rounding)
+        return dx, ds.reshape(scales.shape), None, None, None, None
+
+
+class CuLSQ_LC(Function):
+    @ staticmethod
+    def forward(ctx, tensor, scales, offsets, channel_axis: int, quant_min: int, quant_max: int,
+                rounding) -> torch.Tensor:
+        r = rounding_value(rounding)
+        quantized = CUDA.LinearQuantize_C(tensor=tensor, scales=scales, offsets=offsets, channel_axis=channel_axis,
+                                          minimum=quant_min, maximum=quant_max, rounding=r)
+        ctx.save_for_backward(tensor, scales, offsets)
+        ctx._quant_params = [quant_min, quant_max, channel_axis, r]
+        return quantized
+
+    @ staticmethod
+    def backward(ctx, dy: torch.Tensor):
+        dy = dy.contiguous()
+        tensor, scales, offsets = ctx.saved_tensors
+        quant_min, quant_max, channel_axis, rounding = ctx._quant_params
+        dx, ds = CUDA.LinearQuantize_C_B(tensor, scales, offsets, dy, quant_min, quant_max, channel_axis, rounding)
+        return dx, ds.reshape(scales.shape), None, None, None, None, None
+
+
+class LSQDelegator:
+    """training.py:318-421 (the TorchQuantizeDelegator protocol: ``__call__(tensor, config)``)."""
+    def __init__(self, config, var, is_parameter_trainable: bool = True, is_scale_trainable: bool = True,
+                 is_offset_trainable: bool = True) -> None:
+        self.config = config
+        self.is_parameter = var.is_parameter
+        self.var = var
+        self.policy = config.policy
+        self.passive = state_value(config.state) == QuantizationStates.PASSIVE.value
+        self.param_backup = None
+        if self.is_parameter and is_parameter_trainable:
+            self.param_backup = self.var.value.clone()
+        active = (state_value(config.state) == QuantizationStates.ACTIVATED.value and config.dominated_by == config)
+        self.scale_backup, self.is_scale_trainable = None, False
+        if is_scale_trainable:
+            if (not config.policy.has_property(P.POWER_OF_2) and config.policy.has_property(P.LINEAR) and active
+                    and isinstance(config.scale, torch.Tensor)):
+                self.is_scale_trainable = True
+                self.scale_backup = self.config.scale.detach().clone()
+        self.offset_backup, self.is_offset_trainable = None, False
+        if is_offset_trainable:
+            if (not config.policy.has_property(P.SYMMETRICAL) and active and isinstance(config.offset, torch.Tensor)):
+                self.is_offset_trainable = True
+                self.offset_backup = self.config.offset.detach().clone()
+
+    def trainable_tensors(self) -> List[torch.Tensor]:
+        params = []
+        if self.is_offset_trainable: params.append(self.config.offset)
+        if self.is_scale_trainable: params.append(self.config.scale)
+        if self.is_parameter: params.append(self.var.value)
+        return params
+
+    def withdraw(self) -> None:
+        with torch.no_grad():
+            if self.scale_backup is not None: self.config.scale.copy_(self.scale_backup)
+            if self.offset_backup is not None: self.config.offset.copy_(self.offset_backup)
+            if self.param_backup is not None: self.var.value.copy_(self.param_backup)
+
+    def finalize(self) -> None:
+        self.scale_backup = self.offset_backup = self.param_backup = None
+
+    def __call__(self, tensor: torch.Tensor, config) -> torch.Tensor:
+        if config.policy.has_property(P.LINEAR):
+            if config.policy.has_property(P.PER_CHANNEL):
+                return CuLSQ_LC.apply(tensor, config.scale, config.offset, config.channel_axis, config.quant_min,
+                                      config.quant_max, config.rounding)
+            elif config.policy.has_property(P.PER_TENSOR):
+                return CuLSQ_LT.apply(tensor, _as_1d(config.scale), _as_1d(config.offset), config.quant_min,
+                                      config.quant_max, config.rounding)
+        elif config.policy.has_property(P.FLOATING):
+            return PPQuantFunction(tensor=tensor, config=config)      # scale is not trainable for FP8
+        raise ValueError('LSQDelegator: unsupported quantization policy')

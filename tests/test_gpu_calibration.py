@@ -317,3 +317,38 @@ def test_graph_and_async_modes_equal_eager(mode):
     p, other = run(use_hip_graph='graph' in mode, async_observe='async' in mode)
     assert len(eager) == 6 and eager == other
     assert (p.graph_replays == 14) == ('graph' in mode)                   # 7 replays per phase
+
+
+def test_lsq_autograd_functions():
+    """CuLSQ_LT / CuLSQ_LC (training.py:17-90): forward == fake quant, backward == the _B kernels,
+    checked against the torch formula of tests/test_cuda_kernel.py:67-78 (grad_x exact)."""
+    from ppq_amd import LinearQuantizationConfig, QuantizationStates
+    from ppq_amd.harness import Variable
+    from ppq_amd.lsq import LSQDelegator
+    from math import sqrt
+    g = torch.Generator().manual_seed(8)
+    t = (torch.rand(4, 6, 50, generator=g) * 50).to(DEV).requires_grad_(True)
+    dy = torch.rand(4, 6, 50, generator=g).to(DEV)
+    for per_channel in (False, True):
+        cfg = LinearQuantizationConfig(symmetrical=False, quant_min=0, quant_max=255, channel_axis=1 if per_channel else None)
+        cfg.scale = (torch.rand(6 if per_channel else 1, generator=g) * 0.5 + 0.05).to(DEV).requires_grad_(True)
+        cfg.offset = torch.randint(0, 255, [6 if per_channel else 1], generator=g).float().to(DEV)
+        cfg.state = QuantizationStates.ACTIVATED
+        d = LSQDelegator(cfg, Variable('x', t, False))
+        assert d.is_scale_trainable and d.is_offset_trainable and any(p is cfg.scale for p in d.trainable_tensors())
+        y = d(t, cfg)
+        y.backward(dy)
+        view = [1, -1, 1] if per_channel else [1]
+        s, o = cfg.scale.detach().view(view), cfg.offset.view(view)
+        qt = torch.round(t.detach() / s) + o
+        clipped = qt.clip(0, 255)
+        assert torch.equal(y.detach(), (clipped - o) * s)
+        dx = torch.where(clipped != qt, torch.zeros_like(dy), dy)
+        assert torch.equal(t.grad, dx)
+        ds = torch.where(clipped == qt, (((qt - o) * s) - t.detach()) * dy / s, torch.zeros_like(dy))
+        ds = ds + torch.where(qt > 255, (255 - o) * dy, torch.zeros_like(dy)) + torch.where(qt < 0, (0 - o) * dy, torch.zeros_like(dy))
+        if per_channel: want = ds.transpose(0, 1).flatten(1).sum(dim=-1) / sqrt(t.numel() * 255)          # linear.cu:402
+        else: want = ds.sum().reshape(1) / sqrt(t.numel() * 255)                                             # linear.cu:299
+        torch.testing.assert_close(cfg.scale.grad, want, rtol=1e-4, atol=1e-6)
+        t.grad = None
+        d.withdraw(); d.finalize()
