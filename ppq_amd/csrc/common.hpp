@@ -200,6 +200,79 @@ __device__ __forceinline__ void stream_elems(const float* __restrict__ x, uint32
     for (uint32_t i = done + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) f(x[i]);
 }
 
+// Same traversal with a WAVE-UNIFORM trip count (ballot-safe): on_tile(sample, valid) is called by
+// every lane once per tile before its elements, on_elem(value, valid) for every slot of the tile
+// (valid == false for slots past the end); the scalar remainder reports one element per "tile".
+template <int U, typename FT, typename FE>
+__device__ __forceinline__ void stream_tiles(const float* __restrict__ x, uint32_t n, bool vec_ok, FT on_tile,
+                                             FE on_elem) {
+    uint32_t done = 0;
+    if (vec_ok) {
+        const uint32_t nvec = n >> 2;
+        const float4* xv = reinterpret_cast<const float4*>(x);
+        const uint32_t tile = blockDim.x * U;
+        const uint32_t tiles = (nvec + tile - 1) / tile;
+        const uint32_t per = (tiles + gridDim.x - 1) / gridDim.x;
+        const uint32_t hi = min((blockIdx.x + 1) * per * tile, nvec);
+        uint32_t v = blockIdx.x * per * tile + threadIdx.x;
+        for (uint32_t t = 0; t < per; t++, v += tile) {
+            float4 a[U];
+#pragma unroll
+            for (int k = 0; k < U; k++)
+                a[k] = (v + k * blockDim.x < hi) ? xv[v + k * blockDim.x] : make_float4(0.f, 0.f, 0.f, 0.f);
+            on_tile(a[0].x, v < hi);
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const bool in = v + k * blockDim.x < hi;
+                on_elem(a[k].x, in); on_elem(a[k].y, in); on_elem(a[k].z, in); on_elem(a[k].w, in);
+            }
+        }
+        done = nvec << 2;
+    }
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t rem = n - done;
+    const uint32_t trips = (rem + stride - 1) / stride;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (uint32_t t = 0; t < trips; t++, i += stride) {
+        const bool in = i < rem;
+        const float a = in ? x[done + i] : 0.f;
+        if ((t & 15u) == 0) on_tile(a, in);
+        on_elem(a, in);
+    }
+}
+
+// One wavefront's view of an LDS counter array (`nbins` counters followed by 64 per-lane trash
+// slots) with a "hot bin" kept in registers: a key shared by many lanes would serialise the LDS
+// atomic unit (a k-way same-address ds_add costs ~k cycles), so hits on the elected hot bin are
+// counted in a VGPR and flushed with one wave reduction.  add() is unconditional: pass trash() for
+// "do not count".  elect() must be reached by all lanes of the wave together.
+struct HotCounter {
+    unsigned int* h;
+    int nbins, hot_bin, hot_cnt;
+    __device__ __forceinline__ void init(unsigned int* base, int bins) { h = base; nbins = bins; hot_bin = -1; hot_cnt = 0; }
+    __device__ __forceinline__ int trash() const { return nbins + (int)(threadIdx.x & 63); }
+    __device__ __forceinline__ void flush() {
+        int c = hot_cnt;
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m, 64);
+        if ((threadIdx.x & 63) == 0 && c != 0 && hot_bin >= 0) atomicAdd(&h[hot_bin], (unsigned int)c);
+        hot_cnt = 0;
+    }
+    __device__ __forceinline__ void elect(int b, bool valid, int min_lanes = 12) {
+        valid = valid && b < nbins;
+        const unsigned long long act = __ballot(valid);
+        if (act == 0ull) return;
+        const int cand = __builtin_amdgcn_readlane(b, __ffsll((long long)act) - 1);
+        if (cand == hot_bin) return;
+        if (__popcll(__ballot(valid && b == cand)) >= min_lanes) { flush(); hot_bin = cand; }
+    }
+    __device__ __forceinline__ void add(int slot) {
+        const bool hit = slot == hot_bin;
+        hot_cnt += hit ? 1 : 0;
+        atomicAdd(&h[hit ? trash() : slot], 1u);
+    }
+};
+
 #endif  // __HIPCC__
 
 // grid size for a streaming kernel that consumes `work_items` items, `per_block` per block-pass,

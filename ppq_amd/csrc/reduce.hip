@@ -196,12 +196,19 @@ __device__ void select_bin(const uint32_t* __restrict__ hist, int nbins, uint32_
     __syncthreads();
 }
 
+constexpr int kQTrash = 64;
+
 __global__ __launch_bounds__(kBlock) void quantile_pass1_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
                                                                 uint32_t* __restrict__ ws) {
-    __shared__ uint32_t h[kQ1];
+    __shared__ uint32_t h[kQ1 + kQTrash];
     for (int i = threadIdx.x; i < kQ1; i += kBlock) h[i] = 0;
     __syncthreads();
-    stream_elems<4>(x, n, vec_ok, [&](float v) { atomicAdd(&h[f2key(v) >> 20], 1u); });
+    HotCounter hc;
+    hc.init(h, kQ1);
+    stream_tiles<4>(x, n, vec_ok,
+                    [&](float v, bool in) { hc.elect((int)(f2key(v) >> 20), in); },
+                    [&](float v, bool in) { hc.add(in ? (int)(f2key(v) >> 20) : hc.trash()); });
+    hc.flush();
     __syncthreads();
     for (int i = threadIdx.x; i < kQ1; i += kBlock)
         if (h[i]) atomicAdd(&ws[kOffH1 + i], h[i]);
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(kBlock) void quantile_pass1_kernel(const float* __r
 __global__ __launch_bounds__(kBlock) void quantile_pass2_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
                                                                 uint32_t k_hi, uint32_t k_lo,
                                                                 uint32_t* __restrict__ ws) {
-    __shared__ uint32_t h[2 * kQ2];
+    __shared__ uint32_t h[2 * (kQ2 + kQTrash)];
     __shared__ uint32_t scratch[kBlock];
     __shared__ uint32_t sel[2];
     select_bin(ws + kOffH1, kQ1, k_hi, scratch, sel);
@@ -218,17 +225,30 @@ __global__ __launch_bounds__(kBlock) void quantile_pass2_kernel(const float* __r
     __syncthreads();
     select_bin(ws + kOffH1, kQ1, k_lo, scratch, sel);
     const uint32_t p_lo = sel[0];
-    for (int i = threadIdx.x; i < 2 * kQ2; i += kBlock) h[i] = 0;
+    for (int i = threadIdx.x; i < 2 * (kQ2 + kQTrash); i += kBlock) h[i] = 0;
     __syncthreads();
-    stream_elems<4>(x, n, vec_ok, [&](float v) {
-        const uint32_t key = f2key(v);
-        const uint32_t top = key >> 20, mid = (key >> 8) & 0xFFFu;
-        if (top == p_hi) atomicAdd(&h[mid], 1u);
-        if (top == p_lo) atomicAdd(&h[kQ2 + mid], 1u);
-    });
+    HotCounter hi_c, lo_c;
+    hi_c.init(h, kQ2);
+    lo_c.init(h + kQ2 + kQTrash, kQ2);
+    stream_tiles<4>(x, n, vec_ok,
+                    [&](float v, bool in) {
+                        const uint32_t key = f2key(v);
+                        hi_c.elect((int)((key >> 8) & 0xFFFu), in && (key >> 20) == p_hi);
+                        lo_c.elect((int)((key >> 8) & 0xFFFu), in && (key >> 20) == p_lo);
+                    },
+                    [&](float v, bool in) {
+                        const uint32_t key = f2key(v);
+                        const uint32_t top = key >> 20;
+                        const int mid = (int)((key >> 8) & 0xFFFu);
+                        if (in && top == p_hi) hi_c.add(mid);      // rare unless the bin is hot (then it is
+                        if (in && top == p_lo) lo_c.add(mid);      // absorbed by the hot register)
+                    });
+    hi_c.flush(); lo_c.flush();
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * kQ2; i += kBlock)
+    for (int i = threadIdx.x; i < kQ2; i += kBlock) {
         if (h[i]) atomicAdd(&ws[kOffH2 + i], h[i]);
+        if (h[kQ2 + kQTrash + i]) atomicAdd(&ws[kOffH2 + kQ2 + i], h[kQ2 + kQTrash + i]);
+    }
 }
 
 // shared by pass 3 and the final pick: 24-bit prefixes and residual ranks of both targets
@@ -249,21 +269,34 @@ __device__ void select_prefix24(const uint32_t* __restrict__ ws, uint32_t k_hi, 
 __global__ __launch_bounds__(kBlock) void quantile_pass3_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
                                                                 uint32_t k_hi, uint32_t k_lo,
                                                                 uint32_t* __restrict__ ws) {
-    __shared__ uint32_t h[2 * kQ3];
+    __shared__ uint32_t h[2 * (kQ3 + kQTrash)];
     __shared__ uint32_t scratch[kBlock];
     __shared__ uint32_t sel[2];
     uint32_t p24[2], r24[2];
     select_prefix24(ws, k_hi, k_lo, scratch, sel, p24, r24);
-    for (int i = threadIdx.x; i < 2 * kQ3; i += kBlock) h[i] = 0;
+    for (int i = threadIdx.x; i < 2 * (kQ3 + kQTrash); i += kBlock) h[i] = 0;
     __syncthreads();
-    stream_elems<4>(x, n, vec_ok, [&](float v) {
-        const uint32_t key = f2key(v);
-        if ((key >> 8) == p24[0]) atomicAdd(&h[key & 0xFFu], 1u);
-        if ((key >> 8) == p24[1]) atomicAdd(&h[kQ3 + (key & 0xFFu)], 1u);
-    });
+    HotCounter hi_c, lo_c;
+    hi_c.init(h, kQ3);
+    lo_c.init(h + kQ3 + kQTrash, kQ3);
+    stream_tiles<4>(x, n, vec_ok,
+                    [&](float v, bool in) {
+                        const uint32_t key = f2key(v);
+                        hi_c.elect((int)(key & 0xFFu), in && (key >> 8) == p24[0]);
+                        lo_c.elect((int)(key & 0xFFu), in && (key >> 8) == p24[1]);
+                    },
+                    [&](float v, bool in) {
+                        const uint32_t key = f2key(v);
+                        const int low = (int)(key & 0xFFu);
+                        if (in && (key >> 8) == p24[0]) hi_c.add(low);
+                        if (in && (key >> 8) == p24[1]) lo_c.add(low);
+                    });
+    hi_c.flush(); lo_c.flush();
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * kQ3; i += kBlock)
+    for (int i = threadIdx.x; i < kQ3; i += kBlock) {
         if (h[i]) atomicAdd(&ws[kOffH3 + i], h[i]);
+        if (h[kQ3 + kQTrash + i]) atomicAdd(&ws[kOffH3 + kQ3 + i], h[kQ3 + kQTrash + i]);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void quantile_pick_kernel(uint32_t k_hi, uint32_t k_lo,
@@ -440,7 +473,8 @@ int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, void* wor
     const uint32_t k_hi = pos(q), k_lo = pos(1 - q);
     uint32_t* ws = (uint32_t*)workspace;
     if (int st = check_hip(hipMemsetAsync(ws, 0, (size_t)kQWords * 4, s), "memset quantile workspace")) return st;
-    const int grid = stream_grid(n, kBlock * 16, kNumCU * 2);
+    static const int qpc = getenv("PPQHIP_Q_PER_CU") ? atoi(getenv("PPQHIP_Q_PER_CU")) : 4;
+    const int grid = stream_grid(n, kBlock * 16, kNumCU * qpc);
     const bool vec_ok = aligned16(x);
     hipLaunchKernelGGL(quantile_pass1_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, vec_ok, ws);
     hipLaunchKernelGGL(quantile_pass2_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, vec_ok, k_hi, k_lo, ws);
