@@ -137,29 +137,69 @@ __device__ __forceinline__ float block_sum(float v, float* lds) {
     return r;  // valid in wave 0
 }
 
+// per tensor: one contiguous chunk per workgroup, 16-B loads of x and dy, 16-B stores of grad_x;
+// the workgroup's partial d(loss)/d(scale) goes to partial[blockIdx.x] (no same-address atomics),
+// lsq_finish_kernel sums the partials in double and applies grad_factor.
 __global__ __launch_bounds__(kBlock) void fq_linear_t_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
-    const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ gs, uint32_t n,
-    int qmin, int qmax, float grad_factor, int rounding) {
+    const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ partial, uint32_t n, int vec_ok,
+    int qmin, int qmax, int rounding) {
     __shared__ float lds[kBlock / kWave];
     const float s = scale[0];
     const float o = __builtin_roundf(offset[0]);
     float acc = 0.f;
+    uint32_t done = 0;
+    if (vec_ok) {
+        const uint32_t nvec = n >> 2;
+        const float4* xv = reinterpret_cast<const float4*>(x);
+        const float4* dv = reinterpret_cast<const float4*>(dy);
+        float4* gv = reinterpret_cast<float4*>(gx);
+        const uint32_t tiles = (nvec + kBlock - 1) / kBlock;
+        const uint32_t per = (tiles + gridDim.x - 1) / gridDim.x;
+        const uint32_t lo = blockIdx.x * per * kBlock;
+        const uint32_t hi = min(lo + per * kBlock, nvec);
+        for (uint32_t v = lo + threadIdx.x; v < hi; v += kBlock) {
+            const float4 a = xv[v], d = dv[v];
+            float4 g;
+            acc += lsq_bwd_elem<false>(a.x, d.x, s, o, qmin, qmax, rounding, &g.x);
+            acc += lsq_bwd_elem<false>(a.y, d.y, s, o, qmin, qmax, rounding, &g.y);
+            acc += lsq_bwd_elem<false>(a.z, d.z, s, o, qmin, qmax, rounding, &g.z);
+            acc += lsq_bwd_elem<false>(a.w, d.w, s, o, qmin, qmax, rounding, &g.w);
+            gv[v] = g;
+        }
+        done = nvec << 2;
+    }
     const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+    for (uint32_t i = done + blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         float g;
         acc += lsq_bwd_elem<false>(x[i], dy[i], s, o, qmin, qmax, rounding, &g);
         gx[i] = g;
     }
     const float tot = block_sum(acc, lds);
-    if (threadIdx.x == 0) atomicAdd(gs, tot * grad_factor);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kBlock) void lsq_finish_kernel(const float* __restrict__ partial, uint32_t count,
+                                                            float grad_factor, float* __restrict__ gs) {
+    __shared__ double lds[kBlock / kWave];
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < count; i += kBlock) acc += (double)partial[i];
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kBlock / kWave; w++) t += lds[w];
+        gs[0] = (float)t * grad_factor;
+    }
 }
 
 // rows = outer * C rows of `epc` contiguous elements; block b handles chunk (b % chunks) of row
-// (b / chunks) -> one channel per block, one atomic per block.
+// (b / chunks) -> one channel per block, one atomic per block (spread over C addresses).
 __global__ __launch_bounds__(kBlock) void fq_linear_c_bwd_row_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
-    const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ gs, uint32_t epc,
+    const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ gs, uint32_t epc, int vec_ok,
     FastDiv chunks, FastDiv num_channel, uint32_t chunk_elems, int qmin, int qmax, float grad_factor,
     int rounding) {
     __shared__ float lds[kBlock / kWave];
@@ -172,10 +212,25 @@ __global__ __launch_bounds__(kBlock) void fq_linear_c_bwd_row_kernel(
     const uint32_t hi = min(lo + chunk_elems, epc);
     const size_t base = (size_t)row * epc;
     float acc = 0.f;
-    for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
-        float g;
-        acc += lsq_bwd_elem<true>(x[base + j], dy[base + j], s, o, qmin, qmax, rounding, &g);
-        gx[base + j] = g;
+    if (vec_ok) {   // epc % 4 == 0, chunk_elems % 4 == 0, 16-B aligned bases
+        const float4* xv = reinterpret_cast<const float4*>(x + base);
+        const float4* dv = reinterpret_cast<const float4*>(dy + base);
+        float4* gv = reinterpret_cast<float4*>(gx + base);
+        for (uint32_t v = (lo >> 2) + threadIdx.x; v < (hi >> 2); v += kBlock) {
+            const float4 a = xv[v], d = dv[v];
+            float4 g;
+            acc += lsq_bwd_elem<true>(a.x, d.x, s, o, qmin, qmax, rounding, &g.x);
+            acc += lsq_bwd_elem<true>(a.y, d.y, s, o, qmin, qmax, rounding, &g.y);
+            acc += lsq_bwd_elem<true>(a.z, d.z, s, o, qmin, qmax, rounding, &g.z);
+            acc += lsq_bwd_elem<true>(a.w, d.w, s, o, qmin, qmax, rounding, &g.w);
+            gv[v] = g;
+        }
+    } else {
+        for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
+            float g;
+            acc += lsq_bwd_elem<true>(x[base + j], dy[base + j], s, o, qmin, qmax, rounding, &g);
+            gx[base + j] = g;
+        }
     }
     const float tot = block_sum(acc, lds);
     if (threadIdx.x == 0) atomicAdd(&gs[c], tot * grad_factor);
@@ -315,12 +370,16 @@ int ppqhip_fq_linear_t_bwd(const float* x, const float* scale, const float* offs
     if (int st = validate_n(n, "fq_linear_t_bwd")) return st;
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_FQ_LINEAR_T_BWD, 12.0 * (double)n, s);
-    if (int st = check_hip(hipMemsetAsync(grad_s, 0, sizeof(float), s), "memset grad_s")) return st;
     // rsqrtf(((double)n * (clip_max - clip_min))): linear.cu:299
     const float grad_factor = (float)(1.0 / sqrt((double)n * (double)(clip_max - clip_min)));
-    hipLaunchKernelGGL(fq_linear_t_bwd_kernel, dim3(stream_grid(n, kBlock * 4, kNumCU * 4)), dim3(kBlock), 0, s, x,
-                       scale, offset, grad_y, grad_x, grad_s, (uint32_t)n, clip_min, clip_max, grad_factor,
-                       rounding);
+    const int grid = stream_grid(n, kBlock * 4 * 4, kNumCU * 8);
+    float* partial = (float*)scratch(s, sizeof(float) * (size_t)grid);
+    if (partial == nullptr) return PPQHIP_ERR_HIP;
+    const int vec_ok = (aligned16(x) && aligned16(grad_y) && aligned16(grad_x)) ? 1 : 0;
+    hipLaunchKernelGGL(fq_linear_t_bwd_kernel, dim3(grid), dim3(kBlock), 0, s, x, scale, offset, grad_y, grad_x,
+                       partial, (uint32_t)n, vec_ok, clip_min, clip_max, rounding);
+    hipLaunchKernelGGL(lsq_finish_kernel, dim3(1), dim3(kBlock), 0, s, (const float*)partial, (uint32_t)grid,
+                       grad_factor, grad_s);
     return finish_launch("fq_linear_t_bwd");
 }
 
@@ -341,8 +400,9 @@ int ppqhip_fq_linear_c_bwd(const float* x, const float* scale, const float* offs
         const uint32_t chunk_elems = 4096;
         const uint32_t chunks = (uint32_t)((elem_per_channel + chunk_elems - 1) / chunk_elems);
         const int64_t rows = n / elem_per_channel;
+        const int vec_ok = (elem_per_channel % 4 == 0 && aligned16(x) && aligned16(grad_y) && aligned16(grad_x)) ? 1 : 0;
         hipLaunchKernelGGL(fq_linear_c_bwd_row_kernel, dim3((uint32_t)(rows * chunks)), dim3(kBlock), 0, s, x,
-                           scale, offset, grad_y, grad_x, grad_s, (uint32_t)elem_per_channel,
+                           scale, offset, grad_y, grad_x, grad_s, (uint32_t)elem_per_channel, vec_ok,
                            make_fastdiv(chunks), nc, chunk_elems, clip_min, clip_max, grad_factor, rounding);
     } else {
         const int use_lds = num_channel <= 8192;
