@@ -76,6 +76,24 @@ def collect_prof():
              'total_bytes': float(arr[i].total_bytes)} for i in range(n)]
 
 
+def pmc_traffic(kernel_name: str):
+    """HBM bytes per launch of `kernel_name` from the committed PMC summary (separate rocprofv3
+    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of THIS command, FETCH_SIZE doubled per the gfx950
+    correction of MI355X_MICROARCH.md; tools/summarize_profile.py).  None when no summary is present."""
+    path = os.path.join(ROOT, 'profiles', 'r01_bench_pmc_bytes.json')
+    if not os.path.exists(path): return None, None
+    data = json.load(open(path))
+    key = {'hist_sym_t': 'hist_t_lds_kernel<false', 'hist_asym_t': 'hist_t_lds_kernel<true', 'minmax_t': 'minmax_t_kernel',
+           'fq_linear_c': 'fq_linear_c_tile_kernel', 'fq_linear_t': 'fq_linear_t_tile_kernel'}.get(kernel_name)
+    if key is None: return None, None
+    tot = n = 0
+    for k, v in data.items():
+        if k.startswith(key) and 'launches' in v:
+            tot += v['launches'] * (v.get('hbm_read_bytes_per_launch_corrected', 0) + v.get('hbm_write_bytes_per_launch', 0))
+            n += v['launches']
+    return (round(tot / n), 'profiles/r01_bench_pmc_bytes.json') if n else (None, None)
+
+
 def cpu_baseline(bins, batch_samples=2, n_batches=2):
     """The same two-phase KL calibration on the host cores, through the CPU oracle."""
     from ppq_amd import harness
@@ -164,8 +182,10 @@ def main():
             avg_s = dom['total_ms'] * 1e-3 / dom['launches']
             avg_b = dom['total_bytes'] / dom['launches']
             ach = avg_b / avg_s / 1e9
+            traffic, traffic_src = pmc_traffic(dom['name'])
             roof = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS,
-                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': None,
+                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': traffic,
+                    'traffic_source': traffic_src,
                     'launches': dom['launches'], 'avg_launch_us': round(avg_s * 1e6, 2),
                     'algorithmic_bytes_per_launch': round(avg_b)}
     if world > 1:
