@@ -404,7 +404,7 @@ static int launch_hist_t(const float* x, int64_t n, BinRule rule, int32_t* hist,
     const int copies = pick_copies(rule.bins, block);
     const size_t lds = lds_bytes(rule.bins, copies);
     const int vec_ok = aligned16(x) ? 1 : 0;
-    static const int small_elems = env_int("PPQHIP_HIST_SMALL_ELEMS", 16 << 20);
+    static const int small_elems = env_int("PPQHIP_HIST_SMALL_ELEMS", 48 << 20);   // sweep: U=1 wins up to ~100 MB
     const bool small = n < small_elems;
     const int grid = hist_grid(n, small ? kHistUSmall : kHistUBig);
     bool failed = false;
