@@ -347,3 +347,49 @@ def small_cnn_graph(seed: int = 0, width: int = 16) -> BaseGraph:
     y = g.create_operation('Gemm', 'fc', [f, w, bb])
     g.outputs[y.name] = y
     return g
+
+
+def transformer_mlp_graph(seed: int = 0, dim: int = 64, hidden: int = 256) -> BaseGraph:
+    """LayerNorm -> Gemm -> Gelu -> Gemm -> Add(residual): the MLP half of a ViT block, the operator
+    mix BASELINE config 4 (ViT-B/16, FP8 E4M3) exercises."""
+    gen = torch.Generator().manual_seed(seed)
+    g = BaseGraph('transformer_mlp')
+    x = g.create_variable('input'); g.inputs['input'] = x
+    gamma = g.create_variable('ln_w', torch.ones(dim) + torch.randn(dim, generator=gen) * 0.05, True)
+    beta = g.create_variable('ln_b', torch.randn(dim, generator=gen) * 0.05, True)
+    h = g.create_operation('LayerNormalization', 'ln', [x, gamma, beta])
+    w1 = g.create_variable('fc1_w', torch.randn([hidden, dim], generator=gen) * (1.0 / dim) ** 0.5, True)
+    b1 = g.create_variable('fc1_b', torch.zeros(hidden), True)
+    h = g.create_operation('Gemm', 'fc1', [h, w1, b1])
+    h = g.create_operation('Gelu', 'gelu', [h])
+    w2 = g.create_variable('fc2_w', torch.randn([dim, hidden], generator=gen) * (1.0 / hidden) ** 0.5, True)
+    b2 = g.create_variable('fc2_b', torch.zeros(dim), True)
+    h = g.create_operation('Gemm', 'fc2', [h, w2, b2])
+    y = g.create_operation('Add', 'residual', [h, x])
+    g.outputs[y.name] = y
+    return g
+
+
+def quantize_graph_fp8(graph: BaseGraph, exponent: int = 4, mantissa: int = 3) -> None:
+    """TRT_FP8-style policy (quantizer/FP8Quantizer.py:107-200): only the inputs of Conv / Gemm / MatMul
+    are quantised -- activations per tensor with the power-of-2 'floating' observer, weights per
+    channel (axis 0) with the same observer; everything else stays FP32."""
+    from .core import FloatingQuantizationConfig
+    qmax = 448.0 if (exponent, mantissa) == (4, 3) else 57344.0
+    for name, op in list(graph.operations.items()):
+        in_cfgs = []
+        for i, v in enumerate(op.inputs):
+            c = FloatingQuantizationConfig(exponent=exponent, mantissa=mantissa, quant_min=-qmax, quant_max=qmax,
+                                           calibration='floating',
+                                           channel_axis=0 if (v.is_parameter and i == 1) else None)
+            if op.type not in COMPUTING_OP or (v.is_parameter and i != 1): c.state = QuantizationStates.FP32
+            in_cfgs.append(c)
+        outs = []
+        for _ in op.outputs:
+            c = FloatingQuantizationConfig(exponent=exponent, mantissa=mantissa, quant_min=-qmax, quant_max=qmax)
+            c.state = QuantizationStates.FP32
+            outs.append(c)
+        qop = QuantableOperation(op, OperationQuantizationConfig(in_cfgs, outs))
+        for v in qop.inputs: v.dest_ops[v.dest_ops.index(op)] = qop
+        for v in qop.outputs: v.source_op = qop
+        graph.operations[name] = qop

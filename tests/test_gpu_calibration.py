@@ -352,3 +352,44 @@ def test_lsq_autograd_functions():
         torch.testing.assert_close(cfg.scale.grad, want, rtol=1e-4, atol=1e-6)
         t.grad = None
         d.withdraw(); d.finalize()
+
+
+def test_fp8_calibration_transformer_block():
+    """BASELINE config 4 in miniature: FP8 E4M3 simulation of a transformer MLP block -- power-of-2
+    scales from the 'floating' observer, fake-quant through FloatingQuantize_T/C, checked against the
+    oracle on the tensors the executor produced."""
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    graph = harness.transformer_mlp_graph(seed=2)
+    harness.quantize_graph_fp8(graph)
+    ex = harness.TorchExecutor(graph, DEV)
+    harness.ParameterQuantizePass().optimize(graph)
+    g = torch.Generator().manual_seed(6)
+    batches = [(torch.randn(8, 197, 64, generator=g) * 2).to(DEV) for _ in range(8)]
+    RuntimeCalibrationPass().optimize(graph, dataloader=batches, executor=ex, calib_steps=8)
+    cands = {.0078125, .03125, .125, 1.0, 4.0, 16.0, 64.0}
+    n_act = n_w = 0
+    for op in graph.operations.values():
+        for cfg, var in op.config_with_variable:
+            if cfg.state.value != 4: continue
+            assert all(float(s) in cands for s in cfg.scale.reshape(-1).tolist())
+            if var.is_parameter:
+                n_w += 1
+                y = ex.quantize_function(var.value, cfg).cpu().numpy()
+                want = O.fq_float_c(var.value.cpu().numpy(), cfg.scale.cpu().numpy(), cfg.offset.cpu().numpy(), 0)
+                assert np.array_equal(y.view(np.uint32), want.view(np.uint32))
+            else:
+                n_act += 1
+    assert (n_act, n_w) == (2, 2)
+    # the quantised input of fc1 lies on the E4M3 grid scaled by its power-of-2 scale
+    seen = {}
+
+    class Spy:
+        def pre_forward_hook(self, inputs, quant_inputs, quant_configs):
+            seen['raw'], seen['q'], seen['cfg'] = inputs[0], quant_inputs[0], quant_configs[0]
+            return quant_inputs
+        def post_forward_hook(self, outputs, quant_outputs, quant_configs): return quant_outputs
+    ex.forward(batches[0], hooks={'fc1': Spy()})
+    cfg = seen['cfg']
+    want = O.fq_float_t(seen['raw'].cpu().numpy(), cfg.scale.cpu().numpy().reshape(1), cfg.offset.cpu().numpy().reshape(1))
+    assert np.array_equal(seen['q'].cpu().numpy().view(np.uint32), want.view(np.uint32))
