@@ -140,11 +140,25 @@ class TorchExecutor:
         self._default_quant_fn = PPQuantFunction
         self.cache_parameter_quantization = False     # opt-in: see _quantize_parameter
         self._param_cache: Dict[str, tuple] = {}
+        self._delegates: Dict[object, Callable] = {}
         for v in graph.variables.values():
             if v.is_parameter and v.value is not None: v.value = v.value.to(device)
 
+    def register_quantize_delegate(self, config, delegator: Callable) -> None:
+        """ppq/executor/torch.py:296-323: a delegator takes over the quantisation of one config."""
+        self._delegates[config] = delegator
+
+    def remove_quantize_delegate(self, config) -> None:
+        self._delegates.pop(config, None)
+
     def quantize_function(self, tensor: torch.Tensor, config=None) -> torch.Tensor:
+        if self._delegates and config in self._delegates:          # torch.py:610-613
+            return self._delegates[config](tensor, config)
         return self._default_quant_fn(tensor, config)
+
+    def forward_with_gradient(self, inputs, output_names: List[str] = None, hooks=None):
+        """torch.py:412-455: the same loop with autograd enabled (finetuning passes)."""
+        return TorchExecutor.forward.__wrapped__(self, inputs, output_names, hooks)
 
     def _quantize_parameter(self, var: Variable, config) -> torch.Tensor:
         """A parameter and its scale do not change between calibration forwards, so its fake-quantised

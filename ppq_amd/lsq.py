@@ -110,3 +110,74 @@ class LSQDelegator:
         elif config.policy.has_property(P.FLOATING):
             return PPQuantFunction(tensor=tensor, config=config)      # scale is not trainable for FP8
         raise ValueError('LSQDelegator: unsupported quantization policy')
+
+
+class LearnedStepSizePass:
+    """The finetune loop of ppq/quantization/optim/training.py:728-826 (LearnedStepSizePass.finetune)
+    for a graph treated as ONE trainable block: LSQDelegators on every activated config, Adam over
+    {weights, scales, offsets}, MSE between the quantised and the FP32 block output (+ gamma * weight
+    quantisation error), withdraw when the loss did not improve.  The reference's block splitting
+    (BlockBuilder, training.py:191-315) is graph plumbing outside this package's scope."""
+    def __init__(self, steps: int = 100, lr: float = 5e-5, gamma: float = 0.0, optimizer=None):
+        self.steps, self.lr, self.gamma, self.optimizer = steps, lr, gamma, optimizer
+
+    @ staticmethod
+    def _loss(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+        return torch.mean(torch.square(a.flatten(1) - b.flatten(1)))          # torch_mean_square_error
+
+    def optimize(self, graph, dataloader, executor, **kwargs):
+        ops = [op for op in graph.operations.values() if hasattr(op, 'config')]
+        saved = {}
+        # FP32 reference outputs: every config switched off (QuantableOperation.dequantize)
+        for op in ops:
+            for cfg, _ in op.config_with_variable:
+                saved[cfg] = cfg.state
+                if QuantizationStates.is_activated(cfg.state): cfg.state = QuantizationStates.FP32
+        batches = list(dataloader)
+        fp_outputs = [executor.forward(b)[0].detach() for b in batches]
+        for cfg, st in saved.items(): cfg.state = st
+
+        def block_loss():
+            with torch.no_grad():
+                return float(sum(self._loss(executor.forward(b)[0], f) for b, f in zip(batches, fp_outputs)) / len(batches))
+        pre_loss = block_loss()
+        delegators, tensors = {}, []
+        for op in ops:
+            if op.type in {'Conv', 'Gemm', 'ConvTranspose', 'MatMul', 'Add', 'Mul'}:
+                for var in op.inputs:
+                    if var.is_parameter:
+                        var.value.requires_grad_(True); tensors.append(var.value)
+            for cfg, var in op.config_with_variable:
+                if state_value(cfg.state) in (QuantizationStates.ACTIVATED.value, QuantizationStates.PASSIVE.value):
+                    for t in (cfg.scale, cfg.offset):
+                        if isinstance(t, torch.Tensor) and t.is_floating_point(): t.requires_grad_(True)
+                    d = LSQDelegator(config=cfg, var=var)
+                    tensors.extend(d.trainable_tensors())
+                    executor.register_quantize_delegate(cfg, d)
+                    delegators[cfg] = d
+        uniq, seen = [], set()
+        for t in tensors:
+            if t.requires_grad and id(t) not in seen: seen.add(id(t)); uniq.append(t)
+        if not uniq:
+            for cfg in delegators: executor.remove_quantize_delegate(cfg)
+            return 0.0, 0.0
+        opt = torch.optim.Adam(uniq, lr=self.lr) if self.optimizer is None else self.optimizer(uniq, lr=self.lr)
+        for step in range(self.steps):
+            b, f = batches[step % len(batches)], fp_outputs[step % len(batches)]
+            opt.zero_grad()
+            out = executor.forward_with_gradient(b)[0]
+            loss = self._loss(out, f)
+            if self.gamma:
+                for op in ops:
+                    if op.type in {'Conv', 'Gemm'}:
+                        w, wc = op.inputs[1].value, op.config.input_quantization_config[1]
+                        loss = loss + self._loss(w, PPQuantFunction(w, wc).detach()) * self.gamma
+            loss.backward()
+            opt.step()
+        post_loss = block_loss()
+        for cfg, d in delegators.items():
+            if post_loss > pre_loss: d.withdraw()
+            d.finalize()
+            executor.remove_quantize_delegate(cfg)
+        for t in uniq: t.requires_grad_(False)
+        return pre_loss, post_loss

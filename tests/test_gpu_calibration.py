@@ -393,3 +393,30 @@ def test_fp8_calibration_transformer_block():
     cfg = seen['cfg']
     want = O.fq_float_t(seen['raw'].cpu().numpy(), cfg.scale.cpu().numpy().reshape(1), cfg.offset.cpu().numpy().reshape(1))
     assert np.array_equal(seen['q'].cpu().numpy().view(np.uint32), want.view(np.uint32))
+
+
+def test_learned_step_size_finetune_int4():
+    """BASELINE config 5 in miniature: INT4 per-channel weights + INT8 activations on a small CNN,
+    scales / weights trained through CuLSQ (forward fake-quant kernels, backward LSQ kernels)."""
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    from ppq_amd.lsq import LearnedStepSizePass
+    graph = harness.small_cnn_graph(seed=5, width=16)
+    harness.quantize_graph(graph, 'minmax')
+    for op in graph.operations.values():                        # weights -> int4 [-8, 7]
+        for cfg, var in op.config_with_variable:
+            if var.is_parameter and cfg.state.value == 1:
+                cfg.num_of_bits, cfg.quant_min, cfg.quant_max = 4, -8, 7
+    ex = harness.TorchExecutor(graph, DEV)
+    harness.ParameterQuantizePass().optimize(graph)
+    g = torch.Generator().manual_seed(7)
+    batches = [torch.rand(8, 3, 24, 24, generator=g).to(DEV) for _ in range(8)]
+    RuntimeCalibrationPass().optimize(graph, dataloader=batches, executor=ex, calib_steps=8)
+    scales_before = [c.scale.clone() for op in graph.operations.values() for c, v in op.config_with_variable
+                     if c.state.value == 4]
+    pre, post = LearnedStepSizePass(steps=60, lr=1e-3).optimize(graph, batches, ex)
+    assert pre > 0 and post <= pre
+    scales_after = [c.scale for op in graph.operations.values() for c, v in op.config_with_variable if c.state.value == 4]
+    if post < pre:
+        assert any(not torch.equal(a, b) for a, b in zip(scales_before, scales_after))
+    assert not ex._delegates
