@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libppq_hip.so')
+# PPQHIP_LIBRARY: developer override used by tools/variants.sh to A/B kernel builds on the GPU box
+LIB_PATH = os.environ.get('PPQHIP_LIBRARY') or os.path.join(_HERE, 'libppq_hip.so')
 
 c_f32p = ctypes.c_void_p     # device pointers travel as integers (tensor.data_ptr())
 c_i32p = ctypes.c_void_p

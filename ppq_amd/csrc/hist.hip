@@ -30,7 +30,10 @@ namespace ppqhip {
 
 constexpr int kMaxLdsBins = 16384;     // 64 KiB of int32 per copy at most
 constexpr int kLdsBudgetInts = 8192;   // target: copies * bins <= 8192 ints (32 KiB) per workgroup
-constexpr int kHistUBig = 4;           // float4 loads in flight per lane (large tensors)
+#ifndef PPQHIP_HIST_UBIG
+#define PPQHIP_HIST_UBIG 2   // sweep on MI355X (tools/variants.sh): 2 > 3 > 4 > 1 > 8 with the ping-pong loop
+#endif
+constexpr int kHistUBig = PPQHIP_HIST_UBIG;           // float4 loads in flight per lane (large tensors)
 constexpr int kHistUSmall = 1;         // small tensors: less code to fetch, more workgroups
 constexpr int kHistMaxBlock = 1024;    // histogram workgroups: 256 .. 1024 threads (runtime)
 constexpr int kTrash = 64;             // per-lane trash slots behind every histogram copy
@@ -96,6 +99,9 @@ struct WaveAcc {
         return b > last ? last : b;
     }
 
+    // (tried: counting hits with ballot + s_bcnt1, v_cvt_flr_i32_f32 for floor+convert, +inf padding
+    //  instead of the `in` select -- each within noise or slower on MI355X, and v_cvt_flr mis-bins
+    //  negative denormals; the kernel is not VALU-count bound.)
     __device__ __forceinline__ void commit(int slot) {
         if (HOT) {
             const bool hit = slot == hot_bin;
@@ -117,7 +123,7 @@ struct WaveAcc {
             if (!sw) tw = aw / hs;
         }
         int bx = slot_of(tx), by = slot_of(ty), bz = slot_of(tz), bw = slot_of(tw);
-        if (!in) { bx = trash; by = trash; bz = trash; bw = trash; }
+        if (!in) { bx = trash; by = trash; bz = trash; bw = trash; }   // CLIP: padded with +inf
         commit(bx); commit(by); commit(bz); commit(bw);
     }
 
@@ -221,35 +227,45 @@ __device__ __forceinline__ void hist_stream(const float* __restrict__ x, uint32_
     const uint32_t trips = ((nvec + tile - 1) / tile + gridDim.x - 1) / gridDim.x;
     const uint32_t hi = min((blockIdx.x + 1) * trips * tile, nvec);
     uint32_t v = blockIdx.x * trips * tile + threadIdx.x;
-    float4 cur[kHistU], nxt[kHistU];
+    const uint32_t last_v = nvec ? nvec - 1 : 0u;
+    float4 bufa[kHistU], bufb[kHistU];
+    auto fetch = [&](float4 (&buf)[kHistU], uint32_t at) {
+        // branch-free: out-of-range lanes re-read the tensor's last float4 (their values are ignored
+        // through `in`), so the loads stay straight-line code and remain in flight while the
+        // previous tile is binned -- a conditional load costs a branch and an immediate vmcnt(0).
 #pragma unroll
-    for (int k = 0; k < kHistU; k++)
-        cur[k] = (v + k * bd < hi) ? load4<NT>(&xv[v + k * bd]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < kHistU; k++) buf[k] = load4<NT>(&xv[min(at + k * bd, last_v)]);
+    };
+    if (trips) fetch(bufa, v);
     const int pitch = rule.bins + kTrash;
     lds_hist_zero(lds, copies * pitch);          // first trip's loads are in flight meanwhile
     WaveAcc<ASYM, CLIP, HOT> acc;
     acc.init(lds + ((threadIdx.x >> 6) % copies) * pitch, rule);
-    for (uint32_t t = 0; t < trips; t++, v += tile) {
-        const uint32_t vn = v + tile;
-#pragma unroll
-        for (int k = 0; k < kHistU; k++)
-            nxt[k] = (vn + k * bd < hi) ? load4<NT>(&xv[vn + k * bd]) : make_float4(0.f, 0.f, 0.f, 0.f);
-        acc.elect(cur[0].x, v < hi);
+    auto consume = [&](const float4 (&buf)[kHistU], uint32_t at) {
+        acc.elect(buf[0].x, at < hi);
 #pragma unroll
         for (int k = 0; k < kHistU; k++) {
-            const bool in = v + k * bd < hi;
+            const bool in = at + k * bd < hi;
             if (FQ && in) {
                 float4 r;
-                r.x = fq_linear_scalar<R>(cur[k].x, s, o, qmin, qmax, rounding);
-                r.y = fq_linear_scalar<R>(cur[k].y, s, o, qmin, qmax, rounding);
-                r.z = fq_linear_scalar<R>(cur[k].z, s, o, qmin, qmax, rounding);
-                r.w = fq_linear_scalar<R>(cur[k].w, s, o, qmin, qmax, rounding);
-                ov[v + k * bd] = r;
+                r.x = fq_linear_scalar<R>(buf[k].x, s, o, qmin, qmax, rounding);
+                r.y = fq_linear_scalar<R>(buf[k].y, s, o, qmin, qmax, rounding);
+                r.z = fq_linear_scalar<R>(buf[k].z, s, o, qmin, qmax, rounding);
+                r.w = fq_linear_scalar<R>(buf[k].w, s, o, qmin, qmax, rounding);
+                ov[at + k * bd] = r;
             }
-            acc.add4(cur[k], in);
+            acc.add4(buf[k], in);
         }
-#pragma unroll
-        for (int k = 0; k < kHistU; k++) cur[k] = nxt[k];
+    };
+    // two trips per iteration, ping-ponging between the register tiles (no tile-sized copy); the
+    // next tile's loads are issued before the current tile is binned.
+    for (uint32_t t = 0; t < trips; t += 2, v += 2 * tile) {
+        fetch(bufb, v + tile);
+        consume(bufa, v);
+        if (t + 1 < trips) {
+            fetch(bufa, v + 2 * tile);
+            consume(bufb, v + tile);
+        }
     }
     {   // scalar remainder (the whole tensor when it is not 16-B aligned)
         const uint32_t done = nvec << 2;

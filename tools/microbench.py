@@ -25,6 +25,8 @@ def timeit(fn, iters=50, warmup=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--relu', action='store_true')
+    ap.add_argument('--dist', default='randn', choices=['randn', 'uniform', 'lanes', 'outliers'],
+                    help='input distribution: lanes = every lane of a wave hits its own bin (no LDS conflicts)')
     ap.add_argument('--bins', type=int, default=2048)
     ap.add_argument('--only', type=str, default='')
     ap.add_argument('--rotate', type=int, default=1, help='cycle through this many distinct input tensors (defeats the 256 MiB Infinity Cache)')
@@ -37,6 +39,13 @@ def main():
     for name, shp in shapes.items():
         if name not in args.tensors.split(','): continue
         xs = [torch.randn(*shp, device=dev) for _ in range(args.rotate)]
+        if args.dist == 'uniform': xs = [torch.rand(*shp, device=dev) * 2 - 1 for _ in range(args.rotate)]
+        if args.dist == 'outliers': xs = [t * (1 + 50 * (torch.rand_like(t) < 1e-5)) for t in xs]
+        if args.dist == 'lanes':
+            nn = xs[0].numel()
+            base = ((torch.arange(nn, device=dev) // 4) % 64).float() + 0.5
+            xs = [(base / 64.0).reshape(shp) * (1 - 1e-3 * k) for k in range(args.rotate)]
+            xs[0].view(-1)[0] = float(args.bins) / 64.0   # abs max -> hist_scale = 1/64, bin = lane
         if args.relu: xs = [torch.relu(t) for t in xs]
         x = xs[0]
         counter = [0]
