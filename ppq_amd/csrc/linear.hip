@@ -34,7 +34,7 @@ __global__ __launch_bounds__(kBlock) void fq_linear_t_tile_kernel(
     float4 a[U];
 #pragma unroll
     for (int k = 0; k < U; k++)
-        if (base + k * kBlock < nvec) a[k] = load4<NT>(&x[base + k * kBlock]);
+        a[k] = load4<NT>(&x[min(base + k * kBlock, nvec - 1)]);   // branch-free (clamped) so all U loads issue back to back
 #pragma unroll
     for (int k = 0; k < U; k++) {
         if (base + k * kBlock < nvec) {
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(kBlock) void fq_linear_c_tile_kernel(
     int o[U];
 #pragma unroll
     for (int k = 0; k < U; k++) {
-        const uint32_t vv = base + k * kBlock;
-        if (vv < nvec) {
+        const uint32_t vv = min(base + k * kBlock, nvec - 1);      // clamped: branch-free loads
+        {
             a[k] = load4<NT>(&x[vv]);
             const uint32_t row = fdiv(vv, vec_per_channel);
             const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
