@@ -121,7 +121,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--backend', type=str, default='nccl')
     ap.add_argument('--single-device', type=int, default=0, help='debug: put every rank on cuda:0 (use with --backend gloo)')
-    ap.add_argument('--hip-graph', type=int, default=0, help='capture each phase forward into a HIP graph')
+    ap.add_argument('--hip-graph', default='auto', choices=['0', '1', 'auto'],
+                    help="replay each phase's forward as a HIP graph: never / always / when one timed eager step is launch-bound")
     ap.add_argument('--async-observe', type=int, default=0, help='observer kernels on a side HIP stream')
     ap.add_argument('--cache-params', type=int, default=0, help='keep fake-quantised weights resident between forwards')
     ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
@@ -147,7 +148,7 @@ def main():
     graph, ex = build_workload(dev, args.bins, args.method, args.cache_params)
     barrier(world)
     t0 = time.perf_counter()
-    p = run_pass(graph, ex, batches, args.steps, args.method, bool(args.async_observe), bool(args.hip_graph))
+    p = run_pass(graph, ex, batches, args.steps, args.method, bool(args.async_observe), {'0': False, '1': True, 'auto': 'auto'}[args.hip_graph])
     barrier(world)
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -208,7 +209,9 @@ def main():
                        'samples': samples, 'batch': args.batch, 'observed_tensors': n_obs,
                        'parallelism': f'dp{world} (batches sharded, 1 all-reduce per phase)',
                        'async_observe': bool(args.async_observe), 'cache_params': bool(args.cache_params),
-                       'hip_graph': bool(args.hip_graph), 'graph_replays': p.graph_replays},
+                       'hip_graph': args.hip_graph, 'graph_replays': p.graph_replays,
+                       'graph_decisions': [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()}
+                                           for d in p.graph_decisions]},
             'roofline': roof, 'cpu_baseline': cpu,
             'kernels': [{'name': r['name'], 'launches': r['launches'], 'total_ms': round(r['total_ms'], 3),
                          'GBps': round(r['total_bytes'] / max(r['total_ms'], 1e-9) / 1e6, 1)} for r in prof_rows],

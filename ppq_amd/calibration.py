@@ -17,6 +17,7 @@ MI355X-first differences (results unchanged):
   merged by :func:`ppq_amd.distributed.merge_observers` -- ONE flat all-reduce per reduction kind
   and phase -- before rendering, so every rank renders identical scales.
 """
+import time
 from math import ceil
 from typing import Callable, Dict, Iterable, List
 
@@ -41,6 +42,11 @@ class QuantizationOptimizationPass:
 
 
 class RuntimeCalibrationPass(QuantizationOptimizationPass):
+    # use_hip_graph='auto' captures a phase when enqueueing a step takes more than this fraction of
+    # its synchronised wall time and at least this many steps remain to amortise capture + instantiate
+    AUTO_GRAPH_ISSUE_FRACTION = 0.7
+    AUTO_GRAPH_MIN_STEPS = 12
+
     def __init__(self, method: str = None, override: bool = False, calib_steps: int = 32,
                  process_group=None, check_steps: bool = True, async_observe: bool = False,
                  use_hip_graph: bool = False) -> None:
@@ -55,6 +61,7 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         self._async_observe = async_observe
         self._use_hip_graph = use_hip_graph
         self.graph_replays = 0
+        self.graph_decisions = []      # use_hip_graph='auto': one record per phase
         self._side_stream = None
 
     def _batches(self, dataloader: Iterable) -> list:
@@ -73,7 +80,7 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         same-shaped CUDA batches and observers whose whole state lives in device buffers."""
         import torch
         from .observer import ConstantObserver, TorchHistObserver, TorchMinMaxObserver, TorchMSEObserver
-        if not self._use_hip_graph or len(batches) < 3: return False
+        if not self._use_hip_graph or len(batches) < 4: return False
         if not all(isinstance(b, torch.Tensor) and b.is_cuda and b.shape == batches[0].shape
                    and b.dtype == batches[0].dtype for b in batches): return False
         safe = (TorchMinMaxObserver, TorchHistObserver, TorchMSEObserver, ConstantObserver)
@@ -87,9 +94,11 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         observer kernels, incl. the side-stream fork) is captured ONCE per phase into a HIP graph and
         replayed for the remaining batches, which takes the Python / launch overhead off the critical
         path.  Batch 0 runs eagerly (it allocates the observer buffers and lets MIOpen pick its
-        kernels), batch 1 is captured, batches 1.. replay.  Measured on MI355X (ResNet-50, batch 32) the
-        eager loop is already GPU-bound, and capture + instantiation of ~3500 nodes costs more than it
-        saves below ~100 steps, so this is off by default."""
+        kernels), then the step is captured and the remaining batches replay.  Measured on MI355X
+        (ResNet-50, 256 samples): batch 1 x 256 steps 127 -> 326 samples/s, batch 8 x 32 steps
+        973 -> 1385, batch 32 x 8 steps: the eager loop is already GPU-bound and capture costs more
+        than it saves.  ``use_hip_graph='auto'`` therefore times one eager step and captures only
+        when the loop is launch-bound."""
         import torch
         batches = self._batches(dataloader)
         if not self._graph_replayable(batches, hooks):
@@ -97,6 +106,26 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
                 executor.forward(inputs=data, hooks=hooks, output_names=output_names)
             return
         executor.forward(inputs=batches[0], hooks=hooks, output_names=output_names)
+        first = 1
+        if self._use_hip_graph == 'auto':
+            # Is this loop launch-bound?  Time batch 1: `issue` = host time to enqueue the step,
+            # `total` = until the GPU has drained it.  A GPU-bound step leaves the host waiting
+            # (issue << total) and a graph cannot help; a launch-bound one (small batches: hundreds
+            # of microsecond kernels) keeps the GPU idle between launches (issue ~ total).
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            executor.forward(inputs=batches[1], hooks=hooks, output_names=output_names)
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            first = 2
+            launch_bound = (t1 - t0) > self.AUTO_GRAPH_ISSUE_FRACTION * (t2 - t0)
+            self.graph_decisions.append({'phase': desc, 'issue_ms': (t1 - t0) * 1e3, 'total_ms': (t2 - t0) * 1e3,
+                                         'graph': bool(launch_bound and len(batches) - first >= self.AUTO_GRAPH_MIN_STEPS)})
+            if not self.graph_decisions[-1]['graph']:
+                for data in batches[first:]:
+                    executor.forward(inputs=data, hooks=hooks, output_names=output_names)
+                return
         static_in = torch.empty_like(batches[0])
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
@@ -104,7 +133,7 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
             executor.forward(inputs=static_in, hooks=hooks, output_names=output_names)
             if self._side_stream is not None:
                 torch.cuda.current_stream().wait_stream(self._side_stream)
-        for data in batches[1:]:
+        for data in batches[first:]:
             static_in.copy_(data, non_blocking=True)
             graph.replay()
             self.graph_replays += 1

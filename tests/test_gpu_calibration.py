@@ -319,6 +319,34 @@ def test_graph_and_async_modes_equal_eager(mode):
     assert (p.graph_replays == 14) == ('graph' in mode)                   # 7 replays per phase
 
 
+def test_auto_graph_mode_equals_eager():
+    """use_hip_graph='auto' times one eager step per phase and captures only when launch-bound; either
+    way the scales equal the eager loop's.  The small CNN at batch 4 is launch-bound, so with the
+    minimum step count lowered both phases must choose the graph."""
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    g = torch.Generator().manual_seed(4)
+    batches = [torch.rand(4, 3, 24, 24, generator=g).to(DEV) for _ in range(10)]
+
+    def run(mode, min_steps):
+        graph = harness.small_cnn_graph(seed=3)
+        harness.quantize_graph(graph, 'kl', hist_bins=2048)
+        ex = harness.TorchExecutor(graph, DEV)
+        harness.ParameterQuantizePass().optimize(graph)
+        p = RuntimeCalibrationPass(method='kl', use_hip_graph=mode)
+        p.AUTO_GRAPH_MIN_STEPS = min_steps
+        p.optimize(graph, dataloader=batches, executor=ex, calib_steps=10)
+        torch.cuda.synchronize()
+        return p, [float(c.scale) for op in graph.operations.values() for c, v in op.config_with_variable
+                   if not v.is_parameter and c.state.value == 4]
+    _, eager = run(False, 12)
+    p, auto = run('auto', 4)
+    assert eager == auto and len(p.graph_decisions) == 2
+    assert all(d['graph'] for d in p.graph_decisions) and p.graph_replays == 16     # 8 replays per phase
+    p, auto = run('auto', 12)                                                      # too few steps left: eager
+    assert eager == auto and p.graph_replays == 0 and not any(d['graph'] for d in p.graph_decisions)
+
+
 def test_lsq_autograd_functions():
     """CuLSQ_LT / CuLSQ_LC (training.py:17-90): forward == fake quant, backward == the _B kernels,
     checked against the torch formula of tests/test_cuda_kernel.py:67-78 (grad_x exact)."""
