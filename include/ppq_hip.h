@@ -138,6 +138,12 @@ int ppqhip_minmax_t(const float* x, int64_t n, float* minmax, void* workspace, v
 int ppqhip_minmax_c(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
                     float* mins, float* maxs, void* stream);
 
+/* per-channel sums in double, deterministic order: sums[c] += sum of channel c.  The DC term of
+ * BiasCorrectionPass.collect_bias (ppq/quantization/optim/training.py:438-448: torch.mean over
+ * every dim but the channel one); the caller divides by n / num_channel. */
+int ppqhip_channel_sum(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
+                       double* sums, void* stream);
+
 /* persistent accumulators for repeated observation (MI355X-native; no twin in the reference) -----
  * An observer that sees many batches keeps one accumulator ROW per workgroup resident in HBM:
  *   rows  : int32 [ppqhip_hist_rows()][num_bins], zero-initialised by the caller

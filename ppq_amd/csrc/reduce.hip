@@ -137,6 +137,71 @@ __global__ __launch_bounds__(kBlock) void minmax_c_generic_kernel(const float* _
     }
 }
 
+// ------------------------------------------------------------------------------------ channel sums
+// sums[c] (+)= sum over every element of channel c, accumulated in DOUBLE and reduced in a fixed
+// order (deterministic, no atomics): the per-channel DC term of BiasCorrectionPass
+// (ppq/quantization/optim/training.py:438-448, torch.mean over all dims but the channel one).
+//   long rows  (epc >= 64): grid = (C, S); workgroup (c, s) walks rows n = s, s + S, ... of channel c
+//                           with 16-B loads, block-reduces and stores partial[s][c]; the finish
+//                           kernel adds the S partials of a channel in index order.
+//   short rows (Gemm [N, C], channel-last ...): one thread per channel, strided rows.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kBlock) void channel_sum_row_kernel(const float* __restrict__ x, uint32_t rows_per_channel,
+                                                                 uint32_t C, uint32_t epc, int vec_ok,
+                                                                 double* __restrict__ partial) {
+    __shared__ double lds[kBlock / kWave];
+    const uint32_t c = blockIdx.x, s = blockIdx.y, S = gridDim.y;
+    double acc = 0.0;
+    for (uint32_t n = s; n < rows_per_channel; n += S) {
+        const float* xr = x + ((size_t)n * C + c) * epc;
+        if (vec_ok) {
+            const float4* xv = reinterpret_cast<const float4*>(xr);
+            for (uint32_t v = threadIdx.x; v < (epc >> 2); v += kBlock) {
+                const float4 a = xv[v];
+                acc += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+            }
+        } else {
+            for (uint32_t j = threadIdx.x; j < epc; j += kBlock) acc += (double)xr[j];
+        }
+    }
+    acc = wave_sum_f64(acc);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) lds[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = lds[0];
+        for (int w = 1; w < kBlock / kWave; w++) t += lds[w];
+        partial[(size_t)s * C + c] = t;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void channel_sum_finish_kernel(const double* __restrict__ partial, uint32_t S,
+                                                                    uint32_t C, double* __restrict__ sums) {
+    const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= C) return;
+    double t = 0.0;
+    for (uint32_t s = 0; s < S; s++) t += partial[(size_t)s * C + c];
+    sums[c] += t;
+}
+
+__global__ __launch_bounds__(kBlock) void channel_sum_generic_kernel(const float* __restrict__ x, uint32_t outer,
+                                                                     uint32_t C, uint32_t epc,
+                                                                     double* __restrict__ sums) {
+    const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
+    if (c >= C) return;
+    double t = 0.0;
+    for (uint32_t n = 0; n < outer; n++) {
+        const float* xr = x + ((size_t)n * C + c) * epc;
+        for (uint32_t j = 0; j < epc; j++) t += (double)xr[j];
+    }
+    sums[c] += t;
+}
+
 // ------------------------------------------------------------------------------------ quantile
 // order-preserving key: ascending uint32 order == ascending float order
 __device__ __forceinline__ uint32_t f2key(float f) {
@@ -449,6 +514,33 @@ int ppqhip_minmax_c(const float* x, int64_t n, int64_t num_channel, int64_t elem
                            s, x, (uint32_t)n, make_fastdiv((uint32_t)elem_per_channel), nc, use_lds, mins, maxs);
     }
     return finish_launch("minmax_c");
+}
+
+int ppqhip_channel_sum(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel, double* sums,
+                       void* stream) {
+    if (int st = validate(n, "channel_sum")) return st;
+    if (num_channel <= 0 || elem_per_channel <= 0 || n % (num_channel * elem_per_channel) != 0) {
+        set_error("channel_sum: bad channel geometry"); return PPQHIP_ERR_INVALID_VALUE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_CHANNEL_SUM, 4.0 * (double)n, s);
+    const uint32_t C = (uint32_t)num_channel, epc = (uint32_t)elem_per_channel;
+    const uint32_t outer = (uint32_t)(n / (num_channel * elem_per_channel));
+    if (epc >= 64) {
+        uint32_t S = (4 * kNumCU + C - 1) / C;            // >= 4 workgroups per CU in total
+        if (S > outer) S = outer;
+        if (S < 1) S = 1;
+        double* partial = (double*)scratch(s, sizeof(double) * (size_t)S * C);
+        if (partial == nullptr) return PPQHIP_ERR_HIP;
+        const int vec_ok = (aligned16(x) && epc % 4 == 0) ? 1 : 0;
+        hipLaunchKernelGGL(channel_sum_row_kernel, dim3(C, S), dim3(kBlock), 0, s, x, outer, C, epc, vec_ok, partial);
+        hipLaunchKernelGGL(channel_sum_finish_kernel, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, s, partial, S,
+                           C, sums);
+    } else {
+        hipLaunchKernelGGL(channel_sum_generic_kernel, dim3((C + kBlock - 1) / kBlock), dim3(kBlock), 0, s, x, outer,
+                           C, epc, sums);
+    }
+    return finish_launch("channel_sum");
 }
 
 int64_t ppqhip_quantile_workspace_bytes(int64_t n) {

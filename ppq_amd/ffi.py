@@ -419,6 +419,16 @@ class _HipExtension:
             _raise(lib.ppqhip_minmax_c(v.data_ptr(), v.numel(), C, epc, mins.data_ptr(), maxs.data_ptr(), _stream()))
 
     @ staticmethod
+    def ChannelSum(value, channel_axis: int, sums) -> None:
+        """sums (float64 [C]) += per-channel sum of value; deterministic double accumulation."""
+        _f32(value, 'Value'); _check(sums, torch.float64, 'Sums(Expect to be FP64)')
+        v = value.contiguous()
+        C, epc = _geometry(v.shape, channel_axis)
+        if sums.numel() != C: raise RuntimeError(_KERNEL_FAILURE + f'sums needs {C} elements')
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_channel_sum(v.data_ptr(), v.numel(), C, epc, sums.data_ptr(), _stream()))
+
+    @ staticmethod
     def KL_Losses(hist, num_of_bits: int) -> torch.Tensor:
         """hist: int32 [num_hist, bins] (or [bins]) -> float64 [num_hist, candidates]."""
         _check(hist, torch.int32, 'Histogram(Expect to be INT32)')
@@ -601,6 +611,20 @@ class CUDA:
     def MinMax_C(tensor, channel_axis: int, mins, maxs):
         HIP_EXTENSION.MinMax_C(tensor, channel_axis, mins, maxs)
         return mins, maxs
+
+    @ staticmethod
+    def ChannelSum(tensor, channel_axis: int, sums):
+        HIP_EXTENSION.ChannelSum(tensor, channel_axis % tensor.ndim, sums)
+        return sums
+
+    @ staticmethod
+    def ChannelMean(tensor, channel_axis: int) -> torch.Tensor:
+        """float32 [C]: mean over every dim but channel_axis -- collect_bias of BiasCorrectionPass
+        (ppq/quantization/optim/training.py:438-448) without the reduce-over-dims temporaries."""
+        axis = channel_axis % tensor.ndim
+        sums = torch.zeros(tensor.shape[axis], dtype=torch.float64, device=tensor.device)
+        HIP_EXTENSION.ChannelSum(tensor, axis, sums)
+        return (sums / (tensor.numel() // tensor.shape[axis])).to(torch.float32)
 
     # persistent accumulators (one row / slot per workgroup, folded on demand) ---------------------
     @ staticmethod

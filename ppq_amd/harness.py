@@ -79,6 +79,23 @@ class QuantableOperation(Operation):
         return list(zip(self.config.input_quantization_config, self.inputs)) + \
             list(zip(self.config.output_quantization_config, self.outputs))
 
+    def dequantize(self):
+        """ppq/IR/quantize.py:124-141 (state part): park every config in FP32, remembering its state."""
+        if getattr(self, '_dequantized', False): return self
+        for cfg, _ in self.config_with_variable:
+            cfg.detail['Stored State'] = cfg.state
+            cfg.state = QuantizationStates.FP32
+        self._dequantized = True
+        return self
+
+    def restore_quantize_state(self):
+        """ppq/IR/quantize.py:143-160."""
+        if not getattr(self, '_dequantized', False): return self
+        for cfg, _ in self.config_with_variable:
+            if 'Stored State' in cfg.detail: cfg.state = cfg.detail.pop('Stored State')
+        self._dequantized = False
+        return self
+
     def baking_parameters(self, quant_func: Callable):
         """IR/quantize.py:98-111."""
         for config, var in self.config_with_variable:
@@ -159,6 +176,33 @@ class TorchExecutor:
     def forward_with_gradient(self, inputs, output_names: List[str] = None, hooks=None):
         """torch.py:412-455: the same loop with autograd enabled (finetuning passes)."""
         return TorchExecutor.forward.__wrapped__(self, inputs, output_names, hooks)
+
+    @ torch.no_grad()
+    def partial_graph_forward(self, operations: List[Operation], feed_dict: Dict[str, torch.Tensor],
+                              output_names: List[str]) -> List[torch.Tensor]:
+        """ppq/executor/torch.py:654-730: run only `operations` (already in execution order) on the
+        given feeds -- the block forward of the training based passes."""
+        g = self._graph
+        for name, value in feed_dict.items(): g.variables[name].value = value.to(self._device)
+        results = [None] * len(output_names)
+        for op in operations:
+            raw_in = [v.value for v in op.inputs]
+            if any(x is None for x in raw_in):
+                raise ValueError(f'partial_graph_forward: input of {op.name} was not fed')
+            if isinstance(op, QuantableOperation):
+                qin = [self._quantize_parameter(v, c) if v.is_parameter else self.quantize_function(x, c)
+                       for v, x, c in zip(op.inputs, raw_in, op.config.input_quantization_config)]
+            else: qin = raw_in
+            outs = _forward(op, qin)
+            outs = list(outs) if isinstance(outs, (list, tuple)) else [outs]
+            if isinstance(op, QuantableOperation):
+                outs = [self.quantize_function(y, c) for y, c in zip(outs, op.config.output_quantization_config)]
+            for v, y in zip(op.outputs, outs):
+                v.value = y
+                if v.name in output_names: results[output_names.index(v.name)] = y
+        for v in g.variables.values():
+            if not v.is_parameter: v.value = None
+        return results
 
     def _quantize_parameter(self, var: Variable, config) -> torch.Tensor:
         """A parameter and its scale do not change between calibration forwards, so its fake-quantised

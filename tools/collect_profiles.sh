@@ -11,15 +11,15 @@ rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 B="python $R/bench.py --no-cpu-baseline"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- $B > $O/bench_trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o bench -- $B > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/write -o bench -- $B > /dev/null 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/trace -o bench -- $B > $O/bench_trace.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o bench -- $B > /dev/null 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $O/write -o bench -- $B > /dev/null 2>&1
 cd $R
 python tools/microbench.py --tensors A,B,Bx8,Bx32 --rotate 4 > $O/microbench_randn_rot4.txt 2>&1
 python tools/microbench.py --tensors B,Bx32 --rotate 4 --relu > $O/microbench_relu_rot4.txt 2>&1
 python tools/microbench.py --tensors A,B --rotate 1 > $O/microbench_randn_cached.txt 2>&1
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/micro_trace -o micro -- python $R/tools/microbench.py --tensors B,Bx32 --rotate 4 > /dev/null 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/micro_trace -o micro -- python $R/tools/microbench.py --tensors B,Bx32 --rotate 4 > /dev/null 2>&1
 cd $R
 # keep the merge-back small: only the CSV summaries
 find $O -name "*.db" -delete 2>/dev/null
