@@ -227,6 +227,9 @@ typedef struct {
 } ppqhip_prof_entry;
 int ppqhip_prof_enable(int on);
 int ppqhip_prof_collect(ppqhip_prof_entry* entries, int max_entries); /* returns #entries */
+/* average elapsed microseconds of `pairs` EMPTY event pairs on `stream` (the bracketing overhead
+ * included in every total_ms above); negative on failure. */
+double ppqhip_prof_event_overhead_us(void* stream, int pairs);
 
 #ifdef __cplusplus
 }

@@ -73,6 +73,7 @@ PROTOTYPES = {
                                             c_i32p, c_i64, c_vp, c_vp]),
     'ppqhip_prof_enable': (c_int, [c_int]),
     'ppqhip_prof_collect': (c_int, [ctypes.POINTER(ProfEntry), c_int]),
+    'ppqhip_prof_event_overhead_us': (ctypes.c_double, [c_vp, c_int]),
 }
 
 if not os.path.exists(LIB_PATH):

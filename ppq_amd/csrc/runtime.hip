@@ -113,6 +113,28 @@ int ppqhip_prof_enable(int on) {
     return PPQHIP_OK;
 }
 
+double ppqhip_prof_event_overhead_us(void* stream, int pairs) {
+    // elapsed time of an EMPTY start/stop event pair on this stream: what a bracketed launch reports
+    // on top of the kernel's own begin->end duration (timestamp writes by the command processor).
+    hipStream_t s = (hipStream_t)stream;
+    if (pairs < 1) pairs = 1;
+    std::vector<hipEvent_t> ev(2 * (size_t)pairs);
+    for (auto& e : ev) if (hipEventCreate(&e) != hipSuccess) return -1.0;
+    for (int i = 0; i < pairs; i++) {
+        (void)hipEventRecord(ev[2 * i], s);
+        (void)hipEventRecord(ev[2 * i + 1], s);
+    }
+    (void)hipStreamSynchronize(s);
+    double total = 0.0;
+    for (int i = 0; i < pairs; i++) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]);
+        total += ms;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return total * 1e3 / pairs;
+}
+
 int ppqhip_prof_collect(ppqhip_prof_entry* entries, int max_entries) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ppqhip_prof_entry agg[K_NUM];
