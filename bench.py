@@ -51,19 +51,39 @@ def barrier(world):
     torch.cuda.synchronize()
 
 
-def build_workload(dev, bins, method, cache_params=False):
+TRACE_STEPS = None
+
+
+def build_workload(dev, bins, method, cache_params=False, fuse_params=True):
     from ppq_amd import harness
     graph = harness.resnet50_graph(seed=0)
     harness.quantize_graph(graph, method, hist_bins=bins)
     ex = harness.TorchExecutor(graph, dev)
     ex.cache_parameter_quantization = bool(cache_params)
+    ex.fuse_parameter_quantization = bool(fuse_params)
     harness.ParameterQuantizePass().optimize(graph)        # weights: per-channel min-max, left ACTIVATED
     return graph, ex
 
 
-def run_pass(graph, ex, batches, steps, method, async_observe=False, hip_graph=False):
+def run_pass(graph, ex, batches, steps, method, async_observe=False, hip_graph=False, batch_observations=True):
     from ppq_amd.calibration import RuntimeCalibrationPass
-    p = RuntimeCalibrationPass(method=method, check_steps=False, async_observe=async_observe, use_hip_graph=hip_graph)
+    p = RuntimeCalibrationPass(method=method, check_steps=False, async_observe=async_observe, use_hip_graph=hip_graph,
+                               batch_observations=batch_observations)
+    if TRACE_STEPS is not None:          # --trace-steps: host timestamp + device event after every forward
+        inner = p._forward
+
+        def traced(executor, data, hooks, output_names):
+            inner(executor, data, hooks, output_names)
+            ev = torch.cuda.Event(enable_timing=True); ev.record()
+            TRACE_STEPS.append((time.perf_counter(), ev))
+        p._forward = traced
+        inner_render = p._render
+
+        def traced_render():
+            torch.cuda.synchronize(); a = time.perf_counter()
+            inner_render()
+            torch.cuda.synchronize(); TRACE_STEPS.append((a, time.perf_counter()))
+        p._render = traced_render
     p.optimize(graph, dataloader=batches, executor=ex, calib_steps=steps)
     return p
 
@@ -124,6 +144,9 @@ def main():
     ap.add_argument('--hip-graph', default='auto', choices=['0', '1', 'auto'],
                     help="replay each phase's forward as a HIP graph: never / always / when one timed eager step is launch-bound")
     ap.add_argument('--async-observe', type=int, default=0, help='observer kernels on a side HIP stream')
+    ap.add_argument('--fuse-params', type=int, default=1, help='all weights of a forward fake-quantised by one multi-tensor launch')
+    ap.add_argument('--batch-observations', type=int, default=1, help='all statistics kernels of a forward in one multi-tensor launch')
+    ap.add_argument('--trace-steps', type=int, default=0, help='debug: per-forward host / device timestamps in the JSON line')
     ap.add_argument('--cache-params', type=int, default=0, help='keep fake-quantised weights resident between forwards')
     ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
     args = ap.parse_args()
@@ -139,18 +162,29 @@ def main():
 
     # warm-up: W batches through a complete two-phase pass (MIOpen find, library load, allocator)
     if args.warmup > 0:
-        graph, ex = build_workload(dev, args.bins, args.method, args.cache_params)
+        graph, ex = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params)
         run_pass(graph, ex, batches[: max(1, min(args.warmup, args.steps))], max(1, min(args.warmup, args.steps)), args.method,
-                 bool(args.async_observe), False)
+                 bool(args.async_observe), False, bool(args.batch_observations))
         del graph, ex
 
     # timed region
-    graph, ex = build_workload(dev, args.bins, args.method, args.cache_params)
+    global TRACE_STEPS
+    if args.trace_steps:
+        TRACE_STEPS = []
+        ev0 = torch.cuda.Event(enable_timing=True)
+    graph, ex = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params)
     barrier(world)
     t0 = time.perf_counter()
-    p = run_pass(graph, ex, batches, args.steps, args.method, bool(args.async_observe), {'0': False, '1': True, 'auto': 'auto'}[args.hip_graph])
+    if args.trace_steps: ev0.record()
+    p = run_pass(graph, ex, batches, args.steps, args.method, bool(args.async_observe), {'0': False, '1': True, 'auto': 'auto'}[args.hip_graph],
+                 bool(args.batch_observations))
     barrier(world)
     elapsed = time.perf_counter() - t0
+    trace = None
+    if args.trace_steps:
+        trace = [{'host_ms': round((t - t0) * 1e3, 2), 'dev_ms': round(ev0.elapsed_time(e), 2)} if not isinstance(e, float)
+                 else {'render_start_ms': round((t - t0) * 1e3, 2), 'render_ms': round((e - t) * 1e3, 2)} for t, e in TRACE_STEPS]
+        TRACE_STEPS = None
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -165,11 +199,11 @@ def main():
     roof = None
     prof_rows = []
     if rank == 0:
-        graph2, ex2 = build_workload(dev, args.bins, args.method, args.cache_params)
+        graph2, ex2 = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params)
         torch.cuda.synchronize()
         _lib.lib.ppqhip_prof_enable(1)
         if world == 1:
-            run_pass(graph2, ex2, batches, args.steps, args.method, False, False)   # eager, one stream -> clean event pairs
+            run_pass(graph2, ex2, batches, args.steps, args.method, False, False, bool(args.batch_observations))   # eager, one stream -> clean event pairs
         else:   # collectives need every rank; profile the local (non-merged) statistics path only
             from ppq_amd.calibration import RuntimeCalibrationPass
             pp = RuntimeCalibrationPass(method=args.method, check_steps=False, async_observe=False, use_hip_graph=False)
@@ -217,6 +251,7 @@ def main():
                        'samples': samples, 'batch': args.batch, 'observed_tensors': n_obs,
                        'parallelism': f'dp{world} (batches sharded, 1 all-reduce per phase)',
                        'async_observe': bool(args.async_observe), 'cache_params': bool(args.cache_params),
+                       'fuse_params': bool(args.fuse_params), 'batch_observations': bool(args.batch_observations),
                        'hip_graph': args.hip_graph, 'graph_replays': p.graph_replays,
                        'graph_decisions': [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()}
                                            for d in p.graph_decisions]},
@@ -225,6 +260,7 @@ def main():
                          'GBps': round(r['total_bytes'] / max(r['total_ms'], 1e-9) / 1e6, 1)} for r in prof_rows],
             'scale_checksum': scale_checksum,
         }
+        if trace is not None: out['trace_steps'] = trace
         print(json.dumps(out), flush=True)
     if world > 1:
         import torch.distributed as dist

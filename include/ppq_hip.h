@@ -56,6 +56,24 @@ int ppqhip_fq_linear_c(const float* x, const float* scale, const float* offset, 
                        int64_t n, int64_t num_channel, int64_t elem_per_channel,
                        int clip_min, int clip_max, int rounding, void* stream);
 
+/* many tensors, one launch (MI355X-native addition): every job is fake-quantised exactly as
+ * ppqhip_fq_linear_c would (a per-tensor job has num_channel = 1, elem_per_channel = n).  Meant for the
+ * weights of a graph, which the executor re-quantises on every forward: `jobs` is a HOST array;
+ * `device_table` is caller-owned device memory of ppqhip_fq_linear_multi_table_bytes(num_jobs) bytes
+ * that holds the converted job table -- pass upload = 1 on the first call and whenever a pointer or
+ * shape in `jobs` changed, 0 otherwise (no host-to-device traffic on the steady path). */
+typedef struct ppqhip_fq_job {
+    const float* x;
+    const float* scale;
+    const float* offset;
+    float* out;
+    int64_t n, num_channel, elem_per_channel;
+    int32_t clip_min, clip_max;
+} ppqhip_fq_job;
+int64_t ppqhip_fq_linear_multi_table_bytes(int num_jobs);
+int ppqhip_fq_linear_multi(const ppqhip_fq_job* jobs, int num_jobs, int rounding, void* device_table,
+                           int upload, void* stream);
+
 /* replaces QuantizeTensor_LT_B, linear.cu:284-324 (CUDA.LinearQuantize_T_B ffi.py:105-118).
  * grad_s (1 elem) is OVERWRITTEN with sum(...) * rsqrt(n * (clip_max - clip_min)). */
 int ppqhip_fq_linear_t_bwd(const float* x, const float* scale, const float* offset,
@@ -156,6 +174,27 @@ int ppqhip_hist_sym_t_rows(const float* x, int64_t n, float hist_scale, int clip
                            int32_t* rows, int64_t num_bins, void* stream);
 int ppqhip_hist_asym_t_rows(const float* x, int64_t n, float min_value, float max_value,
                             int clip_outliers, int32_t* rows, int64_t num_bins, void* stream);
+/* many tensors, one launch: job k folds its tensor into ITS OWN slots exactly as ppqhip_minmax_t_slots.
+ * `jobs` is a HOST array, copied into the kernel arguments. */
+typedef struct ppqhip_minmax_job {
+    const float* x;   /* device, n floats */
+    float* slots;     /* device, float [ppqhip_minmax_slots()][2] */
+    int64_t n;
+} ppqhip_minmax_job;
+int ppqhip_minmax_t_slots_multi(const ppqhip_minmax_job* jobs, int num_jobs, void* stream);
+
+/* many tensors, one launch: every job bins its tensor into ITS OWN rows buffer exactly as
+ * ppqhip_hist_sym_t_rows (asymmetric = 0: p0 = hist_scale) or ppqhip_hist_asym_t_rows
+ * (asymmetric = 1: p0 = min_value, p1 = max_value) would.  `jobs` is a HOST array; it is copied into
+ * the kernel arguments, so it may be reused as soon as the call returns. */
+typedef struct ppqhip_hist_job {
+    const float* x;   /* device, n floats */
+    int32_t* rows;    /* device, int32 [ppqhip_hist_rows()][num_bins] */
+    int64_t n;
+    float p0, p1;
+} ppqhip_hist_job;
+int ppqhip_hist_t_rows_multi(const ppqhip_hist_job* jobs, int num_jobs, int asymmetric,
+                             int clip_outliers, int64_t num_bins, void* stream);
 int ppqhip_hist_rows_finish(const int32_t* rows, int64_t num_bins, int32_t* hist, void* stream);
 int64_t ppqhip_minmax_slots(void);
 int ppqhip_minmax_t_slots(const float* x, int64_t n, float* slots, void* stream);

@@ -51,6 +51,10 @@ PROTOTYPES = {
     'ppqhip_minmax_workspace_bytes': (c_i64, [c_i64]),
     'ppqhip_minmax_t': (c_int, [c_f32p, c_i64, c_f32p, c_vp, c_vp]),
     'ppqhip_minmax_c': (c_int, [c_f32p, c_i64, c_i64, c_i64, c_f32p, c_f32p, c_vp]),
+    'ppqhip_fq_linear_multi_table_bytes': (c_i64, [c_int]),
+    'ppqhip_fq_linear_multi': (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_vp]),
+    'ppqhip_minmax_t_slots_multi': (c_int, [c_vp, c_int, c_vp]),
+    'ppqhip_hist_t_rows_multi': (c_int, [c_vp, c_int, c_int, c_int, c_i64, c_vp]),
     'ppqhip_channel_sum': (c_int, [c_f32p, c_i64, c_i64, c_i64, c_f64p, c_vp]),
     'ppqhip_hist_rows': (c_i64, []),
     'ppqhip_hist_sym_t_rows': (c_int, [c_f32p, c_i64, c_flt, c_int, c_i32p, c_i64, c_vp]),

@@ -49,7 +49,7 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
 
     def __init__(self, method: str = None, override: bool = False, calib_steps: int = 32,
                  process_group=None, check_steps: bool = True, async_observe: bool = False,
-                 use_hip_graph: bool = False) -> None:
+                 use_hip_graph: bool = False, batch_observations: bool = True) -> None:
         super().__init__(name='PPQ Runtime Calibration Pass')
         self._method = method
         self._observers: Dict[str, OperationObserver] = {}
@@ -60,6 +60,8 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         self._check_steps = check_steps
         self._async_observe = async_observe
         self._use_hip_graph = use_hip_graph
+        self._batch_observations = batch_observations
+        self._queue = None
         self.graph_replays = 0
         self.graph_decisions = []      # use_hip_graph='auto': one record per phase
         self._side_stream = None
@@ -86,6 +88,10 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         safe = (TorchMinMaxObserver, TorchHistObserver, TorchMSEObserver, ConstantObserver)
         return all(type(ob) in safe for hook in hooks.values() for ob in hook._observer_table.values())
 
+    def _forward(self, executor, data, hooks, output_names):
+        executor.forward(inputs=data, hooks=hooks, output_names=output_names)
+        if self._queue is not None: self._queue.flush()      # one multi-tensor launch per statistic kind
+
     def calibrate(self, desc: str, dataloader: Iterable, executor, hooks: Dict[str, object],
                   output_names: List[str] = None):
         """calibration.py:105-121 (progress bar omitted).
@@ -103,9 +109,9 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         batches = self._batches(dataloader)
         if not self._graph_replayable(batches, hooks):
             for data in batches:
-                executor.forward(inputs=data, hooks=hooks, output_names=output_names)
+                self._forward(executor, data, hooks, output_names)
             return
-        executor.forward(inputs=batches[0], hooks=hooks, output_names=output_names)
+        self._forward(executor, batches[0], hooks, output_names)
         first = 1
         if self._use_hip_graph == 'auto':
             # Is this loop launch-bound?  Time batch 1: `issue` = host time to enqueue the step,
@@ -114,7 +120,7 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
             # of microsecond kernels) keeps the GPU idle between launches (issue ~ total).
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            executor.forward(inputs=batches[1], hooks=hooks, output_names=output_names)
+            self._forward(executor, batches[1], hooks, output_names)
             t1 = time.perf_counter()
             torch.cuda.synchronize()
             t2 = time.perf_counter()
@@ -124,13 +130,13 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
                                          'graph': bool(launch_bound and len(batches) - first >= self.AUTO_GRAPH_MIN_STEPS)})
             if not self.graph_decisions[-1]['graph']:
                 for data in batches[first:]:
-                    executor.forward(inputs=data, hooks=hooks, output_names=output_names)
+                    self._forward(executor, data, hooks, output_names)
                 return
         static_in = torch.empty_like(batches[0])
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            executor.forward(inputs=static_in, hooks=hooks, output_names=output_names)
+            self._forward(executor, static_in, hooks, output_names)
             if self._side_stream is not None:
                 torch.cuda.current_stream().wait_stream(self._side_stream)
         for data in batches[first:]:
@@ -143,6 +149,7 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
 
     def _render(self):
         observers = self._all_tensor_observers()
+        if self._queue is not None: self._queue.flush()
         if self._side_stream is not None:          # join the observer stream before reading statistics
             import torch
             torch.cuda.current_stream().wait_stream(self._side_stream)
@@ -187,6 +194,14 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
             observer.hook.stream = self._side_stream
             self._observers[op_name] = observer
             hooks[op_name] = observer.hook
+
+        # queue the per-tensor statistics kernels of a forward into one multi-tensor launch; side-stream
+        # observation keeps its per-tensor launches (they are ordered against each producer)
+        self._queue = None
+        if self._batch_observations and self._side_stream is None:
+            from .observer import ObservationQueue
+            self._queue = ObservationQueue()
+        for ob in self._all_tensor_observers(): ob.queue = self._queue
 
         self.calibrate(desc='Calibration Progress(Phase 1)', dataloader=dataloader, executor=executor,
                        hooks=hooks, output_names=None)

@@ -175,15 +175,17 @@ __device__ __forceinline__ float4 load4(const float4* p) {
 // 4.7 TB/s on a 205 MB read), walks it in tiles of blockDim * U float4 with U 16-B loads in flight
 // per lane; the tail (n % 4) and unaligned tensors fall back to 4-B loads.  Order is unspecified.
 template <int U, bool NT = false, typename F>
-__device__ __forceinline__ void stream_elems(const float* __restrict__ x, uint32_t n, bool vec_ok, F f) {
+__device__ __forceinline__ void stream_elems(const float* __restrict__ x, uint32_t n, bool vec_ok, F f,
+                                             uint32_t bidx = blockIdx.x, uint32_t nblk = gridDim.x) {
+    // bidx / nblk: index of this workgroup among the nblk workgroups sharing the tensor
     uint32_t done = 0;
     if (vec_ok) {
         const uint32_t nvec = n >> 2;
         const float4* xv = reinterpret_cast<const float4*>(x);
         const uint32_t tile = blockDim.x * U;
         const uint32_t tiles = (nvec + tile - 1) / tile;
-        const uint32_t per = (tiles + gridDim.x - 1) / gridDim.x;            // tiles per workgroup
-        const uint32_t lo = blockIdx.x * per * tile;
+        const uint32_t per = (tiles + nblk - 1) / nblk;                      // tiles per workgroup
+        const uint32_t lo = bidx * per * tile;
         const uint32_t hi = min(lo + per * tile, nvec);
         for (uint32_t v = lo + threadIdx.x; v < hi; v += tile) {
             float4 a[U];
@@ -196,8 +198,8 @@ __device__ __forceinline__ void stream_elems(const float* __restrict__ x, uint32
         }
         done = nvec << 2;
     }
-    const uint32_t stride = gridDim.x * blockDim.x;
-    for (uint32_t i = done + blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) f(x[i]);
+    const uint32_t stride = nblk * blockDim.x;
+    for (uint32_t i = done + bidx * blockDim.x + threadIdx.x; i < n; i += stride) f(x[i]);
 }
 
 // Same traversal with a WAVE-UNIFORM trip count (ballot-safe): on_tile(sample, valid) is called by

@@ -176,10 +176,11 @@ __device__ __forceinline__ void lds_hist_zero(int* lds, int total) {
 // (one row per workgroup, so a plain read-modify-write is race free and stream ordered): nothing is
 // reduced per launch, ppqhip_hist_rows_finish sums the rows once, when the histogram is needed.
 __device__ __forceinline__ void lds_hist_flush(const int* lds, int bins, int copies, int* __restrict__ hist,
-                                               int* __restrict__ partial = nullptr, bool accumulate = false) {
+                                               int* __restrict__ partial = nullptr, bool accumulate = false,
+                                               uint32_t row = blockIdx.x) {
     __syncthreads();
     const int pitch = bins + kTrash;
-    int* dst = partial ? partial + (size_t)blockIdx.x * bins : nullptr;
+    int* dst = partial ? partial + (size_t)row * bins : nullptr;
     for (int b = threadIdx.x; b < bins; b += blockDim.x) {
         int s = 0;
         for (int c = 0; c < copies; c++) s += lds[c * pitch + b];
@@ -214,8 +215,10 @@ __global__ __launch_bounds__(kBlock) void hist_reduce_kernel(const int* __restri
 template <bool ASYM, bool CLIP, bool HOT, bool FQ, int R, bool NT, int kHistU>
 __device__ __forceinline__ void hist_stream(const float* __restrict__ x, uint32_t n, int vec_ok, const BinRule& rule,
                                             int copies, int* lds, float* __restrict__ out, float s, int o, int qmin,
-                                            int qmax, int rounding) {
-    const uint32_t stride = gridDim.x * blockDim.x;
+                                            int qmax, int rounding, uint32_t bidx, uint32_t nblk) {
+    // bidx / nblk: this workgroup's index among the workgroups that share the tensor (== blockIdx.x /
+    // gridDim.x for the single-tensor kernels; a sub-range of the grid for hist_t_multi_kernel)
+    const uint32_t stride = nblk * blockDim.x;
     const uint32_t nvec = vec_ok ? (n >> 2) : 0u;
     const float4* xv = reinterpret_cast<const float4*>(x);
     float4* ov = reinterpret_cast<float4*>(out);
@@ -224,9 +227,9 @@ __device__ __forceinline__ void hist_stream(const float* __restrict__ x, uint32_
     // whole grid, so the ballots of WaveAcc::elect always see whole wavefronts.
     const uint32_t bd = blockDim.x;
     const uint32_t tile = bd * kHistU;
-    const uint32_t trips = ((nvec + tile - 1) / tile + gridDim.x - 1) / gridDim.x;
-    const uint32_t hi = min((blockIdx.x + 1) * trips * tile, nvec);
-    uint32_t v = blockIdx.x * trips * tile + threadIdx.x;
+    const uint32_t trips = ((nvec + tile - 1) / tile + nblk - 1) / nblk;
+    const uint32_t hi = min((bidx + 1) * trips * tile, nvec);
+    uint32_t v = bidx * trips * tile + threadIdx.x;
     const uint32_t last_v = nvec ? nvec - 1 : 0u;
     float4 bufa[kHistU], bufb[kHistU];
     auto fetch = [&](float4 (&buf)[kHistU], uint32_t at) {
@@ -271,7 +274,7 @@ __device__ __forceinline__ void hist_stream(const float* __restrict__ x, uint32_
         const uint32_t done = nvec << 2;
         const uint32_t rem = n - done;
         const uint32_t rtrips = (rem + stride - 1) / stride;
-        uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+        uint32_t i = bidx * blockDim.x + threadIdx.x;
         for (uint32_t t = 0; t < rtrips; t++, i += stride) {
             const bool in = i < rem;
             const float a = in ? x[done + i] : 0.f;
@@ -288,8 +291,50 @@ __global__ __launch_bounds__(kHistMaxBlock) void hist_t_lds_kernel(const float* 
                                                                    BinRule rule, int copies, int* __restrict__ hist,
                                                                    int* __restrict__ partial, int accumulate) {
     extern __shared__ int lds[];
-    hist_stream<ASYM, CLIP, HOT, false, 0, NT, U>(x, n, vec_ok, rule, copies, lds, nullptr, 0.f, 0, 0, 0, 0);
+    hist_stream<ASYM, CLIP, HOT, false, 0, NT, U>(x, n, vec_ok, rule, copies, lds, nullptr, 0.f, 0, 0, 0, 0, blockIdx.x,
+                                                  gridDim.x);
     lds_hist_flush(lds, rule.bins, copies, hist, partial, accumulate != 0);
+}
+
+// ---- many tensors, one launch --------------------------------------------------------------------
+// A calibration forward observes ~70 activation tensors of 3..100 MB; launched one by one every
+// histogram pays ~5 us of launch / fill / drain latency on top of its streaming time.  The observers
+// therefore queue their tensors and ONE launch bins them all: the job table travels by value in the
+// kernel arguments, job j owns workgroups [first_block[j], first_block[j+1]) and each of them streams
+// a contiguous chunk of its tensor into LDS and adds it to its own row of that job's persistent
+// rows buffer (same accumulate-mode contract as ppqhip_hist_*_t_rows).
+constexpr int kMultiMax = 64;                 // jobs per launch (2.6 KB of kernel arguments)
+constexpr uint32_t kMultiChunk = 128u << 10;  // elements per workgroup (512 KB): rows RMW is 3 % of the read
+struct HistJob {
+    const float* x;
+    int* rows;
+    uint32_t n;
+    float a, hs, rcp;
+    uint32_t first_block;
+    uint32_t vec_ok;
+};
+struct HistJobs {
+    HistJob job[kMultiMax];
+    uint32_t count;
+    int bins, clip, copies;
+};
+
+template <bool ASYM, bool CLIP, bool HOT, int U>
+__global__ __launch_bounds__(kHistMaxBlock) void hist_t_multi_kernel(const HistJobs jobs) {
+    extern __shared__ int lds[];
+    uint32_t lo = 0, hi = jobs.count;          // largest lo with first_block[lo] <= blockIdx.x (uniform)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (jobs.job[mid].first_block <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const HistJob& j = jobs.job[lo];
+    const uint32_t end = lo + 1 < jobs.count ? jobs.job[lo + 1].first_block : gridDim.x;
+    const uint32_t bidx = blockIdx.x - j.first_block, nblk = end - j.first_block;
+    BinRule rule;
+    rule.a = j.a; rule.hs = j.hs; rule.rcp = j.rcp; rule.bins = jobs.bins; rule.clip = jobs.clip; rule.asym = ASYM;
+    hist_stream<ASYM, CLIP, HOT, false, 0, false, U>(j.x, j.n, (int)j.vec_ok, rule, jobs.copies, lds, nullptr, 0.f, 0, 0,
+                                                     0, 0, bidx, nblk);
+    lds_hist_flush(lds, jobs.bins, jobs.copies, nullptr, j.rows, true, bidx);
 }
 
 // fused: out = fake_quant(x) (== fq_linear_t) and hist += histogram(x) (== hist_sym_t), one read
@@ -301,7 +346,8 @@ __global__ __launch_bounds__(kHistMaxBlock) void fq_linear_t_hist_kernel(
     extern __shared__ int lds[];
     const float s = scale[0];
     const int o = round_offset(offset[0]);
-    hist_stream<false, CLIP, HOT, true, R, false, kHistUBig>(x, n, vec_ok, rule, copies, lds, out, s, o, qmin, qmax, rounding);
+    hist_stream<false, CLIP, HOT, true, R, false, kHistUBig>(x, n, vec_ok, rule, copies, lds, out, s, o, qmin, qmax, rounding,
+                                                             blockIdx.x, gridDim.x);
     lds_hist_flush(lds, rule.bins, copies, hist, partial);
 }
 
@@ -454,6 +500,48 @@ static int launch_hist_t(const float* x, int64_t n, BinRule rule, int32_t* hist,
     return PPQHIP_OK;
 }
 
+static int launch_hist_multi(const ppqhip_hist_job* jobs, int count, int bins, int clip, int asym, hipStream_t s) {
+    const int block = hist_block();
+    const int copies = pick_copies(bins, block);
+    const size_t lds = lds_bytes(bins, copies);
+    const uint32_t max_rows = (uint32_t)(kNumCU * hist_blocks_per_cu());
+    for (int base = 0; base < count; base += kMultiMax) {
+        HistJobs args;
+        args.count = (uint32_t)((count - base) < kMultiMax ? (count - base) : kMultiMax);
+        args.bins = bins; args.clip = clip; args.copies = copies;
+        uint32_t blocks = 0;
+        for (uint32_t k = 0; k < args.count; k++) {
+            const ppqhip_hist_job& src = jobs[base + k];
+            HistJob& d = args.job[k];
+            d.x = src.x; d.rows = src.rows; d.n = (uint32_t)src.n;
+            if (asym) { d.a = src.p0; d.hs = (src.p1 - src.p0) / (float)bins; }     // sort.cu:123
+            else { d.a = 0.f; d.hs = src.p0; }
+            d.rcp = 1.0f / d.hs;
+            d.vec_ok = aligned16(src.x) ? 1u : 0u;
+            d.first_block = blocks;
+            uint32_t nb = (uint32_t)((src.n + kMultiChunk - 1) / kMultiChunk);
+            if (nb > max_rows) nb = max_rows;
+            if (nb < 1) nb = 1;
+            blocks += nb;
+        }
+#define PPQ_LAUNCH_MULTI(A, C, H)                                                                              \
+        hipLaunchKernelGGL((hist_t_multi_kernel<A, C, H, kHistUSmall>), dim3(blocks), dim3(block), lds, s, args)
+        const int sel = (asym ? 4 : 0) | (clip ? 2 : 0) | (hist_hot() ? 1 : 0);
+        switch (sel) {
+            case 0: PPQ_LAUNCH_MULTI(false, false, false); break;
+            case 1: PPQ_LAUNCH_MULTI(false, false, true); break;
+            case 2: PPQ_LAUNCH_MULTI(false, true, false); break;
+            case 3: PPQ_LAUNCH_MULTI(false, true, true); break;
+            case 4: PPQ_LAUNCH_MULTI(true, false, false); break;
+            case 5: PPQ_LAUNCH_MULTI(true, false, true); break;
+            case 6: PPQ_LAUNCH_MULTI(true, true, false); break;
+            default: PPQ_LAUNCH_MULTI(true, true, true); break;
+        }
+#undef PPQ_LAUNCH_MULTI
+    }
+    return PPQHIP_OK;
+}
+
 }  // namespace ppqhip
 
 using namespace ppqhip;
@@ -512,6 +600,27 @@ int ppqhip_hist_asym_t_rows(const float* x, int64_t n, float min_value, float ma
     BinRule rule = make_rule(min_value, hs, (int)num_bins, clip_outliers ? 1 : 0, 1);
     if (int st = launch_hist_t(x, n, rule, nullptr, nullptr, s, rows)) return st;
     return finish_launch("hist_asym_t_rows");
+}
+
+int ppqhip_hist_t_rows_multi(const ppqhip_hist_job* jobs, int num_jobs, int asymmetric, int clip_outliers,
+                             int64_t num_bins, void* stream) {
+    if (num_jobs <= 0) return PPQHIP_OK;
+    if (jobs == nullptr) { set_error("hist_t_rows_multi: jobs is null"); return PPQHIP_ERR_INVALID_VALUE; }
+    if (num_bins <= 0 || num_bins > kMaxLdsBins) {
+        set_error("hist_t_rows_multi: 1..%d bins", kMaxLdsBins); return PPQHIP_ERR_UNSUPPORTED;
+    }
+    double bytes = 0.0;
+    for (int k = 0; k < num_jobs; k++) {
+        if (int st = validate(jobs[k].n, num_bins, "hist_t_rows_multi")) return st;
+        if (jobs[k].x == nullptr || jobs[k].rows == nullptr) {
+            set_error("hist_t_rows_multi: job %d has a null pointer", k); return PPQHIP_ERR_INVALID_VALUE;
+        }
+        bytes += 4.0 * (double)jobs[k].n;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(asymmetric ? K_HIST_ASYM_T : K_HIST_SYM_T, bytes, s);
+    if (int st = launch_hist_multi(jobs, num_jobs, (int)num_bins, clip_outliers ? 1 : 0, asymmetric ? 1 : 0, s)) return st;
+    return finish_launch("hist_t_rows_multi");
 }
 
 int ppqhip_hist_rows_finish(const int32_t* rows, int64_t num_bins, int32_t* hist, void* stream) {

@@ -13,6 +13,8 @@
 //     so results do not depend on the launch shape.
 #include <cstdlib>
 
+#include <vector>
+
 #include "common.hpp"
 
 namespace ppqhip {
@@ -334,6 +336,89 @@ static void launch_lc(const float* x, const float* scale, const float* offset, f
     }
 }
 
+// ---- many tensors, one launch --------------------------------------------------------------------
+// Every forward of a quantised graph fake-quantises all of its weights again (the reference executor
+// does so until ParameterBakingPass); ResNet-50 has 54 of them, 0.01 .. 9 MB each -- one launch per
+// weight is pure launch latency.  Here one launch serves them all: the job table lives in device
+// memory (it only changes when a weight / scale tensor is replaced), the kernel arguments carry the
+// prefix of workgroup counts so a workgroup finds its job without touching memory, and each
+// workgroup quantises one tile of kBlock * U float4 (or the same range element-wise when the tensor
+// cannot be vectorised: elem_per_channel % 4 != 0 or unaligned).  Per-tensor jobs are C = 1.
+constexpr int kFqMultiMax = 128;
+struct FqJob {
+    const float* x;
+    float* out;
+    const float* scale;
+    const float* offset;
+    uint32_t n;
+    uint32_t vec_ok;
+    FastDiv per;          // vec_ok: float4 per channel row; else elements per channel row
+    FastDiv nc;
+    int qmin, qmax;
+};
+struct FqMultiArgs {
+    uint32_t first_block[kFqMultiMax];
+    uint32_t count;
+    int rounding;
+    const FqJob* jobs;
+};
+
+template <int R, int U>
+__global__ __launch_bounds__(kBlock) void fq_linear_multi_kernel(const FqMultiArgs args) {
+    uint32_t lo = 0, hi = args.count;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (args.first_block[mid] <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const FqJob j = args.jobs[lo];                      // uniform address: scalar loads
+    const uint32_t base = (blockIdx.x - args.first_block[lo]) * (kBlock * U) + threadIdx.x;
+    const uint32_t C = j.nc.d;
+    if (j.vec_ok) {
+        const uint32_t nvec = j.n >> 2;
+        const float4* xv = reinterpret_cast<const float4*>(j.x);
+        float4* ov = reinterpret_cast<float4*>(j.out);
+        float4 a[U];
+        float s[U];
+        int o[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const uint32_t vv = min(base + k * kBlock, nvec - 1);
+            a[k] = xv[vv];
+            const uint32_t row = fdiv(vv, j.per);
+            const uint32_t c = row - fdiv(row, j.nc) * C;
+            s[k] = j.scale[c];
+            o[k] = round_offset(j.offset[c]);
+        }
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const uint32_t vv = base + k * kBlock;
+            if (vv < nvec) {
+                float4 r;
+                r.x = fq_linear_scalar<R>(a[k].x, s[k], o[k], j.qmin, j.qmax, args.rounding);
+                r.y = fq_linear_scalar<R>(a[k].y, s[k], o[k], j.qmin, j.qmax, args.rounding);
+                r.z = fq_linear_scalar<R>(a[k].z, s[k], o[k], j.qmin, j.qmax, args.rounding);
+                r.w = fq_linear_scalar<R>(a[k].w, s[k], o[k], j.qmin, j.qmax, args.rounding);
+                ov[vv] = r;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const uint32_t e0 = (base + k * kBlock) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t e = e0 + q;
+                if (e < j.n) {
+                    const uint32_t row = fdiv(e, j.per);
+                    const uint32_t c = row - fdiv(row, j.nc) * C;
+                    j.out[e] = fq_linear_scalar<R>(j.x[e], j.scale[c], round_offset(j.offset[c]), j.qmin, j.qmax,
+                                                   args.rounding);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace ppqhip
 
 using namespace ppqhip;
@@ -362,6 +447,64 @@ int ppqhip_fq_linear_c(const float* x, const float* scale, const float* offset, 
                                    rounding, s);
     else launch_lc<-1>(x, scale, offset, out, n, num_channel, elem_per_channel, clip_min, clip_max, rounding, s);
     return finish_launch("fq_linear_c");
+}
+
+int64_t ppqhip_fq_linear_multi_table_bytes(int num_jobs) {
+    return num_jobs > 0 ? (int64_t)sizeof(FqJob) * num_jobs : 0;
+}
+
+int ppqhip_fq_linear_multi(const ppqhip_fq_job* jobs, int num_jobs, int rounding, void* device_table, int upload,
+                           void* stream) {
+    if (num_jobs <= 0) return PPQHIP_OK;
+    if (jobs == nullptr || device_table == nullptr) {
+        set_error("fq_linear_multi: jobs / device_table is null"); return PPQHIP_ERR_INVALID_VALUE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    double bytes = 0.0;
+    for (int k = 0; k < num_jobs; k++) {
+        if (int st = validate_n(jobs[k].n, "fq_linear_multi")) return st;
+        if (int st = validate_channels(jobs[k].n, jobs[k].num_channel, jobs[k].elem_per_channel, "fq_linear_multi")) return st;
+        if (!jobs[k].x || !jobs[k].out || !jobs[k].scale || !jobs[k].offset) {
+            set_error("fq_linear_multi: job %d has a null pointer", k); return PPQHIP_ERR_INVALID_VALUE;
+        }
+        bytes += 8.0 * (double)jobs[k].n;
+    }
+    LaunchScope scope(K_FQ_LINEAR_C, bytes, s);
+    constexpr int U = 2;
+    for (int base = 0; base < num_jobs; base += kFqMultiMax) {
+        const int count = (num_jobs - base) < kFqMultiMax ? (num_jobs - base) : kFqMultiMax;
+        FqMultiArgs args;
+        args.count = (uint32_t)count; args.rounding = rounding;
+        args.jobs = (const FqJob*)device_table + base;
+        std::vector<FqJob> table(upload ? count : 0);
+        uint32_t blocks = 0;
+        for (int k = 0; k < count; k++) {
+            const ppqhip_fq_job& src = jobs[base + k];
+            const bool vec = aligned16(src.x) && aligned16(src.out) && (src.elem_per_channel % 4 == 0);
+            args.first_block[k] = blocks;
+            const uint64_t quads = ((uint64_t)src.n + 3) / 4;
+            blocks += (uint32_t)((quads + kBlock * U - 1) / (kBlock * U));
+            if (upload) {
+                FqJob& d = table[k];
+                d.x = src.x; d.out = src.out; d.scale = src.scale; d.offset = src.offset;
+                d.n = (uint32_t)src.n; d.vec_ok = vec ? 1u : 0u;
+                d.per = make_fastdiv((uint32_t)(vec ? src.elem_per_channel / 4 : src.elem_per_channel));
+                d.nc = make_fastdiv((uint32_t)src.num_channel);
+                d.qmin = src.clip_min; d.qmax = src.clip_max;
+            }
+        }
+        if (upload) {
+            // pageable source: the runtime stages the copy before returning, `table` may go out of scope
+            if (int st = check_hip(hipMemcpyAsync((FqJob*)device_table + base, table.data(), sizeof(FqJob) * count,
+                                                  hipMemcpyHostToDevice, s), "fq_linear_multi table upload"))
+                return st;
+        }
+        if (rounding == ROUND_HALF_EVEN)
+            hipLaunchKernelGGL((fq_linear_multi_kernel<ROUND_HALF_EVEN, U>), dim3(blocks), dim3(kBlock), 0, s, args);
+        else
+            hipLaunchKernelGGL((fq_linear_multi_kernel<-1, U>), dim3(blocks), dim3(kBlock), 0, s, args);
+    }
+    return finish_launch("fq_linear_multi");
 }
 
 int ppqhip_fq_linear_t_bwd(const float* x, const float* scale, const float* offset, const float* grad_y,

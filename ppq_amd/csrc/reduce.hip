@@ -60,6 +60,46 @@ __global__ __launch_bounds__(kBlock) void minmax_t_kernel(const float* __restric
     }
 }
 
+// many tensors, one launch (see hist_t_multi_kernel): job j owns workgroups [first_block[j],
+// first_block[j+1]); workgroup b of a job folds its chunk into slot b of that job's persistent slots.
+constexpr int kMinMaxMultiMax = 96;              // jobs per launch (2.3 KB of kernel arguments)
+constexpr uint32_t kMinMaxMultiChunk = 64u << 10;   // elements per workgroup (256 KB)
+struct MinMaxJob {
+    const float* x;
+    float* slots;
+    uint32_t n;
+    uint32_t first_block;
+};
+struct MinMaxJobs {
+    MinMaxJob job[kMinMaxMultiMax];
+    uint32_t count;
+};
+
+__global__ __launch_bounds__(kBlock) void minmax_t_multi_kernel(const MinMaxJobs jobs) {
+    __shared__ float lds[16];
+    uint32_t lo = 0, hi = jobs.count;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (jobs.job[mid].first_block <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const MinMaxJob& j = jobs.job[lo];
+    const uint32_t end = lo + 1 < jobs.count ? jobs.job[lo + 1].first_block : gridDim.x;
+    const uint32_t bidx = blockIdx.x - j.first_block, nblk = end - j.first_block;
+    float mn = INFINITY, mx = -INFINITY;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(j.x) & 15u) == 0;
+    stream_elems<4, false>(j.x, j.n, vec_ok, [&](float a) { mn = fminf(mn, a); mx = fmaxf(mx, a); }, bidx, nblk);
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { lds[wid] = mn; lds[8 + wid] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / kWave; w++) { mn = fminf(mn, lds[w]); mx = fmaxf(mx, lds[8 + w]); }
+        j.slots[2 * bidx] = fminf(mn, j.slots[2 * bidx]);
+        j.slots[2 * bidx + 1] = fmaxf(mx, j.slots[2 * bidx + 1]);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void minmax_finish_kernel(const float* __restrict__ partial, uint32_t count,
                                                                float* __restrict__ minmax) {
     __shared__ float lds[16];
@@ -483,6 +523,38 @@ int64_t ppqhip_minmax_slots(void) { return (int64_t)kNumCU * 8; }
 int ppqhip_minmax_t_slots(const float* x, int64_t n, float* slots, void* stream) {
     if (slots == nullptr) { set_error("minmax_t_slots: slots is null"); return PPQHIP_ERR_INVALID_VALUE; }
     return minmax_t_impl(x, n, nullptr, nullptr, slots, stream);
+}
+
+int ppqhip_minmax_t_slots_multi(const ppqhip_minmax_job* jobs, int num_jobs, void* stream) {
+    if (num_jobs <= 0) return PPQHIP_OK;
+    if (jobs == nullptr) { set_error("minmax_t_slots_multi: jobs is null"); return PPQHIP_ERR_INVALID_VALUE; }
+    double bytes = 0.0;
+    for (int k = 0; k < num_jobs; k++) {
+        if (int st = validate(jobs[k].n, "minmax_t_slots_multi")) return st;
+        if (jobs[k].x == nullptr || jobs[k].slots == nullptr) {
+            set_error("minmax_t_slots_multi: job %d has a null pointer", k); return PPQHIP_ERR_INVALID_VALUE;
+        }
+        bytes += 4.0 * (double)jobs[k].n;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_MINMAX_T, bytes, s);
+    const uint32_t max_slots = (uint32_t)ppqhip_minmax_slots();
+    for (int base = 0; base < num_jobs; base += kMinMaxMultiMax) {
+        MinMaxJobs args;
+        args.count = (uint32_t)((num_jobs - base) < kMinMaxMultiMax ? (num_jobs - base) : kMinMaxMultiMax);
+        uint32_t blocks = 0;
+        for (uint32_t k = 0; k < args.count; k++) {
+            const ppqhip_minmax_job& src = jobs[base + k];
+            args.job[k].x = src.x; args.job[k].slots = src.slots; args.job[k].n = (uint32_t)src.n;
+            args.job[k].first_block = blocks;
+            uint32_t nb = (uint32_t)((src.n + kMinMaxMultiChunk - 1) / kMinMaxMultiChunk);
+            if (nb > max_slots) nb = max_slots;
+            if (nb < 1) nb = 1;
+            blocks += nb;
+        }
+        hipLaunchKernelGGL(minmax_t_multi_kernel, dim3(blocks), dim3(kBlock), 0, s, args);
+    }
+    return finish_launch("minmax_t_slots_multi");
 }
 
 int ppqhip_minmax_slots_finish(const float* slots, float* minmax, void* stream) {

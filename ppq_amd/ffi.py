@@ -18,6 +18,7 @@ Errors follow the reference's convention as seen from Python: the C++ ``ValueTyp
 """
 from typing import List
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -108,6 +109,59 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
         ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
         _workspaces[key] = ws
     return ws
+
+
+# host-side job records of the multi-tensor entry points (struct layouts of include/ppq_hip.h)
+_MINMAX_JOB = np.dtype([('x', '<u8'), ('slots', '<u8'), ('n', '<i8')])
+_FQ_JOB = np.dtype([('x', '<u8'), ('scale', '<u8'), ('offset', '<u8'), ('out', '<u8'), ('n', '<i8'),
+                    ('num_channel', '<i8'), ('elem_per_channel', '<i8'), ('clip_min', '<i4'), ('clip_max', '<i4')])
+_HIST_JOB = np.dtype([('x', '<u8'), ('rows', '<u8'), ('n', '<i8'), ('p0', '<f4'), ('p1', '<f4')])
+
+
+class LinearQuantizePlan:
+    """Fake-quantise MANY tensors with ONE launch per call (``ppqhip_fq_linear_multi``): the weights of
+    a graph, which the executor quantises again on every forward.  Built once from
+    ``(value, scale, offset, channel_axis | None, quant_min, quant_max)`` items that share a rounding
+    policy; ``run()`` re-quantises all of them into one resident arena and returns views shaped like
+    the inputs -- values identical to ``CUDA.LinearQuantize_C`` / ``_T`` per item.  The device job
+    table is uploaded at construction; ``signature()`` lets the owner detect replaced tensors."""
+    def __init__(self, items, rounding: int = 0):
+        if not items: raise ValueError('LinearQuantizePlan needs at least one item')
+        self._keep = []                       # the tensors the device table points at
+        dev = items[0][0].device
+        total = 0
+        for value, scale, offset, axis, qmin, qmax in items:
+            _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset')
+            if value.device != dev or scale.device != dev or offset.device != dev:
+                raise RuntimeError(_KERNEL_FAILURE + 'LinearQuantizePlan: every tensor must live on one device')
+            total += (value.numel() + 3) // 4 * 4
+        self._arena = torch.empty(total, dtype=torch.float32, device=dev)
+        self._jobs = np.zeros(len(items), dtype=_FQ_JOB)
+        self._outs = []
+        at = 0
+        for k, (value, scale, offset, axis, qmin, qmax) in enumerate(items):
+            v = value.contiguous()
+            sc, of = scale.contiguous().reshape(-1), offset.contiguous().reshape(-1)
+            if axis is None: C, epc = 1, v.numel()
+            else: C, epc = _geometry(v.shape, axis)
+            if sc.numel() != C or of.numel() != C:
+                raise RuntimeError(_KERNEL_FAILURE + f'LinearQuantizePlan: item {k} needs {C} scales / offsets')
+            out = self._arena[at: at + v.numel()].view(v.shape)
+            at += (v.numel() + 3) // 4 * 4          # every output starts 16-B aligned
+            self._keep.append((v, sc, of))
+            self._outs.append(out)
+            self._jobs[k] = (v.data_ptr(), sc.data_ptr(), of.data_ptr(), out.data_ptr(), v.numel(), C, epc, int(qmin), int(qmax))
+        self._rounding = int(getattr(rounding, 'value', rounding))
+        self._table = torch.empty(int(lib.ppqhip_fq_linear_multi_table_bytes(len(items))), dtype=torch.uint8, device=dev)
+        self._uploaded = False
+        self.bytes = 8 * sum(v.numel() for v, _, _ in self._keep)
+
+    def run(self) -> List[torch.Tensor]:
+        with _DeviceOf(self._arena):
+            _raise(lib.ppqhip_fq_linear_multi(self._jobs.ctypes.data, len(self._jobs), self._rounding,
+                                              self._table.data_ptr(), 0 if self._uploaded else 1, _stream()))
+        self._uploaded = True
+        return self._outs
 
 
 class _HipExtension:
@@ -372,6 +426,50 @@ class _HipExtension:
         v = value.contiguous()
         with _DeviceOf(v):
             _raise(lib.ppqhip_minmax_t_slots(v.data_ptr(), v.numel(), slots.data_ptr(), _stream()))
+
+    @ staticmethod
+    def MinMax_T_Slots_Multi(values, slots) -> None:
+        """One launch for many (value, slots) pairs; each pair as MinMax_T_Slots.  All on one device."""
+        if len(values) != len(slots): raise RuntimeError(_KERNEL_FAILURE + 'values / slots length mismatch')
+        if not values: return
+        S = 2 * lib.ppqhip_minmax_slots()
+        vs = []
+        for v, sl in zip(values, slots):
+            _f32(v, 'Value'); _f32(sl, 'Slots')
+            if sl.numel() != S or not sl.is_contiguous() or sl.device != values[0].device or v.device != values[0].device:
+                raise RuntimeError(_KERNEL_FAILURE + 'slots must be contiguous [minmax_slots(), 2] tensors on the values\' device')
+            vs.append(v.contiguous())
+        jobs = np.empty(len(vs), dtype=_MINMAX_JOB)
+        jobs['x'] = [v.data_ptr() for v in vs]
+        jobs['slots'] = [sl.data_ptr() for sl in slots]
+        jobs['n'] = [v.numel() for v in vs]
+        with _DeviceOf(vs[0]):
+            _raise(lib.ppqhip_minmax_t_slots_multi(jobs.ctypes.data, len(vs), _stream()))
+
+    @ staticmethod
+    def Histogram_T_Rows_Multi(values, rows, p0, p1, asymmetric: bool, clip_outliers: bool) -> None:
+        """One launch for many (value, rows) pairs sharing the bin count: symmetric jobs take
+        p0 = hist_scale, asymmetric ones p0 = min, p1 = max; each pair as Histogram_[Asymmetric_]T_Rows."""
+        if not (len(values) == len(rows) == len(p0)) or (asymmetric and len(p1) != len(values)):
+            raise RuntimeError(_KERNEL_FAILURE + 'values / rows / parameter length mismatch')
+        if not values: return
+        R, bins = lib.ppqhip_hist_rows(), rows[0].shape[-1]
+        vs = []
+        for v, r in zip(values, rows):
+            _f32(v, 'Value'); _check(r, torch.int32, 'Rows(Expect to be INT32)')
+            if (r.ndim != 2 or r.shape[0] != R or r.shape[1] != bins or not r.is_contiguous()
+                    or r.device != values[0].device or v.device != values[0].device):
+                raise RuntimeError(_KERNEL_FAILURE + f'rows must be contiguous [{R}, {bins}] tensors on the values\' device')
+            vs.append(v.contiguous())
+        jobs = np.empty(len(vs), dtype=_HIST_JOB)
+        jobs['x'] = [v.data_ptr() for v in vs]
+        jobs['rows'] = [r.data_ptr() for r in rows]
+        jobs['n'] = [v.numel() for v in vs]
+        jobs['p0'] = np.asarray(p0, dtype=np.float32)
+        jobs['p1'] = np.asarray(p1, dtype=np.float32) if asymmetric else 0.0
+        with _DeviceOf(vs[0]):
+            _raise(lib.ppqhip_hist_t_rows_multi(jobs.ctypes.data, len(vs), int(bool(asymmetric)),
+                                                int(bool(clip_outliers)), bins, _stream()))
 
     @ staticmethod
     def MinMax_Slots_Finish(slots, minmax) -> None:
@@ -642,6 +740,21 @@ class CUDA:
     def MinMax_Slots_Finish(slots, minmax):
         HIP_EXTENSION.MinMax_Slots_Finish(slots, minmax)
         return minmax
+
+    @ staticmethod
+    def MinMax_T_Slots_Multi(tensors, slots):
+        HIP_EXTENSION.MinMax_T_Slots_Multi(tensors, slots)
+        return slots
+
+    @ staticmethod
+    def Histogram_T_Rows_Multi(tensors, rows, scales, clip_outliers: bool = True):
+        HIP_EXTENSION.Histogram_T_Rows_Multi(tensors, rows, scales, None, False, clip_outliers)
+        return rows
+
+    @ staticmethod
+    def Histogram_Asymmetric_T_Rows_Multi(min_values, max_values, tensors, rows, clip_outliers: bool = True):
+        HIP_EXTENSION.Histogram_T_Rows_Multi(tensors, rows, min_values, max_values, True, clip_outliers)
+        return rows
 
     @ staticmethod
     def Histogram_T_Rows(tensor, rows, scale: float, clip_outliers: bool = True):

@@ -157,6 +157,10 @@ class TorchExecutor:
         self._default_quant_fn = PPQuantFunction
         self.cache_parameter_quantization = False     # opt-in: see _quantize_parameter
         self._param_cache: Dict[str, tuple] = {}
+        self.fuse_parameter_quantization = True       # all weights of a forward in ONE launch: _fused_parameters
+        self._plans: list = []
+        self._plan_signature = None
+        self._fused: Dict[tuple, torch.Tensor] = {}
         self._delegates: Dict[object, Callable] = {}
         for v in graph.variables.values():
             if v.is_parameter and v.value is not None: v.value = v.value.to(device)
@@ -185,6 +189,7 @@ class TorchExecutor:
         g = self._graph
         for name, value in feed_dict.items(): g.variables[name].value = value.to(self._device)
         results = [None] * len(output_names)
+        self._fused_parameters()
         for op in operations:
             raw_in = [v.value for v in op.inputs]
             if any(x is None for x in raw_in):
@@ -204,7 +209,48 @@ class TorchExecutor:
             if not v.is_parameter: v.value = None
         return results
 
+    def _fused_parameters(self) -> None:
+        """Fake-quantise every parameter whose config is an activated, non-delegated LINEAR one with a
+        single multi-tensor launch (ffi.LinearQuantizePlan -> ppqhip_fq_linear_multi) instead of one
+        launch per weight; same per-forward work as the reference executor (torch.py:516-518), same
+        values as PPQLinearQuantFunction.  The device job table holds POINTERS, so in-place updates of
+        weights / scales need no rebuild; replaced tensors or edited configs do (signature check)."""
+        self._fused = {}
+        if not self.fuse_parameter_quantization or self._default_quant_fn is not PPQuantFunction: return
+        todo, sig = [], []
+        for op in self._graph.operations.values():
+            if not isinstance(op, QuantableOperation): continue
+            for v, c in zip(op.inputs, op.config.input_quantization_config):
+                if not (v.is_parameter and isinstance(v.value, torch.Tensor) and v.value.is_cuda): continue
+                if not QuantizationStates.is_activated(c.state) or c in self._delegates: continue
+                pol = c.policy
+                if not pol.has_property(P.LINEAR) or pol.has_property(P.DYNAMIC): continue
+                if v.value.dtype != torch.float32 or v.value.requires_grad or v.value.numel() == 0: continue
+                if not (isinstance(c.scale, torch.Tensor) and isinstance(c.offset, torch.Tensor)): continue
+                axis = c.channel_axis if pol.has_property(P.PER_CHANNEL) else None
+                rnd = int(getattr(c.rounding, 'value', c.rounding))
+                todo.append((v, c, axis, rnd))
+                sig.append((v.name, id(c), v.value.data_ptr(), c.scale.data_ptr(), c.offset.data_ptr(), tuple(v.value.shape), c.scale.numel(),
+                            axis, c.quant_min, c.quant_max, rnd))
+        if not todo:
+            self._plans, self._plan_signature = [], None
+            return
+        if sig != self._plan_signature:
+            from .ffi import LinearQuantizePlan
+            groups: Dict[int, list] = {}
+            for item in todo: groups.setdefault(item[3], []).append(item)
+            self._plans = []
+            for rnd, items in groups.items():
+                plan = LinearQuantizePlan([(v.value, c.scale, c.offset, axis, c.quant_min, c.quant_max)
+                                           for v, c, axis, _ in items], rounding=rnd)
+                self._plans.append((plan, [(v.name, id(c)) for v, c, _, _ in items]))
+            self._plan_signature = sig
+        for plan, keys in self._plans:
+            for key, out in zip(keys, plan.run()): self._fused[key] = out
+
     def _quantize_parameter(self, var: Variable, config) -> torch.Tensor:
+        hit = self._fused.get((var.name, id(config)))
+        if hit is not None: return hit
         """A parameter and its scale do not change between calibration forwards, so its fake-quantised
         value is computed once and kept resident (the reference recomputes it every forward until
         ParameterBakingPass; same values, ppq/executor/torch.py:516-518).  The cache entry is keyed on
@@ -228,6 +274,7 @@ class TorchExecutor:
         if output_names is None: output_names = list(g.outputs)
         results = [None] * len(output_names)
         visited = set()
+        self._fused_parameters()
         for op in g.topological_sort():
             hook = hooks.get(op.name) if hooks else None
             raw_in = [v.value for v in op.inputs]

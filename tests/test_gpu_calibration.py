@@ -527,3 +527,147 @@ def test_bias_correction_pass():
     assert all(not getattr(op, '_dequantized', False) for op in graph.operations.values())
     with pytest.raises(NotImplementedError):
         BiasCorrectionPass(block_size=4)
+
+
+def test_multi_tensor_launches_equal_single(CUDA):
+    """MinMax_T_Slots_Multi / Histogram_*_T_Rows_Multi: one launch over many tensors == one launch per
+    tensor (bit-exact after the fold) and == the oracle; covers > 64 jobs (several launches), a
+    1-element tensor, an unaligned view, accumulation over two rounds and a large tensor that needs
+    more workgroups than there are rows."""
+    g = torch.Generator().manual_seed(21)
+    sizes = [1, 5, 1000, 4097, 65536, 300001, 1 << 20] * 10 + [40 * (1 << 20)]
+    xs = [(torch.randn(n + 1, generator=g) * (1 + i % 5)).to(DEV)[(i % 2):][:n] for i, n in enumerate(sizes)]   # odd i: unaligned
+    assert len(xs) == 71
+    R, S, bins = CUDA.hist_rows(), CUDA.minmax_slots(), 2048
+    # min / max -------------------------------------------------------------------------------
+    seed = torch.tensor([float('inf'), float('-inf')], device=DEV)
+    slots_a = [seed.repeat(S, 1).contiguous() for _ in xs]
+    slots_b = [seed.repeat(S, 1).contiguous() for _ in xs]
+    for rnd in range(2):
+        ys = [x * (1 + rnd) for x in xs]
+        CUDA.MinMax_T_Slots_Multi(ys, slots_a)
+        for y, sl in zip(ys, slots_b): CUDA.MinMax_T_Slots(y, sl)
+    for x, a, b in zip(xs, slots_a, slots_b):
+        ra, rb = seed.clone(), seed.clone()
+        CUDA.MinMax_Slots_Finish(a, ra); CUDA.MinMax_Slots_Finish(b, rb)
+        assert torch.equal(ra, rb)
+        assert float(ra[0]) == float((x * 2).min().clamp(max=float(x.min()))) and float(ra[1]) == float(torch.maximum(x.max(), (x * 2).max()))
+    # symmetric + asymmetric histograms ----------------------------------------------------------
+    scales = [float(x.abs().max()) / bins * 0.9 for x in xs]          # 0.9: some outliers get clipped
+    los = [float(x.min()) * 0.8 for x in xs]; his = [float(x.max()) * 0.8 + 1e-3 for x in xs]
+    for asym in (False, True):
+        rows_a = [torch.zeros(R, bins, dtype=torch.int32, device=DEV) for _ in xs]
+        rows_b = [torch.zeros(R, bins, dtype=torch.int32, device=DEV) for _ in xs]
+        for rnd in range(2):
+            if asym:
+                CUDA.Histogram_Asymmetric_T_Rows_Multi(los, his, xs, rows_a)
+                for x, r, lo, hi in zip(xs, rows_b, los, his): CUDA.Histogram_Asymmetric_T_Rows(lo, hi, x, r)
+            else:
+                CUDA.Histogram_T_Rows_Multi(xs, rows_a, scales)
+                for x, r, s in zip(xs, rows_b, scales): CUDA.Histogram_T_Rows(x, r, s)
+        for i, (x, a, b) in enumerate(zip(xs, rows_a, rows_b)):
+            ha = torch.zeros(bins, dtype=torch.int32, device=DEV); hb = torch.zeros_like(ha)
+            CUDA.Histogram_Rows_Finish(a, ha); CUDA.Histogram_Rows_Finish(b, hb)
+            assert torch.equal(ha, hb), (asym, i)
+            if x.numel() <= (1 << 20):
+                want = np.zeros(bins, np.int32)
+                xn = x.cpu().numpy()
+                for _ in range(2):
+                    if asym: O.hist_asym_t(xn, los[i], his[i], want, True)
+                    else: O.hist_sym_t(xn, scales[i], want, True)
+                assert np.array_equal(ha.cpu().numpy(), want), (asym, i)
+    with pytest.raises(RuntimeError):
+        CUDA.Histogram_T_Rows_Multi(xs[:2], [torch.zeros(R, bins, dtype=torch.int32, device=DEV)], scales[:2])
+
+
+@pytest.mark.parametrize('method', ['kl', 'mse', 'minmax'])
+def test_batched_observations_equal_per_tensor_launches(method):
+    """RuntimeCalibrationPass(batch_observations=True) (one multi-tensor launch per forward and statistic)
+    renders exactly the scales / offsets of the per-tensor launches."""
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    g = torch.Generator().manual_seed(4)
+    batches = [torch.rand(4, 3, 24, 24, generator=g).to(DEV) - 0.3 for _ in range(8)]
+
+    def run(batch):
+        graph = harness.small_cnn_graph(seed=3)
+        harness.quantize_graph(graph, method, hist_bins=2048 if method == 'kl' else None)
+        ex = harness.TorchExecutor(graph, DEV)
+        harness.ParameterQuantizePass().optimize(graph)
+        p = RuntimeCalibrationPass(method=method, batch_observations=batch)
+        p.optimize(graph, dataloader=batches, executor=ex, calib_steps=8)
+        torch.cuda.synchronize()
+        return p, [(float(c.scale), float(c.offset)) for op in graph.operations.values() for c, v in op.config_with_variable
+                   if not v.is_parameter and c.state.value == 4]
+    p0, single = run(False)
+    p1, multi = run(True)
+    assert p0._queue is None and p1._queue is not None and p1._queue.launches >= 8
+    assert len(single) == 6 and single == multi
+
+
+@pytest.mark.parametrize('rounding', [0, 1, 4])
+def test_linear_quantize_plan_equals_per_tensor_kernels(CUDA, rounding):
+    """LinearQuantizePlan (one launch for many weights) == LinearQuantize_C / _T item by item, bit-exact:
+    conv / gemm weights, elem_per_channel % 4 != 0 (scalar path), an unaligned view, per-tensor items,
+    asymmetric and int4 ranges, > 128 items (several launches); in-place weight updates are picked up
+    without rebuilding (the table holds pointers)."""
+    from ppq_amd.ffi import LinearQuantizePlan
+    g = torch.Generator().manual_seed(31)
+    shapes = [(64, 3, 7, 7), (64, 64, 1, 1), (128, 64, 3, 3), (1000, 512), (7, 5, 3), (1, 1), (33, 1, 3, 3), (512, 2048, 1, 1)]
+    items, want = [], []
+    for rep in range(17):
+        for i, shp in enumerate(shapes):
+            w = (torch.randn(*shp, generator=g) * 0.2).to(DEV)
+            if (rep + i) % 5 == 0:                                    # unaligned storage offset
+                w = torch.cat([w.flatten(), w.flatten()[:1]])[1:].view(shp) if w.numel() > 1 else w
+            per_channel = (rep + i) % 3 != 0
+            C = shp[0] if per_channel else 1
+            scale = (torch.rand(C, generator=g) * 0.01 + 1e-3).to(DEV)
+            asym = (rep + i) % 2 == 0
+            qmin, qmax = ((0, 255) if asym else (-128, 127)) if i % 4 else (-8, 7)
+            offset = (torch.randint(0, 255, [C], generator=g).float() if asym else torch.zeros(C)).to(DEV)
+            items.append((w, scale, offset, 0 if per_channel else None, qmin, qmax))
+    assert len(items) == 136
+    plan = LinearQuantizePlan(items, rounding=rounding)
+
+    def reference():
+        return [CUDA.LinearQuantize_C(w, s, o, ax, lo, hi, rounding) if ax is not None
+                else CUDA.LinearQuantize_T(w, s, o, lo, hi, rounding) for w, s, o, ax, lo, hi in items]
+    for got, ref, it in zip(plan.run(), reference(), items):
+        assert got.shape == it[0].shape and torch.equal(got, ref)
+    for w, s, *_ in items[::7]:                                       # in-place updates: no rebuild needed
+        w.mul_(1.5); s.mul_(0.9)
+    for got, ref in zip(plan.run(), reference()): assert torch.equal(got, ref)
+
+
+def test_fused_parameter_quantization_equals_per_weight_launches():
+    """TorchExecutor(fuse_parameter_quantization=True): one launch for all weights per forward gives the
+    forward outputs of the per-weight launches, follows re-rendered scales, and leaves delegated configs alone."""
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    g = torch.Generator().manual_seed(4)
+    batches = [torch.rand(4, 3, 24, 24, generator=g).to(DEV) for _ in range(8)]
+
+    def run(fuse):
+        graph = harness.small_cnn_graph(seed=3)
+        harness.quantize_graph(graph, 'kl', hist_bins=2048)
+        ex = harness.TorchExecutor(graph, DEV)
+        ex.fuse_parameter_quantization = fuse
+        harness.ParameterQuantizePass().optimize(graph)
+        RuntimeCalibrationPass(method='kl').optimize(graph, dataloader=batches, executor=ex, calib_steps=8)
+        return graph, ex, ex.forward(batches[0])[0].clone()
+    _, ex0, y0 = run(False)
+    graph, ex1, y1 = run(True)
+    assert not ex0._plans and len(ex1._plans) == 1 and torch.equal(y0, y1)
+    # a config edit (new scale tensor) is followed
+    conv = next(op for op in graph.operations.values() if op.type == 'Conv')
+    wcfg = conv.config.input_quantization_config[1]
+    wcfg.scale = wcfg.scale * 2
+    y2 = ex1.forward(batches[0])[0].clone()
+    ex1.fuse_parameter_quantization = False
+    assert torch.equal(ex1.forward(batches[0])[0], y2) and not torch.equal(y2, y1)
+    # a delegated config is not part of the plan
+    ex1.fuse_parameter_quantization = True
+    ex1.register_quantize_delegate(wcfg, lambda t, c: t)
+    ex1.forward(batches[0])
+    assert (conv.inputs[1].name, id(wcfg)) not in ex1._fused
