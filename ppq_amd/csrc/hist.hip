@@ -304,7 +304,13 @@ __global__ __launch_bounds__(kHistMaxBlock) void hist_t_lds_kernel(const float* 
 // a contiguous chunk of its tensor into LDS and adds it to its own row of that job's persistent
 // rows buffer (same accumulate-mode contract as ppqhip_hist_*_t_rows).
 constexpr int kMultiMax = 64;                 // jobs per launch (2.6 KB of kernel arguments)
-constexpr uint32_t kMultiChunk = 128u << 10;  // elements per workgroup (512 KB): rows RMW is 3 % of the read
+#ifndef PPQHIP_MULTI_CHUNK
+#define PPQHIP_MULTI_CHUNK (128u << 10)
+#endif
+#ifndef PPQHIP_MULTI_U
+#define PPQHIP_MULTI_U kHistUBig     // MI355X sweep (tools/multi_bench.py): U=2 5.0 TB/s, U=1 4.8; chunk 512 KB > 256 KB, 1 MB, 2 MB
+#endif
+constexpr uint32_t kMultiChunk = PPQHIP_MULTI_CHUNK;  // elements per workgroup (512 KB): rows RMW is 3 % of the read
 struct HistJob {
     const float* x;
     int* rows;
@@ -525,7 +531,7 @@ static int launch_hist_multi(const ppqhip_hist_job* jobs, int count, int bins, i
             blocks += nb;
         }
 #define PPQ_LAUNCH_MULTI(A, C, H)                                                                              \
-        hipLaunchKernelGGL((hist_t_multi_kernel<A, C, H, kHistUSmall>), dim3(blocks), dim3(block), lds, s, args)
+        hipLaunchKernelGGL((hist_t_multi_kernel<A, C, H, PPQHIP_MULTI_U>), dim3(blocks), dim3(block), lds, s, args)
         const int sel = (asym ? 4 : 0) | (clip ? 2 : 0) | (hist_hot() ? 1 : 0);
         switch (sel) {
             case 0: PPQ_LAUNCH_MULTI(false, false, false); break;

@@ -1,0 +1,40 @@
+"""Device time of the multi-tensor observer launches on a ResNet-50-like set of activation tensors
+(batch 32): ONE launch over all of them vs one launch per tensor."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ppq_amd import CUDA
+dev = 'cuda'
+B = 32
+shapes = [(B, 64, 112, 112)] + [(B, 256, 56, 56)] * 3 + [(B, 64, 56, 56)] * 6 + [(B, 512, 28, 28)] * 4 + [(B, 128, 28, 28)] * 8 \
+    + [(B, 1024, 14, 14)] * 6 + [(B, 256, 14, 14)] * 12 + [(B, 2048, 7, 7)] * 3 + [(B, 512, 7, 7)] * 6 + [(B, 1000)]
+torch.manual_seed(0)
+xs = [torch.relu(torch.randn(*s, device=dev)) for s in shapes]
+total = sum(x.numel() for x in xs) * 4
+R, S = CUDA.hist_rows(), CUDA.minmax_slots()
+rows = [torch.zeros(R, 2048, dtype=torch.int32, device=dev) for _ in xs]
+seed = torch.tensor([float('inf'), float('-inf')], device=dev)
+slots = [seed.repeat(S, 1).contiguous() for _ in xs]
+scales = [float(x.max()) / 2048 for x in xs]
+
+
+def timed(fn, n=20):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
+
+
+def per_tensor_hist():
+    for x, r, s in zip(xs, rows, scales): CUDA.Histogram_T_Rows(x, r, s)
+
+
+def per_tensor_minmax():
+    for x, sl in zip(xs, slots): CUDA.MinMax_T_Slots(x, sl)
+
+
+print(f'{len(xs)} tensors, {total / 1e6:.0f} MB')
+for name, fn in (('hist multi', lambda: CUDA.Histogram_T_Rows_Multi(xs, rows, scales)), ('hist per-tensor', per_tensor_hist),
+                 ('minmax multi', lambda: CUDA.MinMax_T_Slots_Multi(xs, slots)), ('minmax per-tensor', per_tensor_minmax)):
+    us = timed(fn)
+    print(f'{name:18s} {us:9.1f} us  {total / us / 1e6:7.2f} TB/s')
