@@ -103,12 +103,15 @@ def pmc_traffic(kernel_name: str):
     path = os.path.join(ROOT, 'profiles', 'r01_bench_pmc_bytes.json')
     if not os.path.exists(path): return None, None
     data = json.load(open(path))
-    key = {'hist_sym_t': 'hist_t_lds_kernel<false', 'hist_asym_t': 'hist_t_lds_kernel<true', 'minmax_t': 'minmax_t_kernel',
-           'fq_linear_c': 'fq_linear_c_tile_kernel', 'fq_linear_t': 'fq_linear_t_tile_kernel'}.get(kernel_name)
-    if key is None: return None, None
+    keys = {'hist_sym_t': ('hist_t_multi_kernel<false', 'hist_t_lds_kernel<false'),
+            'hist_asym_t': ('hist_t_multi_kernel<true', 'hist_t_lds_kernel<true'),
+            'minmax_t': ('minmax_t_multi_kernel', 'minmax_t_kernel'),
+            'fq_linear_c': ('fq_linear_multi_kernel', 'fq_linear_c_tile_kernel'),
+            'fq_linear_t': ('fq_linear_t_tile_kernel',)}.get(kernel_name)
+    if keys is None: return None, None
     tot = n = 0
     for k, v in data.items():
-        if k.startswith(key) and 'launches' in v:
+        if k.startswith(keys) and 'launches' in v:
             tot += v['launches'] * (v.get('hbm_read_bytes_per_launch_corrected', 0) + v.get('hbm_write_bytes_per_launch', 0))
             n += v['launches']
     return (round(tot / n), 'profiles/r01_bench_pmc_bytes.json') if n else (None, None)
@@ -146,6 +149,7 @@ def main():
     ap.add_argument('--async-observe', type=int, default=0, help='observer kernels on a side HIP stream')
     ap.add_argument('--fuse-params', type=int, default=1, help='all weights of a forward fake-quantised by one multi-tensor launch')
     ap.add_argument('--batch-observations', type=int, default=1, help='all statistics kernels of a forward in one multi-tensor launch')
+    ap.add_argument('--settle-ms', type=float, default=400.0, help='untimed: extra warm-up forwards (ms of wall clock) so device clocks settle')
     ap.add_argument('--trace-steps', type=int, default=0, help='debug: per-forward host / device timestamps in the JSON line')
     ap.add_argument('--cache-params', type=int, default=0, help='keep fake-quantised weights resident between forwards')
     ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
@@ -165,6 +169,13 @@ def main():
         graph, ex = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params)
         run_pass(graph, ex, batches[: max(1, min(args.warmup, args.steps))], max(1, min(args.warmup, args.steps)), args.method,
                  bool(args.async_observe), False, bool(args.batch_observations))
+        # keep the device under the workload's own load profile for a moment: a GPU that sat idle (fresh
+        # box) otherwise spends the first timed steps in clock / power transitions (sporadic 10-20 ms
+        # device-side stalls were traced to the first steps after idle; tools/find_stall.py)
+        t_settle = time.perf_counter()
+        while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+            for b in batches[:2]: ex.forward(b)
+            torch.cuda.synchronize()
         del graph, ex
 
     # timed region

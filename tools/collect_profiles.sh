@@ -18,6 +18,8 @@ cd $R
 python tools/microbench.py --tensors A,B,Bx8,Bx32 --rotate 4 > $O/microbench_randn_rot4.txt 2>&1
 python tools/microbench.py --tensors B,Bx32 --rotate 4 --relu > $O/microbench_relu_rot4.txt 2>&1
 python tools/microbench.py --tensors A,B --rotate 1 > $O/microbench_randn_cached.txt 2>&1
+python tools/multi_bench.py > $O/multi_bench.txt 2>&1
+for b in 1 8; do python bench.py --no-cpu-baseline --batch $b --steps $((256 / b)) > $O/bench_batch$b.json 2>/dev/null; done
 cd /tmp
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/micro_trace -o micro -- python $R/tools/microbench.py --tensors B,Bx32 --rotate 4 > /dev/null 2>&1
 cd $R
