@@ -252,7 +252,8 @@ def main():
     if rank == 0:
         samples = world * args.steps * args.batch
         out = {
-            'metric': 'calibration samples/sec (RuntimeCalibrationPass, KL 2048-bin, ResNet-50 INT8)',
+            'metric': ('calibration samples/sec (RuntimeCalibrationPass, KL 2048-bin, ResNet-50 INT8)' if args.method == 'kl' and args.bins == 2048
+                       else f'calibration samples/sec (RuntimeCalibrationPass, {args.method}, {args.bins} bins, ResNet-50 INT8)'),
             'value': round(samples / elapsed, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',

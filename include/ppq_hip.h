@@ -140,6 +140,18 @@ int64_t ppqhip_quantile_workspace_bytes(int64_t n);
 int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, void* workspace,
                       void* stream);
 
+/* many tensors, one launch per pass: dest_k[0..1] = (q, 1-q) order statistics of job k exactly as
+ * ppqhip_quantile_t.  `jobs` is a HOST array (copied into the kernel arguments); workspace holds
+ * ppqhip_quantile_multi_workspace_bytes(num_jobs) bytes. */
+typedef struct ppqhip_quantile_job {
+    const float* x;   /* device, n floats */
+    float* dest;      /* device, 2 floats */
+    int64_t n;
+} ppqhip_quantile_job;
+int64_t ppqhip_quantile_multi_workspace_bytes(int num_jobs);
+int ppqhip_quantile_t_multi(const ppqhip_quantile_job* jobs, int num_jobs, float q, void* workspace,
+                            void* stream);
+
 /* replaces Isotone_T, sort.cu:61-73: dest = [max, 2nd max, min, 2nd min] (with multiplicity).
  * `workspace`: device scratch of ppqhip_quantile_workspace_bytes(n) bytes (shared sizing). */
 int ppqhip_isotone_t(const float* x, int64_t n, float* dest, void* workspace, void* stream);

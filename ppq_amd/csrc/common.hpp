@@ -207,16 +207,16 @@ __device__ __forceinline__ void stream_elems(const float* __restrict__ x, uint32
 // (valid == false for slots past the end); the scalar remainder reports one element per "tile".
 template <int U, typename FT, typename FE>
 __device__ __forceinline__ void stream_tiles(const float* __restrict__ x, uint32_t n, bool vec_ok, FT on_tile,
-                                             FE on_elem) {
+                                             FE on_elem, uint32_t bidx = blockIdx.x, uint32_t nblk = gridDim.x) {
     uint32_t done = 0;
     if (vec_ok) {
         const uint32_t nvec = n >> 2;
         const float4* xv = reinterpret_cast<const float4*>(x);
         const uint32_t tile = blockDim.x * U;
         const uint32_t tiles = (nvec + tile - 1) / tile;
-        const uint32_t per = (tiles + gridDim.x - 1) / gridDim.x;
-        const uint32_t hi = min((blockIdx.x + 1) * per * tile, nvec);
-        uint32_t v = blockIdx.x * per * tile + threadIdx.x;
+        const uint32_t per = (tiles + nblk - 1) / nblk;
+        const uint32_t hi = min((bidx + 1) * per * tile, nvec);
+        uint32_t v = bidx * per * tile + threadIdx.x;
         for (uint32_t t = 0; t < per; t++, v += tile) {
             float4 a[U];
 #pragma unroll
@@ -231,10 +231,10 @@ __device__ __forceinline__ void stream_tiles(const float* __restrict__ x, uint32
         }
         done = nvec << 2;
     }
-    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t stride = nblk * blockDim.x;
     const uint32_t rem = n - done;
     const uint32_t trips = (rem + stride - 1) / stride;
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = bidx * blockDim.x + threadIdx.x;
     for (uint32_t t = 0; t < trips; t++, i += stride) {
         const bool in = i < rem;
         const float a = in ? x[done + i] : 0.f;

@@ -303,8 +303,8 @@ __device__ void select_bin(const uint32_t* __restrict__ hist, int nbins, uint32_
 
 constexpr int kQTrash = 64;
 
-__global__ __launch_bounds__(kBlock) void quantile_pass1_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
-                                                                uint32_t* __restrict__ ws) {
+__device__ __forceinline__ void quantile_pass1_body(const float* __restrict__ x, uint32_t n, bool vec_ok,
+                                                    uint32_t* __restrict__ ws, uint32_t bidx, uint32_t nblk) {
     __shared__ uint32_t h[kQ1 + kQTrash];
     for (int i = threadIdx.x; i < kQ1; i += kBlock) h[i] = 0;
     __syncthreads();
@@ -312,16 +312,21 @@ __global__ __launch_bounds__(kBlock) void quantile_pass1_kernel(const float* __r
     hc.init(h, kQ1);
     stream_tiles<4>(x, n, vec_ok,
                     [&](float v, bool in) { hc.elect((int)(f2key(v) >> 20), in); },
-                    [&](float v, bool in) { hc.add(in ? (int)(f2key(v) >> 20) : hc.trash()); });
+                    [&](float v, bool in) { hc.add(in ? (int)(f2key(v) >> 20) : hc.trash()); }, bidx, nblk);
     hc.flush();
     __syncthreads();
     for (int i = threadIdx.x; i < kQ1; i += kBlock)
         if (h[i]) atomicAdd(&ws[kOffH1 + i], h[i]);
 }
 
-__global__ __launch_bounds__(kBlock) void quantile_pass2_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
-                                                                uint32_t k_hi, uint32_t k_lo,
+__global__ __launch_bounds__(kBlock) void quantile_pass1_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
                                                                 uint32_t* __restrict__ ws) {
+    quantile_pass1_body(x, n, vec_ok, ws, blockIdx.x, gridDim.x);
+}
+
+__device__ __forceinline__ void quantile_pass2_body(const float* __restrict__ x, uint32_t n, bool vec_ok,
+                                                    uint32_t k_hi, uint32_t k_lo, uint32_t* __restrict__ ws,
+                                                    uint32_t bidx, uint32_t nblk) {
     __shared__ uint32_t h[2 * (kQ2 + kQTrash)];
     __shared__ uint32_t scratch[kBlock];
     __shared__ uint32_t sel[2];
@@ -347,13 +352,19 @@ __global__ __launch_bounds__(kBlock) void quantile_pass2_kernel(const float* __r
                         const int mid = (int)((key >> 8) & 0xFFFu);
                         if (in && top == p_hi) hi_c.add(mid);      // rare unless the bin is hot (then it is
                         if (in && top == p_lo) lo_c.add(mid);      // absorbed by the hot register)
-                    });
+                    }, bidx, nblk);
     hi_c.flush(); lo_c.flush();
     __syncthreads();
     for (int i = threadIdx.x; i < kQ2; i += kBlock) {
         if (h[i]) atomicAdd(&ws[kOffH2 + i], h[i]);
         if (h[kQ2 + kQTrash + i]) atomicAdd(&ws[kOffH2 + kQ2 + i], h[kQ2 + kQTrash + i]);
     }
+}
+
+__global__ __launch_bounds__(kBlock) void quantile_pass2_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
+                                                                uint32_t k_hi, uint32_t k_lo,
+                                                                uint32_t* __restrict__ ws) {
+    quantile_pass2_body(x, n, vec_ok, k_hi, k_lo, ws, blockIdx.x, gridDim.x);
 }
 
 // shared by pass 3 and the final pick: 24-bit prefixes and residual ranks of both targets
@@ -371,9 +382,9 @@ __device__ void select_prefix24(const uint32_t* __restrict__ ws, uint32_t k_hi, 
     }
 }
 
-__global__ __launch_bounds__(kBlock) void quantile_pass3_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
-                                                                uint32_t k_hi, uint32_t k_lo,
-                                                                uint32_t* __restrict__ ws) {
+__device__ __forceinline__ void quantile_pass3_body(const float* __restrict__ x, uint32_t n, bool vec_ok,
+                                                    uint32_t k_hi, uint32_t k_lo, uint32_t* __restrict__ ws,
+                                                    uint32_t bidx, uint32_t nblk) {
     __shared__ uint32_t h[2 * (kQ3 + kQTrash)];
     __shared__ uint32_t scratch[kBlock];
     __shared__ uint32_t sel[2];
@@ -395,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void quantile_pass3_kernel(const float* __r
                         const int low = (int)(key & 0xFFu);
                         if (in && (key >> 8) == p24[0]) hi_c.add(low);
                         if (in && (key >> 8) == p24[1]) lo_c.add(low);
-                    });
+                    }, bidx, nblk);
     hi_c.flush(); lo_c.flush();
     __syncthreads();
     for (int i = threadIdx.x; i < kQ3; i += kBlock) {
@@ -404,9 +415,14 @@ __global__ __launch_bounds__(kBlock) void quantile_pass3_kernel(const float* __r
     }
 }
 
-__global__ __launch_bounds__(kBlock) void quantile_pick_kernel(uint32_t k_hi, uint32_t k_lo,
-                                                               const uint32_t* __restrict__ ws,
-                                                               float* __restrict__ dest) {
+__global__ __launch_bounds__(kBlock) void quantile_pass3_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
+                                                                uint32_t k_hi, uint32_t k_lo,
+                                                                uint32_t* __restrict__ ws) {
+    quantile_pass3_body(x, n, vec_ok, k_hi, k_lo, ws, blockIdx.x, gridDim.x);
+}
+
+__device__ __forceinline__ void quantile_pick_body(uint32_t k_hi, uint32_t k_lo, const uint32_t* __restrict__ ws,
+                                                   float* __restrict__ dest) {
     __shared__ uint32_t scratch[kBlock];
     __shared__ uint32_t sel[2];
     uint32_t p24[2], r24[2];
@@ -416,6 +432,49 @@ __global__ __launch_bounds__(kBlock) void quantile_pick_kernel(uint32_t k_hi, ui
         if (threadIdx.x == 0) dest[w] = key2f((p24[w] << 8) | sel[0]);
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(kBlock) void quantile_pick_kernel(uint32_t k_hi, uint32_t k_lo,
+                                                               const uint32_t* __restrict__ ws,
+                                                               float* __restrict__ dest) {
+    quantile_pick_body(k_hi, k_lo, ws, dest);
+}
+
+// many tensors, one launch per pass (see hist_t_multi_kernel): job j owns workgroups
+// [first_block[j], first_block[j+1]) and its own kQWords-word slice of the workspace.
+constexpr int kQuantileMultiMax = 64;                  // jobs per launch (2.6 KB of kernel arguments)
+constexpr uint32_t kQuantileMultiChunk = 32u << 10;    // elements per workgroup (128 KB)
+constexpr uint32_t kQuantileMultiCap = 1024;           // workgroups per job at most
+struct QuantileJob {
+    const float* x;
+    uint32_t* ws;
+    float* dest;
+    uint32_t n, k_hi, k_lo, first_block;
+};
+struct QuantileJobs {
+    QuantileJob job[kQuantileMultiMax];
+    uint32_t count;
+};
+
+template <int PASS>
+__global__ __launch_bounds__(kBlock) void quantile_multi_kernel(const QuantileJobs jobs) {
+    if (PASS == 4) {                                   // pick: one workgroup per job
+        const QuantileJob& j = jobs.job[blockIdx.x];
+        quantile_pick_body(j.k_hi, j.k_lo, j.ws, j.dest);
+        return;
+    }
+    uint32_t lo = 0, hi = jobs.count;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (jobs.job[mid].first_block <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const QuantileJob& j = jobs.job[lo];
+    const uint32_t end = lo + 1 < jobs.count ? jobs.job[lo + 1].first_block : gridDim.x;
+    const uint32_t bidx = blockIdx.x - j.first_block, nblk = end - j.first_block;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(j.x) & 15u) == 0;
+    if (PASS == 1) quantile_pass1_body(j.x, j.n, vec_ok, j.ws, bidx, nblk);
+    if (PASS == 2) quantile_pass2_body(j.x, j.n, vec_ok, j.k_hi, j.k_lo, j.ws, bidx, nblk);
+    if (PASS == 3) quantile_pass3_body(j.x, j.n, vec_ok, j.k_hi, j.k_lo, j.ws, bidx, nblk);
 }
 
 // ------------------------------------------------------------------------------------ isotone
@@ -645,6 +704,57 @@ int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, void* wor
     hipLaunchKernelGGL(quantile_pass3_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, vec_ok, k_hi, k_lo, ws);
     hipLaunchKernelGGL(quantile_pick_kernel, dim3(1), dim3(kBlock), 0, s, k_hi, k_lo, ws, dest);
     return finish_launch("quantile_t");
+}
+
+int64_t ppqhip_quantile_multi_workspace_bytes(int num_jobs) {
+    return num_jobs > 0 ? (int64_t)num_jobs * kQWords * 4 : 0;
+}
+
+int ppqhip_quantile_t_multi(const ppqhip_quantile_job* jobs, int num_jobs, float q, void* workspace, void* stream) {
+    if (num_jobs <= 0) return PPQHIP_OK;
+    if (jobs == nullptr || workspace == nullptr) {
+        set_error("quantile_t_multi: jobs / workspace is null"); return PPQHIP_ERR_INVALID_VALUE;
+    }
+    double bytes = 0.0;
+    for (int k = 0; k < num_jobs; k++) {
+        if (int st = validate(jobs[k].n, "quantile_t_multi")) return st;
+        if (jobs[k].x == nullptr || jobs[k].dest == nullptr) {
+            set_error("quantile_t_multi: job %d has a null pointer", k); return PPQHIP_ERR_INVALID_VALUE;
+        }
+        bytes += 4.0 * (double)jobs[k].n;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_QUANTILE, bytes, s);
+    uint32_t* ws = (uint32_t*)workspace;
+    if (int st = check_hip(hipMemsetAsync(ws, 0, (size_t)num_jobs * kQWords * 4, s), "memset quantile workspace"))
+        return st;
+    for (int base = 0; base < num_jobs; base += kQuantileMultiMax) {
+        QuantileJobs args;
+        args.count = (uint32_t)((num_jobs - base) < kQuantileMultiMax ? (num_jobs - base) : kQuantileMultiMax);
+        uint32_t blocks = 0;
+        for (uint32_t k = 0; k < args.count; k++) {
+            const ppqhip_quantile_job& src = jobs[base + k];
+            const int64_t n = src.n;
+            auto pos = [n](float f) -> uint32_t {               // sort.cu:13-19, as in ppqhip_quantile_t
+                float p = nearbyintf((float)n * f);
+                if (!(p > 0.f)) return 0u;
+                if (p >= (float)(n - 1)) return (uint32_t)(n - 1);
+                return (uint32_t)p;
+            };
+            QuantileJob& d = args.job[k];
+            d.x = src.x; d.dest = src.dest; d.n = (uint32_t)n; d.ws = ws + (size_t)(base + k) * kQWords;
+            d.k_hi = pos(q); d.k_lo = pos(1 - q); d.first_block = blocks;
+            uint32_t nb = (uint32_t)((n + kQuantileMultiChunk - 1) / kQuantileMultiChunk);
+            if (nb > kQuantileMultiCap) nb = kQuantileMultiCap;
+            if (nb < 1) nb = 1;
+            blocks += nb;
+        }
+        hipLaunchKernelGGL(quantile_multi_kernel<1>, dim3(blocks), dim3(kBlock), 0, s, args);
+        hipLaunchKernelGGL(quantile_multi_kernel<2>, dim3(blocks), dim3(kBlock), 0, s, args);
+        hipLaunchKernelGGL(quantile_multi_kernel<3>, dim3(blocks), dim3(kBlock), 0, s, args);
+        hipLaunchKernelGGL(quantile_multi_kernel<4>, dim3(args.count), dim3(kBlock), 0, s, args);
+    }
+    return finish_launch("quantile_t_multi");
 }
 
 int ppqhip_isotone_t(const float* x, int64_t n, float* dest, void* workspace, void* stream) {

@@ -115,6 +115,7 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
 _MINMAX_JOB = np.dtype([('x', '<u8'), ('slots', '<u8'), ('n', '<i8')])
 _FQ_JOB = np.dtype([('x', '<u8'), ('scale', '<u8'), ('offset', '<u8'), ('out', '<u8'), ('n', '<i8'),
                     ('num_channel', '<i8'), ('elem_per_channel', '<i8'), ('clip_min', '<i4'), ('clip_max', '<i4')])
+_QUANTILE_JOB = np.dtype([('x', '<u8'), ('dest', '<u8'), ('n', '<i8')])
 _HIST_JOB = np.dtype([('x', '<u8'), ('rows', '<u8'), ('n', '<i8'), ('p0', '<f4'), ('p1', '<f4')])
 
 
@@ -320,6 +321,30 @@ class _HipExtension:
             _raise(lib.ppqhip_quantile_t(v.data_ptr(), v.numel(), float(q), dest.data_ptr(), ws.data_ptr(),
                                          _stream()))
         return dest
+
+    @ staticmethod
+    def Quantile_T_Multi(sources, q: float, dests=None) -> list:
+        """One launch per pass for many tensors; each result as Quantile_T.  ``dests``: optional list of
+        preallocated float32[2] device tensors to fill."""
+        if not sources: return []
+        vs = []
+        for v in sources:
+            _f32(v, 'Value')
+            if v.device != sources[0].device: raise RuntimeError(_KERNEL_FAILURE + 'Quantile_T_Multi: one device per call')
+            vs.append(v.contiguous())
+        if dests is None: dests = [torch.empty(2, dtype=torch.float32, device=vs[0].device) for _ in vs]
+        if len(dests) != len(vs): raise RuntimeError(_KERNEL_FAILURE + 'sources / dests length mismatch')
+        for d in dests:
+            _f32(d, 'Dest')
+            if d.numel() != 2 or not d.is_contiguous(): raise RuntimeError(_KERNEL_FAILURE + 'dest must be a contiguous float32[2]')
+        jobs = np.empty(len(vs), dtype=_QUANTILE_JOB)
+        jobs['x'] = [v.data_ptr() for v in vs]
+        jobs['dest'] = [d.data_ptr() for d in dests]
+        jobs['n'] = [v.numel() for v in vs]
+        with _DeviceOf(vs[0]):
+            ws = _workspace(vs[0].device, lib.ppqhip_quantile_multi_workspace_bytes(len(vs)))
+            _raise(lib.ppqhip_quantile_t_multi(jobs.ctypes.data, len(vs), float(q), ws.data_ptr(), _stream()))
+        return dests
 
     @ staticmethod
     def Isotone_T(source) -> torch.Tensor:
@@ -639,6 +664,10 @@ class CUDA:
     @ staticmethod
     def Quantile(tensor, q: float):
         return HIP_EXTENSION.Quantile_T(tensor, q)
+
+    @ staticmethod
+    def Quantile_Multi(tensors, q: float, dests=None):
+        return HIP_EXTENSION.Quantile_T_Multi(tensors, q, dests)
 
     @ staticmethod
     def Isotone(tensor):

@@ -105,11 +105,14 @@ class ObservationQueue:
     def __init__(self, max_pending_bytes: int = 1 << 30):
         self._minmax = []                  # (tensor, slots)
         self._hist = {}                    # (asymmetric, bins, device) -> [(tensor, rows, p0, p1)]
+        self._quantile = {}                # (q, device) -> [(tensor, dest)]
         self._bytes = 0
         self._max = max_pending_bytes
         self.launches = 0
 
-    def __len__(self): return len(self._minmax) + sum(len(v) for v in self._hist.values())
+    def __len__(self):
+        return (len(self._minmax) + sum(len(v) for v in self._hist.values())
+                + sum(len(v) for v in self._quantile.values()))
 
     def _grow(self, value) -> None:
         self._bytes += value.numel() * 4
@@ -123,7 +126,19 @@ class ObservationQueue:
         self._hist.setdefault((bool(asymmetric), rows.shape[1], value.device), []).append((value, rows, p0, p1))
         self._grow(value)
 
+    def add_quantile(self, value: torch.Tensor, q: float) -> torch.Tensor:
+        """Returns the float32[2] (max-side, min-side) result tensor; it is filled at the next flush."""
+        dest = torch.empty(2, dtype=torch.float32, device=value.device)
+        self._quantile.setdefault((float(q), value.device), []).append((value, dest))
+        self._grow(value)
+        return dest
+
     def flush(self) -> None:
+        if self._quantile:
+            pending, self._quantile = self._quantile, {}
+            for (q, _), items in pending.items():
+                CUDA.Quantile_Multi([v for v, _ in items], q, [d for _, d in items])
+                self.launches += 1
         if self._minmax:
             by_dev = {}
             for v, sl in self._minmax: by_dev.setdefault(v.device, []).append((v, sl))
@@ -416,13 +431,17 @@ class TorchPercentileObserver(BaseTensorObserver):
         assert value.numel() > 0, (f'You are observing an empty tensor({getattr(self._watch_on, "name", "")}).')
         assert isinstance(value, torch.Tensor), 'TorchMinMaxObserver can only deal with torch Tensor values'
         if self._quant_cfg.policy.has_property(P.PER_TENSOR):
-            self._percentile_collector.append(CUDA.Quantile(value, self._percentile).view(1, -1))
+            if self.queue is not None and value.is_cuda:
+                self._percentile_collector.append(self.queue.add_quantile(value, self._percentile).view(1, -1))
+            else:
+                self._percentile_collector.append(CUDA.Quantile(value, self._percentile).view(1, -1))
         elif self._quant_cfg.policy.has_property(P.PER_CHANNEL):
             raise PermissionError('Percentile observer can not deal with per channel quantization.')
         else:
             raise TypeError('Min-max Observer only work with per-tensor or per-channel quantize policy.')
 
     def _fold(self):
+        self._drain()
         if self._percentile_collector:
             stacked = torch.cat(self._percentile_collector, dim=0).float()
             part = torch.cat([stacked.sum(dim=0), stacked.new_tensor([float(stacked.shape[0])])])
@@ -440,6 +459,7 @@ class TorchPercentileObserver(BaseTensorObserver):
             if single_shard and len(self._percentile_collector) == 0:
                 raise ValueError('Can not render quantization config yet, Observer data collator is empty. '
                                  'Invoke observe() function before render config.')
+            self._drain()
             if single_shard:      # exactly the reference's expression, range.py:369
                 device = self._percentile_collector[-1].device
                 mean = torch.cat(self._percentile_collector, dim=0).float().mean(dim=0).cpu()

@@ -583,7 +583,7 @@ def test_multi_tensor_launches_equal_single(CUDA):
         CUDA.Histogram_T_Rows_Multi(xs[:2], [torch.zeros(R, bins, dtype=torch.int32, device=DEV)], scales[:2])
 
 
-@pytest.mark.parametrize('method', ['kl', 'mse', 'minmax'])
+@pytest.mark.parametrize('method', ['kl', 'mse', 'minmax', 'percentile'])
 def test_batched_observations_equal_per_tensor_launches(method):
     """RuntimeCalibrationPass(batch_observations=True) (one multi-tensor launch per forward and statistic)
     renders exactly the scales / offsets of the per-tensor launches."""
@@ -674,3 +674,24 @@ def test_fused_parameter_quantization_equals_per_weight_launches():
     ex1.register_quantize_delegate(wcfg, lambda t, c: t)
     ex1.forward(batches[0])
     assert (conv.inputs[1].name, id(wcfg)) not in ex1._fused
+
+
+def test_multi_tensor_quantile_equals_single(CUDA):
+    """Quantile_Multi (one launch per radix pass for many tensors) == Quantile per tensor == the oracle's
+    order statistics (sort.cu:6-59 index rule), incl. > 64 jobs, 1-element and unaligned tensors,
+    ReLU-style data (half the elements equal) and a tensor needing the workgroup cap."""
+    g = torch.Generator().manual_seed(33)
+    sizes = [1, 2, 7, 1000, 4097, 65536, 300001] * 10 + [40 * (1 << 20)]
+    xs = []
+    for i, n in enumerate(sizes):
+        x = torch.randn(n + 1, generator=g) * (1 + i % 3)
+        if i % 4 == 0: x = torch.relu(x)
+        xs.append(x.to(DEV)[(i % 2):][:n])
+    for q in (0.9999, 0.99, 0.5):
+        multi = CUDA.Quantile_Multi(xs, q)
+        for i, (x, got) in enumerate(zip(xs, multi)):
+            single = CUDA.Quantile(x, q)
+            assert torch.equal(got, single), (q, i)
+            if x.numel() <= 300001:
+                want = O.quantile_t(x.cpu().numpy(), q)
+                assert np.array_equal(got.cpu().numpy(), np.asarray(want, np.float32)), (q, i)

@@ -33,8 +33,13 @@ def per_tensor_minmax():
     for x, sl in zip(xs, slots): CUDA.MinMax_T_Slots(x, sl)
 
 
+def per_tensor_quantile():
+    for x in xs: CUDA.Quantile(x, 0.9999)
+
+
 print(f'{len(xs)} tensors, {total / 1e6:.0f} MB')
 for name, fn in (('hist multi', lambda: CUDA.Histogram_T_Rows_Multi(xs, rows, scales)), ('hist per-tensor', per_tensor_hist),
-                 ('minmax multi', lambda: CUDA.MinMax_T_Slots_Multi(xs, slots)), ('minmax per-tensor', per_tensor_minmax)):
+                 ('minmax multi', lambda: CUDA.MinMax_T_Slots_Multi(xs, slots)), ('minmax per-tensor', per_tensor_minmax),
+                 ('quantile multi', lambda: CUDA.Quantile_Multi(xs, 0.9999)), ('quantile per-tensor', per_tensor_quantile)):
     us = timed(fn)
     print(f'{name:18s} {us:9.1f} us  {total / us / 1e6:7.2f} TB/s')
