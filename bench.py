@@ -65,10 +65,11 @@ def build_workload(dev, bins, method, cache_params=False, fuse_params=True):
     return graph, ex
 
 
-def run_pass(graph, ex, batches, steps, method, async_observe=False, hip_graph=False, batch_observations=True):
+def run_pass(graph, ex, batches, steps, method, async_observe=False, hip_graph=False, batch_observations=True,
+             reuse_activations=False):
     from ppq_amd.calibration import RuntimeCalibrationPass
     p = RuntimeCalibrationPass(method=method, check_steps=False, async_observe=async_observe, use_hip_graph=hip_graph,
-                               batch_observations=batch_observations)
+                               batch_observations=batch_observations, reuse_activations=reuse_activations)
     if TRACE_STEPS is not None:          # --trace-steps: host timestamp + device event after every forward
         inner = p._forward
 
@@ -151,6 +152,8 @@ def main():
     ap.add_argument('--batch-observations', type=int, default=1, help='all statistics kernels of a forward in one multi-tensor launch')
     ap.add_argument('--settle-ms', type=float, default=400.0, help='untimed: extra warm-up forwards (ms of wall clock) so device clocks settle')
     ap.add_argument('--trace-steps', type=int, default=0, help='debug: per-forward host / device timestamps in the JSON line')
+    ap.add_argument('--reuse-activations', type=int, default=0,
+                    help='OPT-IN, off for the headline number: keep the phase-1 activations in HBM and bin them in phase 2 instead of running the forward again')
     ap.add_argument('--cache-params', type=int, default=0, help='keep fake-quantised weights resident between forwards')
     ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
     args = ap.parse_args()
@@ -188,7 +191,7 @@ def main():
     t0 = time.perf_counter()
     if args.trace_steps: ev0.record()
     p = run_pass(graph, ex, batches, args.steps, args.method, bool(args.async_observe), {'0': False, '1': True, 'auto': 'auto'}[args.hip_graph],
-                 bool(args.batch_observations))
+                 bool(args.batch_observations), bool(args.reuse_activations))
     barrier(world)
     elapsed = time.perf_counter() - t0
     trace = None
@@ -264,6 +267,7 @@ def main():
                        'parallelism': f'dp{world} (batches sharded, 1 all-reduce per phase)',
                        'async_observe': bool(args.async_observe), 'cache_params': bool(args.cache_params),
                        'fuse_params': bool(args.fuse_params), 'batch_observations': bool(args.batch_observations),
+                       'reuse_activations': bool(args.reuse_activations), 'replayed_batches': p.replayed_batches,
                        'hip_graph': args.hip_graph, 'graph_replays': p.graph_replays,
                        'graph_decisions': [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()}
                                            for d in p.graph_decisions]},

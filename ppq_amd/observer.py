@@ -109,6 +109,7 @@ class ObservationQueue:
         self._bytes = 0
         self._max = max_pending_bytes
         self.launches = 0
+        self.recorder: Optional[list] = None   # RuntimeCalibrationPass(reuse_activations=True): (observer, tensor) of phase 1
 
     def __len__(self):
         return (len(self._minmax) + sum(len(v) for v in self._hist.values())
@@ -316,6 +317,8 @@ class TorchHistObserver(TorchMinMaxObserver):
         if not is_initial(self._quant_cfg): return
         assert value.numel() > 0, (f'You are observing an empty tensor({getattr(self._watch_on, "name", "")}).')
         if self._phase == 'Detecting Minmax':
+            if self.queue is not None and self.queue.recorder is not None and value.is_cuda:
+                self.queue.recorder.append((self, value))
             return super().observe(value)
         elif self._phase == 'Collating Hist':
             if self._hist is None:

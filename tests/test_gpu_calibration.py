@@ -695,3 +695,37 @@ def test_multi_tensor_quantile_equals_single(CUDA):
             if x.numel() <= 300001:
                 want = O.quantile_t(x.cpu().numpy(), q)
                 assert np.array_equal(got.cpu().numpy(), np.asarray(want, np.float32)), (q, i)
+
+
+def test_reuse_activations_equals_second_forward():
+    """RuntimeCalibrationPass(reuse_activations=True) keeps the phase-1 activations in HBM and bins them in
+    phase 2 instead of running the forward again: identical scales on an all-KL graph; on a graph where the
+    phase-1 render activates an activation config (mixed minmax / kl) the kept tensors are dropped and the
+    forward runs again (still identical); a small budget replays only the leading batches."""
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    g = torch.Generator().manual_seed(4)
+    batches = [torch.rand(4, 3, 24, 24, generator=g).to(DEV) - 0.2 for _ in range(8)]
+
+    def run(mixed, **kw):
+        graph = harness.small_cnn_graph(seed=3)
+        harness.quantize_graph(graph, 'kl', hist_bins=2048)
+        if mixed:
+            cfg = next(c for op in graph.topological_sort() if hasattr(op, 'config')
+                       for c, v in op.config_with_variable if not v.is_parameter and c.state.value == 1)   # first INITIAL activation
+            cfg.observer_algorithm = 'minmax'
+        ex = harness.TorchExecutor(graph, DEV)
+        harness.ParameterQuantizePass().optimize(graph)
+        p = RuntimeCalibrationPass(method=None, **kw)
+        p.optimize(graph, dataloader=batches, executor=ex, calib_steps=8)
+        torch.cuda.synchronize()
+        return p, [float(c.scale) for op in graph.operations.values() for c, v in op.config_with_variable
+                   if not v.is_parameter and c.state.value == 4]
+    _, ref = run(False)
+    p, got = run(False, reuse_activations=True)
+    assert p.replayed_batches == 8 and got == ref and len(ref) == 6
+    p, got = run(False, reuse_activations=True, reuse_budget_bytes=3 * 400_000)     # room for one or two batches
+    assert 0 < p.replayed_batches < 8 and got == ref
+    _, ref_mixed = run(True)
+    p, got = run(True, reuse_activations=True)
+    assert p.replayed_batches == 0 and got == ref_mixed and ref_mixed != ref
