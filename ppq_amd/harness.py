@@ -146,6 +146,12 @@ def _forward(op: Operation, x: List[torch.Tensor]):
     if t == 'Flatten': return torch.flatten(x[0], 1)
     if t == 'LayerNormalization': return F.layer_norm(x[0], x[0].shape[-1:], x[1], x[2])
     if t == 'Softmax': return F.softmax(x[0], dim=a.get('axis', -1))
+    if t == 'Mul': return x[0] * (x[1] if len(x) > 1 else a['value'])
+    if t == 'Reshape': return x[0].reshape(a['shape'])
+    if t == 'Transpose': return x[0].permute(a['perm'])
+    if t == 'Concat': return torch.cat([v.expand(x[-1].shape[0], *v.shape[1:]) if v.shape[0] == 1 else v for v in x],
+                                       dim=a.get('axis', 1))
+    if t == 'Slice': return x[0].narrow(a['axis'], a['start'], a['length'])
     raise NotImplementedError(f'Graph op: {op.name}({op.type}) has no backend implementation')
 
 
@@ -471,6 +477,61 @@ def transformer_mlp_graph(seed: int = 0, dim: int = 64, hidden: int = 256) -> Ba
     b2 = g.create_variable('fc2_b', torch.zeros(dim), True)
     h = g.create_operation('Gemm', 'fc2', [h, w2, b2])
     y = g.create_operation('Add', 'residual', [h, x])
+    g.outputs[y.name] = y
+    return g
+
+
+def vit_graph(seed: int = 0, depth: int = 12, dim: int = 768, heads: int = 12, mlp_dim: int = 3072, patch: int = 16,
+              image: int = 224, num_classes: int = 1000) -> BaseGraph:
+    """ViT-B/16 topology (BASELINE config 4): patch-embedding Conv, class token + position embedding,
+    `depth` pre-norm blocks (LayerNorm -> QKV Gemm -> scaled-dot-product attention with two MatMul ->
+    projection Gemm -> residual; LayerNorm -> Gemm -> Gelu -> Gemm -> residual), final LayerNorm, head.
+    Seeded random weights (no onnx / checkpoints in the image)."""
+    gen = torch.Generator().manual_seed(seed)
+    g = BaseGraph('vit')
+    tokens, hd = (image // patch) ** 2 + 1, dim // heads
+
+    def param(name, *shape, std=None, ones=False):
+        if ones: val = torch.ones(*shape)
+        elif std == 0: val = torch.zeros(*shape)
+        else: val = torch.randn(*shape, generator=gen) * (std if std is not None else (1.0 / shape[-1]) ** 0.5)
+        return g.create_variable(name, val, True)
+
+    def gemm(inp, name, cin, cout):
+        return g.create_operation('Gemm', name, [inp, param(name + '_w', cout, cin), param(name + '_b', cout, std=0)])
+
+    def layer_norm(inp, name):
+        return g.create_operation('LayerNormalization', name, [inp, param(name + '_w', dim, ones=True), param(name + '_b', dim, std=0)])
+    x = g.create_variable('input'); g.inputs['input'] = x
+    h = g.create_operation('Conv', 'patch_embed', [x, param('patch_w', dim, 3, patch, patch, std=(1.0 / (3 * patch * patch)) ** 0.5),
+                                                  param('patch_b', dim, std=0)], {'strides': patch})
+    h = g.create_operation('Reshape', 'patch_flat', [h], {'shape': (-1, dim, tokens - 1)})
+    h = g.create_operation('Transpose', 'patch_tokens', [h], {'perm': (0, 2, 1)})
+    h = g.create_operation('Concat', 'cat_cls', [param('cls_token', 1, 1, dim, std=0.02), h], {'axis': 1})
+    h = g.create_operation('Add', 'add_pos', [h, param('pos_embed', 1, tokens, dim, std=0.02)])
+    for i in range(depth):
+        p = f'blk{i}_'
+        a = layer_norm(h, p + 'ln1')
+        qkv = gemm(a, p + 'qkv', dim, 3 * dim)
+        parts = []
+        for k, nm in enumerate('qkv'):
+            t = g.create_operation('Slice', p + nm + '_slice', [qkv], {'axis': 2, 'start': k * dim, 'length': dim})
+            t = g.create_operation('Reshape', p + nm + '_heads', [t], {'shape': (-1, tokens, heads, hd)})
+            parts.append(g.create_operation('Transpose', p + nm + '_t', [t], {'perm': (0, 2, 3, 1) if nm == 'k' else (0, 2, 1, 3)}))
+        att = g.create_operation('MatMul', p + 'qk', [parts[0], parts[1]])
+        att = g.create_operation('Mul', p + 'scale', [att], {'value': hd ** -0.5})
+        att = g.create_operation('Softmax', p + 'softmax', [att], {'axis': -1})
+        ctx = g.create_operation('MatMul', p + 'av', [att, parts[2]])
+        ctx = g.create_operation('Transpose', p + 'ctx_t', [ctx], {'perm': (0, 2, 1, 3)})
+        ctx = g.create_operation('Reshape', p + 'ctx', [ctx], {'shape': (-1, tokens, dim)})
+        h = g.create_operation('Add', p + 'res1', [gemm(ctx, p + 'proj', dim, dim), h])
+        m = layer_norm(h, p + 'ln2')
+        m = g.create_operation('Gelu', p + 'gelu', [gemm(m, p + 'fc1', dim, mlp_dim)])
+        h = g.create_operation('Add', p + 'res2', [gemm(m, p + 'fc2', mlp_dim, dim), h])
+    h = layer_norm(h, 'ln_f')
+    h = g.create_operation('Slice', 'cls_out', [h], {'axis': 1, 'start': 0, 'length': 1})
+    h = g.create_operation('Reshape', 'cls_flat', [h], {'shape': (-1, dim)})
+    y = gemm(h, 'head', dim, num_classes)
     g.outputs[y.name] = y
     return g
 

@@ -729,3 +729,47 @@ def test_reuse_activations_equals_second_forward():
     _, ref_mixed = run(True)
     p, got = run(True, reuse_activations=True)
     assert p.replayed_batches == 0 and got == ref_mixed and ref_mixed != ref
+
+
+def test_vit_b16_fp8_calibration():
+    """BASELINE config 4 at full size: ViT-B/16 topology (86.6 M parameters, 197 tokens), FP8 E4M3 simulation
+    with the TRT_FP8 policy (inputs of Conv / Gemm / MatMul only; power-of-2 scales from the 'floating'
+    observer).  Every activated config carries candidate scales, the fake-quantised operands the executor
+    feeds to an attention MatMul and a per-channel weight equal the oracle's FP8 rounding bit for bit, and
+    the FP8 network stays close to the FP32 one."""
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    graph = harness.vit_graph(seed=0)
+    harness.quantize_graph_fp8(graph)
+    ex = harness.TorchExecutor(graph, DEV)
+    g = torch.Generator().manual_seed(6)
+    batches = [torch.randn(2, 3, 224, 224, generator=g).to(DEV) for _ in range(8)]
+    fp32_out = ex.forward(batches[0])[0].clone()              # every config still INITIAL: plain FP32 forward
+    harness.ParameterQuantizePass().optimize(graph)
+    RuntimeCalibrationPass().optimize(graph, dataloader=batches, executor=ex, calib_steps=8)
+    cands = {.0078125, .03125, .125, 1.0, 4.0, 16.0, 64.0}
+    n_act = n_w = 0
+    for op in graph.operations.values():
+        for cfg, var in op.config_with_variable:
+            if cfg.state.value != 4: continue
+            assert all(float(s) in cands for s in cfg.scale.reshape(-1).tolist())
+            n_w += var.is_parameter; n_act += not var.is_parameter
+    assert (n_act, n_w) == (98, 50)
+    seen = {}
+
+    class Spy:
+        def __init__(self, key): self.key = key
+        def pre_forward_hook(self, inputs, quant_inputs, quant_configs):
+            seen[self.key] = (inputs, quant_inputs, quant_configs)
+            return quant_inputs
+        def post_forward_hook(self, outputs, quant_outputs, quant_configs): return quant_outputs
+    q_out = ex.forward(batches[0], hooks={'blk0_qk': Spy('qk'), 'blk5_qkv': Spy('qkv')})[0]
+    raw, q, cfgs = seen['qk']                                  # attention scores: both operands are activations
+    for r, y, c in zip(raw, q, cfgs):
+        want = O.fq_float_t(r.contiguous().cpu().numpy(), c.scale.cpu().numpy().reshape(1), c.offset.cpu().numpy().reshape(1))
+        assert np.array_equal(y.contiguous().cpu().numpy().view(np.uint32), want.view(np.uint32))
+    raw, q, cfgs = seen['qkv']                                 # weight: per-channel FP8
+    want = O.fq_float_c(raw[1].cpu().numpy(), cfgs[1].scale.cpu().numpy(), cfgs[1].offset.cpu().numpy(), 0)
+    assert np.array_equal(q[1].cpu().numpy().view(np.uint32), want.view(np.uint32))
+    cos = torch.nn.functional.cosine_similarity(q_out.flatten(), fp32_out.flatten(), dim=0)
+    assert torch.isfinite(q_out).all() and float(cos) > 0.98, float(cos)
