@@ -773,3 +773,49 @@ def test_vit_b16_fp8_calibration():
     assert np.array_equal(q[1].cpu().numpy().view(np.uint32), want.view(np.uint32))
     cos = torch.nn.functional.cosine_similarity(q_out.flatten(), fp32_out.flatten(), dim=0)
     assert torch.isfinite(q_out).all() and float(cos) > 0.98, float(cos)
+
+
+def _sharded_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        q.put((rank, _calibrate_config3(list(range(rank, 8, world)), dist.group.WORLD)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _calibrate_config3(batch_ids, group):
+    """BASELINE config 3 in miniature: per-channel ASYMMETRIC int8 weights (minmax) + per-tensor asymmetric
+    activations by MSE clipping search, on the batches `batch_ids` of a fixed 8-batch set."""
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    g = torch.Generator().manual_seed(12)
+    batches = [torch.rand(4, 3, 24, 24, generator=g) - 0.4 for _ in range(8)]
+    graph = harness.small_cnn_graph(seed=3)
+    harness.quantize_graph(graph, 'mse', symmetrical=False, weight_symmetrical=False)
+    ex = harness.TorchExecutor(graph, DEV)
+    harness.ParameterQuantizePass().optimize(graph)
+    p = RuntimeCalibrationPass(method='mse', process_group=group, check_steps=False)
+    p.optimize(graph, dataloader=[batches[i].to(DEV) for i in batch_ids], executor=ex, calib_steps=len(batch_ids))
+    torch.cuda.synchronize()
+    return [(v.name, c.scale.reshape(-1).tolist(), c.offset.reshape(-1).tolist())
+            for op in graph.operations.values() for c, v in op.config_with_variable if c.state.value == 4]
+
+
+def test_sharded_mse_calibration_equals_union():
+    """Two ranks (gloo, sharing this GPU), each calibrating half of the batches with the histogram /
+    range all-reduce of distributed.merge_observers, render exactly the scales and offsets of one process
+    over all batches -- integer SUM and float MIN/MAX are order independent."""
+    import torch.multiprocessing as mp
+    want = _calibrate_config3(list(range(8)), None)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs: p.join(timeout=60)
+    assert len(want) >= 9 and any(len(s) > 1 for _, s, _ in want)           # activations + per-channel weights
+    assert any(o != 0 for _, _, off in want for o in off)                   # asymmetric: non-zero offsets
+    assert res[0] == want and res[1] == want
