@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run through gpurun / at round end)')
+    # a fresh checkout has no built artefacts (they are git-ignored): build the HIP library and the
+    # oracle once, exactly as the driver's build() check does
+    needed = [os.path.join(ROOT, 'ppq_amd', 'libppq_hip.so'), os.path.join(ROOT, 'oracle', 'libppq_oracle.so')]
+    if not all(os.path.exists(p) for p in needed):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 def pytest_collection_modifyitems(config, items):
