@@ -66,10 +66,11 @@ def build_workload(dev, bins, method, cache_params=False, fuse_params=True):
 
 
 def run_pass(graph, ex, batches, steps, method, async_observe=False, hip_graph=False, batch_observations=True,
-             reuse_activations=False):
+             reuse_activations=False, queue_bytes=None):
     from ppq_amd.calibration import RuntimeCalibrationPass
     p = RuntimeCalibrationPass(method=method, check_steps=False, async_observe=async_observe, use_hip_graph=hip_graph,
-                               batch_observations=batch_observations, reuse_activations=reuse_activations)
+                               batch_observations=batch_observations, reuse_activations=reuse_activations,
+                               queue_bytes=queue_bytes)
     if TRACE_STEPS is not None:          # --trace-steps: host timestamp + device event after every forward
         inner = p._forward
 
@@ -154,6 +155,7 @@ def main():
     ap.add_argument('--trace-steps', type=int, default=0, help='debug: per-forward host / device timestamps in the JSON line')
     ap.add_argument('--reuse-activations', type=int, default=0,
                     help='OPT-IN, off for the headline number: keep the phase-1 activations in HBM and bin them in phase 2 instead of running the forward again')
+    ap.add_argument('--queue-mib', type=int, default=0, help='debug: ObservationQueue flush threshold (MiB), 0 = default')
     ap.add_argument('--cache-params', type=int, default=0, help='keep fake-quantised weights resident between forwards')
     ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
     args = ap.parse_args()
@@ -191,7 +193,7 @@ def main():
     t0 = time.perf_counter()
     if args.trace_steps: ev0.record()
     p = run_pass(graph, ex, batches, args.steps, args.method, bool(args.async_observe), {'0': False, '1': True, 'auto': 'auto'}[args.hip_graph],
-                 bool(args.batch_observations), bool(args.reuse_activations))
+                 bool(args.batch_observations), bool(args.reuse_activations), (args.queue_mib << 20) or None)
     barrier(world)
     elapsed = time.perf_counter() - t0
     trace = None
@@ -217,7 +219,8 @@ def main():
         torch.cuda.synchronize()
         _lib.lib.ppqhip_prof_enable(1)
         if world == 1:
-            run_pass(graph2, ex2, batches, args.steps, args.method, False, False, bool(args.batch_observations))   # eager, one stream -> clean event pairs
+            run_pass(graph2, ex2, batches, args.steps, args.method, False, False, bool(args.batch_observations), False,
+                     (args.queue_mib << 20) or None)   # eager, one stream -> clean event pairs
         else:   # collectives need every rank; profile the local (non-merged) statistics path only
             from ppq_amd.calibration import RuntimeCalibrationPass
             pp = RuntimeCalibrationPass(method=args.method, check_steps=False, async_observe=False, use_hip_graph=False)

@@ -50,7 +50,8 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
     def __init__(self, method: str = None, override: bool = False, calib_steps: int = 32,
                  process_group=None, check_steps: bool = True, async_observe: bool = False,
                  use_hip_graph: bool = False, batch_observations: bool = True,
-                 reuse_activations: bool = False, reuse_budget_bytes: int = 64 << 30) -> None:
+                 reuse_activations: bool = False, reuse_budget_bytes: int = 64 << 30,
+                 queue_bytes: int = None) -> None:
         super().__init__(name='PPQ Runtime Calibration Pass')
         self._method = method
         self._observers: Dict[str, OperationObserver] = {}
@@ -64,6 +65,7 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         self._batch_observations = batch_observations
         self._queue = None
         self._reuse_activations = reuse_activations
+        self._queue_bytes = queue_bytes
         self._reuse_budget = reuse_budget_bytes
         self._replay: list = []            # per phase-1 batch: [(hist observer, activation tensor)]
         self._replay_bytes = 0
@@ -234,7 +236,7 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         self._queue = None
         if self._batch_observations and self._side_stream is None:
             from .observer import ObservationQueue
-            self._queue = ObservationQueue()
+            self._queue = ObservationQueue() if self._queue_bytes is None else ObservationQueue(self._queue_bytes)
         for ob in self._all_tensor_observers(): ob.queue = self._queue
 
         self._replay, self._replay_bytes = [], 0

@@ -99,10 +99,10 @@ class ObservationQueue:
 
     Contract: an observed tensor must not be modified in place between ``observe`` and ``flush``
     (the pass flushes at the end of every forward; executor ops return new tensors).  The queue keeps
-    the tensors alive until then; ``max_pending_bytes`` bounds that (1 GiB by default: launches of
-    >= 1 GiB already run at streaming bandwidth, and a bounded working set keeps the caching allocator
-    from growing new segments mid-calibration)."""
-    def __init__(self, max_pending_bytes: int = 1 << 30):
+    the tensors alive until then; ``max_pending_bytes`` bounds that (4 GiB by default -- one launch per
+    forward of ResNet-50 at batch 32, 2.15 GB; measured in situ: 0.5 / 1 / 4 GiB thresholds give
+    4.0 / 4.7 / 5.0 TB/s for the histogram launch)."""
+    def __init__(self, max_pending_bytes: int = 4 << 30):
         self._minmax = []                  # (tensor, slots)
         self._hist = {}                    # (asymmetric, bins, device) -> [(tensor, rows, p0, p1)]
         self._quantile = {}                # (q, device) -> [(tensor, dest)]
