@@ -54,13 +54,14 @@ def barrier(world):
 TRACE_STEPS = None
 
 
-def build_workload(dev, bins, method, cache_params=False, fuse_params=True):
+def build_workload(dev, bins, method, cache_params=False, fuse_params=True, channels_last=False):
     from ppq_amd import harness
     graph = harness.resnet50_graph(seed=0)
     harness.quantize_graph(graph, method, hist_bins=bins)
     ex = harness.TorchExecutor(graph, dev)
     ex.cache_parameter_quantization = bool(cache_params)
     ex.fuse_parameter_quantization = bool(fuse_params)
+    if channels_last: ex.use_channels_last()
     harness.ParameterQuantizePass().optimize(graph)        # weights: per-channel min-max, left ACTIVATED
     return graph, ex
 
@@ -156,6 +157,7 @@ def main():
     ap.add_argument('--reuse-activations', type=int, default=0,
                     help='OPT-IN, off for the headline number: keep the phase-1 activations in HBM and bin them in phase 2 instead of running the forward again')
     ap.add_argument('--queue-mib', type=int, default=0, help='debug: ObservationQueue flush threshold (MiB), 0 = default')
+    ap.add_argument('--channels-last', type=int, default=0, help='activations and conv weights in channels-last (NHWC) memory format')
     ap.add_argument('--cache-params', type=int, default=0, help='keep fake-quantised weights resident between forwards')
     ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
     args = ap.parse_args()
@@ -171,7 +173,7 @@ def main():
 
     # warm-up: W batches through a complete two-phase pass (MIOpen find, library load, allocator)
     if args.warmup > 0:
-        graph, ex = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params)
+        graph, ex = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params, bool(args.channels_last))
         run_pass(graph, ex, batches[: max(1, min(args.warmup, args.steps))], max(1, min(args.warmup, args.steps)), args.method,
                  bool(args.async_observe), False, bool(args.batch_observations))
         # keep the device under the workload's own load profile for a moment: a GPU that sat idle (fresh
@@ -188,7 +190,7 @@ def main():
     if args.trace_steps:
         TRACE_STEPS = []
         ev0 = torch.cuda.Event(enable_timing=True)
-    graph, ex = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params)
+    graph, ex = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params, bool(args.channels_last))
     barrier(world)
     t0 = time.perf_counter()
     if args.trace_steps: ev0.record()
@@ -215,7 +217,7 @@ def main():
     roof = None
     prof_rows = []
     if rank == 0:
-        graph2, ex2 = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params)
+        graph2, ex2 = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params, bool(args.channels_last))
         torch.cuda.synchronize()
         _lib.lib.ppqhip_prof_enable(1)
         if world == 1:
@@ -269,7 +271,7 @@ def main():
                        'samples': samples, 'batch': args.batch, 'observed_tensors': n_obs,
                        'parallelism': f'dp{world} (batches sharded, 1 all-reduce per phase)',
                        'async_observe': bool(args.async_observe), 'cache_params': bool(args.cache_params),
-                       'fuse_params': bool(args.fuse_params), 'batch_observations': bool(args.batch_observations),
+                       'channels_last': bool(args.channels_last), 'fuse_params': bool(args.fuse_params), 'batch_observations': bool(args.batch_observations),
                        'reuse_activations': bool(args.reuse_activations), 'replayed_batches': p.replayed_batches,
                        'hip_graph': args.hip_graph, 'graph_replays': p.graph_replays,
                        'graph_decisions': [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()}

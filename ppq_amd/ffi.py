@@ -59,6 +59,19 @@ def _f32(t, name):
     _check(t, torch.float32, name + '(Expect to be FP32)')
 
 
+def _dense(t: torch.Tensor, channel_axis=None) -> torch.Tensor:
+    """The tensor the kernels stream, WITHOUT a layout copy where none is needed: per-tensor kernels are
+    order agnostic, so a dense channels-last tensor (MIOpen's preferred activation layout on MI355X) is
+    read in storage order; per-channel kernels may do the same when the channel axis is the outermost
+    one (conv weights [O, I, H, W] in channels-last keep one contiguous I*H*W chunk per output channel).
+    Everything else falls back to ``.contiguous()`` like the reference (linear.cu:106,207)."""
+    if t.is_contiguous(): return t
+    if channel_axis is None or channel_axis % t.dim() == 0:
+        if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last): return t
+        if t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d): return t
+    return t.contiguous()
+
+
 def _raise(status: int) -> None:
     if status != 0:
         raise RuntimeError(_KERNEL_FAILURE + _lib.last_error())
@@ -141,13 +154,13 @@ class LinearQuantizePlan:
         self._outs = []
         at = 0
         for k, (value, scale, offset, axis, qmin, qmax) in enumerate(items):
-            v = value.contiguous()
+            v = _dense(value, axis)
             sc, of = scale.contiguous().reshape(-1), offset.contiguous().reshape(-1)
             if axis is None: C, epc = 1, v.numel()
             else: C, epc = _geometry(v.shape, axis)
             if sc.numel() != C or of.numel() != C:
                 raise RuntimeError(_KERNEL_FAILURE + f'LinearQuantizePlan: item {k} needs {C} scales / offsets')
-            out = self._arena[at: at + v.numel()].view(v.shape)
+            out = self._arena[at: at + v.numel()].as_strided(v.shape, v.stride())     # same memory format as the input
             at += (v.numel() + 3) // 4 * 4          # every output starts 16-B aligned
             self._keep.append((v, sc, of))
             self._outs.append(out)
@@ -173,7 +186,7 @@ class _HipExtension:
     @ staticmethod
     def QuantizeTensor_LT(value, scale, offset, clip_min: int, clip_max: int, rounding: int) -> torch.Tensor:
         _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset')
-        v = value.contiguous()
+        v = _dense(value)
         out = torch.empty_like(v)
         with _DeviceOf(v):
             _raise(lib.ppqhip_fq_linear_t(v.data_ptr(), scale.data_ptr(), offset.data_ptr(), out.data_ptr(),
@@ -184,7 +197,7 @@ class _HipExtension:
     def QuantizeTensor_LC(value, scale, offset, clip_min: int, clip_max: int, channel_axis: int,
                           rounding: int) -> torch.Tensor:
         _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset')
-        v = value.contiguous()
+        v = _dense(value, channel_axis)
         C, epc = _geometry(v.shape, channel_axis)
         if scale.numel() < C or offset.numel() < C:
             raise RuntimeError(_KERNEL_FAILURE + f'scale/offset need {C} elements for channel axis {channel_axis}')
@@ -226,7 +239,7 @@ class _HipExtension:
     def QuantizeTensor_FT(value, scale, offset, exponent: int, mantissa: int, clip_min: float, clip_max: float,
                           rounding: int) -> torch.Tensor:
         _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset')
-        v = value.contiguous()
+        v = _dense(value)
         out = torch.empty_like(v)
         with _DeviceOf(v):
             _raise(lib.ppqhip_fq_float_t(v.data_ptr(), scale.data_ptr(), offset.data_ptr(), out.data_ptr(),
@@ -284,7 +297,7 @@ class _HipExtension:
     @ staticmethod
     def Histogram_T(value, hist_scale: float, clip_outliers: bool, hist) -> None:
         _f32(value, 'Value'); _HipExtension._check_hist(hist)
-        v = value.contiguous()
+        v = _dense(value)
         with _DeviceOf(v):
             ws = _workspace(v.device, lib.ppqhip_hist_workspace_bytes(v.numel(), hist.numel()))
             _raise(lib.ppqhip_hist_sym_t(v.data_ptr(), v.numel(), float(hist_scale), int(bool(clip_outliers)),
@@ -293,7 +306,7 @@ class _HipExtension:
     @ staticmethod
     def Histogram_Asymmetric_T(min: float, max: float, value, clip_outliers: bool, hist) -> None:
         _f32(value, 'Value'); _HipExtension._check_hist(hist)
-        v = value.contiguous()
+        v = _dense(value)
         with _DeviceOf(v):
             ws = _workspace(v.device, lib.ppqhip_hist_workspace_bytes(v.numel(), hist.numel()))
             _raise(lib.ppqhip_hist_asym_t(v.data_ptr(), v.numel(), float(min), float(max),
@@ -314,7 +327,7 @@ class _HipExtension:
     @ staticmethod
     def Quantile_T(source, q: float) -> torch.Tensor:
         _f32(source, 'Value')
-        v = source.contiguous()
+        v = _dense(source)
         dest = torch.empty(2, dtype=torch.float32, device=v.device)
         with _DeviceOf(v):
             ws = _workspace(v.device, lib.ppqhip_quantile_workspace_bytes(v.numel()))
@@ -331,7 +344,7 @@ class _HipExtension:
         for v in sources:
             _f32(v, 'Value')
             if v.device != sources[0].device: raise RuntimeError(_KERNEL_FAILURE + 'Quantile_T_Multi: one device per call')
-            vs.append(v.contiguous())
+            vs.append(_dense(v))
         if dests is None: dests = [torch.empty(2, dtype=torch.float32, device=vs[0].device) for _ in vs]
         if len(dests) != len(vs): raise RuntimeError(_KERNEL_FAILURE + 'sources / dests length mismatch')
         for d in dests:
@@ -436,7 +449,7 @@ class _HipExtension:
     def MinMax_T(value, minmax) -> None:
         """minmax: float32[2] on the GPU, accumulated in place; seed with [+inf, -inf]."""
         _f32(value, 'Value'); _f32(minmax, 'MinMax')
-        v = value.contiguous()
+        v = _dense(value)
         with _DeviceOf(v):
             ws = _workspace(v.device, lib.ppqhip_minmax_workspace_bytes(v.numel()))
             _raise(lib.ppqhip_minmax_t(v.data_ptr(), v.numel(), minmax.data_ptr(), ws.data_ptr(), _stream()))
@@ -448,7 +461,7 @@ class _HipExtension:
         _f32(value, 'Value'); _f32(slots, 'Slots')
         if slots.numel() != 2 * lib.ppqhip_minmax_slots() or not slots.is_contiguous():
             raise RuntimeError(_KERNEL_FAILURE + f'slots must be a contiguous [{lib.ppqhip_minmax_slots()}, 2] tensor')
-        v = value.contiguous()
+        v = _dense(value)
         with _DeviceOf(v):
             _raise(lib.ppqhip_minmax_t_slots(v.data_ptr(), v.numel(), slots.data_ptr(), _stream()))
 
@@ -463,7 +476,7 @@ class _HipExtension:
             _f32(v, 'Value'); _f32(sl, 'Slots')
             if sl.numel() != S or not sl.is_contiguous() or sl.device != values[0].device or v.device != values[0].device:
                 raise RuntimeError(_KERNEL_FAILURE + 'slots must be contiguous [minmax_slots(), 2] tensors on the values\' device')
-            vs.append(v.contiguous())
+            vs.append(_dense(v))
         jobs = np.empty(len(vs), dtype=_MINMAX_JOB)
         jobs['x'] = [v.data_ptr() for v in vs]
         jobs['slots'] = [sl.data_ptr() for sl in slots]
@@ -485,7 +498,7 @@ class _HipExtension:
             if (r.ndim != 2 or r.shape[0] != R or r.shape[1] != bins or not r.is_contiguous()
                     or r.device != values[0].device or v.device != values[0].device):
                 raise RuntimeError(_KERNEL_FAILURE + f'rows must be contiguous [{R}, {bins}] tensors on the values\' device')
-            vs.append(v.contiguous())
+            vs.append(_dense(v))
         jobs = np.empty(len(vs), dtype=_HIST_JOB)
         jobs['x'] = [v.data_ptr() for v in vs]
         jobs['rows'] = [r.data_ptr() for r in rows]
@@ -509,7 +522,7 @@ class _HipExtension:
         R = lib.ppqhip_hist_rows()
         if rows.ndim != 2 or rows.shape[0] != R or not rows.is_contiguous():
             raise RuntimeError(_KERNEL_FAILURE + f'rows must be a contiguous [{R}, bins] tensor')
-        v = value.contiguous()
+        v = _dense(value)
         with _DeviceOf(v):
             _raise(lib.ppqhip_hist_sym_t_rows(v.data_ptr(), v.numel(), float(hist_scale), int(bool(clip_outliers)),
                                               rows.data_ptr(), rows.shape[1], _stream()))
@@ -520,7 +533,7 @@ class _HipExtension:
         R = lib.ppqhip_hist_rows()
         if rows.ndim != 2 or rows.shape[0] != R or not rows.is_contiguous():
             raise RuntimeError(_KERNEL_FAILURE + f'rows must be a contiguous [{R}, bins] tensor')
-        v = value.contiguous()
+        v = _dense(value)
         with _DeviceOf(v):
             _raise(lib.ppqhip_hist_asym_t_rows(v.data_ptr(), v.numel(), float(min), float(max),
                                                int(bool(clip_outliers)), rows.data_ptr(), rows.shape[1], _stream()))
@@ -534,7 +547,7 @@ class _HipExtension:
     @ staticmethod
     def MinMax_C(value, channel_axis: int, mins, maxs) -> None:
         _f32(value, 'Value'); _f32(mins, 'Mins'); _f32(maxs, 'Maxs')
-        v = value.contiguous()
+        v = _dense(value, channel_axis)
         C, epc = _geometry(v.shape, channel_axis)
         if mins.numel() != C or maxs.numel() != C:
             raise RuntimeError(_KERNEL_FAILURE + f'mins / maxs need {C} elements')

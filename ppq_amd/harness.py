@@ -168,8 +168,26 @@ class TorchExecutor:
         self._plan_signature = None
         self._fused: Dict[tuple, torch.Tensor] = {}
         self._delegates: Dict[object, Callable] = {}
+        self.channels_last = False                    # see use_channels_last()
         for v in graph.variables.values():
             if v.is_parameter and v.value is not None: v.value = v.value.to(device)
+
+    def use_channels_last(self) -> 'TorchExecutor':
+        """Keep 4-D activations and conv weights in channels-last memory format: MIOpen's FP32 convolutions
+        are ~8 % faster in NHWC on MI355X (tools/conv_format_probe.py) and the per-tensor statistics /
+        fake-quant kernels stream any dense layout in storage order (ffi._dense), so no layout copy appears
+        anywhere on the calibration path.  Values are those of the NCHW run up to the convolution
+        algorithm's own rounding."""
+        self.channels_last = True
+        for v in self._graph.variables.values():
+            if v.is_parameter and isinstance(v.value, torch.Tensor) and v.value.dim() == 4:
+                v.value = v.value.contiguous(memory_format=torch.channels_last)
+        return self
+
+    def _place(self, value: torch.Tensor) -> torch.Tensor:
+        value = value.to(self._device)
+        if self.channels_last and value.dim() == 4: value = value.contiguous(memory_format=torch.channels_last)
+        return value
 
     def register_quantize_delegate(self, config, delegator: Callable) -> None:
         """ppq/executor/torch.py:296-323: a delegator takes over the quantisation of one config."""
@@ -193,7 +211,7 @@ class TorchExecutor:
         """ppq/executor/torch.py:654-730: run only `operations` (already in execution order) on the
         given feeds -- the block forward of the training based passes."""
         g = self._graph
-        for name, value in feed_dict.items(): g.variables[name].value = value.to(self._device)
+        for name, value in feed_dict.items(): g.variables[name].value = self._place(value)
         results = [None] * len(output_names)
         self._fused_parameters()
         for op in operations:
@@ -276,7 +294,7 @@ class TorchExecutor:
         g = self._graph
         if isinstance(inputs, torch.Tensor): inputs = {next(iter(g.inputs)): inputs}
         elif isinstance(inputs, (list, tuple)): inputs = {k: v for k, v in zip(g.inputs, inputs)}
-        for name, value in inputs.items(): g.variables[name].value = value.to(self._device)
+        for name, value in inputs.items(): g.variables[name].value = self._place(value)
         if output_names is None: output_names = list(g.outputs)
         results = [None] * len(output_names)
         visited = set()

@@ -819,3 +819,56 @@ def test_sharded_mse_calibration_equals_union():
     assert len(want) >= 9 and any(len(s) > 1 for _, s, _ in want)           # activations + per-channel weights
     assert any(o != 0 for _, _, off in want for o in off)                   # asymmetric: non-zero offsets
     assert res[0] == want and res[1] == want
+
+
+def test_channels_last_tensors_need_no_layout_copy(CUDA):
+    """Dense channels-last tensors are streamed in storage order: per-tensor fake-quant returns the same
+    values in the same memory format, statistics are those of the NCHW tensor, per-channel ops on axis 0
+    (conv weights) too; a per-channel op on axis 1 still goes through the NCHW copy."""
+    from ppq_amd.ffi import LinearQuantizePlan
+    g = torch.Generator().manual_seed(41)
+    x = (torch.randn(4, 24, 9, 7, generator=g) * 3).to(DEV)
+    xcl = x.contiguous(memory_format=torch.channels_last)
+    s, o = torch.tensor([0.05], device=DEV), torch.tensor([3.0], device=DEV)
+    y, ycl = CUDA.LinearQuantize_T(x, s, o, 0, 255, 0), CUDA.LinearQuantize_T(xcl, s, o, 0, 255, 0)
+    assert ycl.is_contiguous(memory_format=torch.channels_last) and torch.equal(y, ycl)
+    h, hcl = torch.zeros(512, dtype=torch.int32, device=DEV), torch.zeros(512, dtype=torch.int32, device=DEV)
+    CUDA.Histogram_T(x, h, 0.02); CUDA.Histogram_T(xcl, hcl, 0.02)
+    assert torch.equal(h, hcl)
+    mm = [torch.tensor([float('inf'), float('-inf')], device=DEV) for _ in range(2)]
+    CUDA.MinMax_T(x, mm[0]); CUDA.MinMax_T(xcl, mm[1])
+    assert torch.equal(mm[0], mm[1]) and torch.equal(CUDA.Quantile(x, 0.99), CUDA.Quantile(xcl, 0.99))
+    w = (torch.randn(24, 4, 3, 3, generator=g) * 0.1).to(DEV)
+    wcl = w.contiguous(memory_format=torch.channels_last)
+    ws, wo = (torch.rand(24, generator=g) * 0.01 + 1e-3).to(DEV), torch.zeros(24, device=DEV)
+    q, qcl = CUDA.LinearQuantize_C(w, ws, wo, 0, -128, 127, 0), CUDA.LinearQuantize_C(wcl, ws, wo, 0, -128, 127, 0)
+    assert qcl.is_contiguous(memory_format=torch.channels_last) and torch.equal(q, qcl)
+    got = LinearQuantizePlan([(wcl, ws, wo, 0, -128, 127), (xcl, s, o, None, 0, 255)]).run()
+    assert got[0].is_contiguous(memory_format=torch.channels_last) and torch.equal(got[0], q) and torch.equal(got[1], y)
+    cs, co = (torch.rand(24, generator=g) * 0.1 + 0.01).to(DEV), torch.zeros(24, device=DEV)
+    assert torch.equal(CUDA.LinearQuantize_C(xcl, cs, co, 1, -128, 127, 0), CUDA.LinearQuantize_C(x, cs, co, 1, -128, 127, 0))
+
+
+def test_channels_last_executor_calibrates_like_nchw():
+    """TorchExecutor.use_channels_last(): same calibration (scales within the convolution algorithms'
+    rounding), activations stay channels-last end to end."""
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    g = torch.Generator().manual_seed(4)
+    batches = [torch.rand(4, 3, 24, 24, generator=g).to(DEV) for _ in range(8)]
+
+    def run(cl):
+        graph = harness.small_cnn_graph(seed=3)
+        harness.quantize_graph(graph, 'kl', hist_bins=2048)
+        ex = harness.TorchExecutor(graph, DEV)
+        if cl: ex.use_channels_last()
+        harness.ParameterQuantizePass().optimize(graph)
+        RuntimeCalibrationPass(method='kl').optimize(graph, dataloader=batches, executor=ex, calib_steps=8)
+        out = ex.forward(batches[0], output_names=['c1_relu_out'])[0]
+        cfgs = [(c, v) for op in graph.operations.values() for c, v in op.config_with_variable if c.state.value == 4]
+        return out, [float(c.scale) for c, v in cfgs if not v.is_parameter], [c.scale.clone() for c, v in cfgs if v.is_parameter]
+    out0, act0, w0 = run(False)
+    out1, act1, w1 = run(True)
+    assert out1.is_contiguous(memory_format=torch.channels_last) and not out0.is_contiguous(memory_format=torch.channels_last)
+    assert all(torch.equal(a, b) for a, b in zip(w0, w1))                    # weights: identical statistics
+    assert act0 == pytest.approx(act1, rel=2e-2) and torch.allclose(out0, out1, rtol=1e-3, atol=1e-3)
