@@ -118,8 +118,29 @@ class LearnedStepSizePass:
     {weights, scales, offsets}, MSE between the quantised and the FP32 block output (+ gamma * weight
     quantisation error), withdraw when the loss did not improve.  The reference's block splitting
     (BlockBuilder, training.py:191-315) is graph plumbing outside this package's scope."""
-    def __init__(self, steps: int = 100, lr: float = 5e-5, gamma: float = 0.0, optimizer=None):
+    def __init__(self, steps: int = 100, lr: float = 5e-5, gamma: float = 0.0, optimizer=None, process_group=None):
         self.steps, self.lr, self.gamma, self.optimizer = steps, lr, gamma, optimizer
+        # data-parallel finetuning (one process per GPU, each with its shard of the batches): gradients of
+        # ALL trainable tensors travel in ONE flat all-reduce per step (a few MB at most for a block --
+        # latency bound on xGMI, so never one collective per tensor), block losses are averaged so every
+        # rank takes the same keep / withdraw decision
+        self.process_group = process_group
+
+    def _world(self) -> int:
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()): return 1
+        return dist.get_world_size(self.process_group)
+
+    def _average(self, tensors: List[torch.Tensor]) -> None:
+        world = self._world()
+        if world == 1 or not tensors: return
+        import torch.distributed as dist
+        flat = torch.cat([t.reshape(-1) for t in tensors])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.process_group)
+        flat /= world
+        pos = 0
+        for t in tensors:
+            n = t.numel(); t.copy_(flat[pos: pos + n].view_as(t)); pos += n
 
     @ staticmethod
     def _loss(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -139,7 +160,10 @@ class LearnedStepSizePass:
 
         def block_loss():
             with torch.no_grad():
-                return float(sum(self._loss(executor.forward(b)[0], f) for b, f in zip(batches, fp_outputs)) / len(batches))
+                loss = sum(self._loss(executor.forward(b)[0], f) for b, f in zip(batches, fp_outputs)) / len(batches)
+                loss = loss.reshape(1).clone()
+                self._average([loss])
+                return float(loss)
         pre_loss = block_loss()
         delegators, tensors = {}, []
         for op in ops:
@@ -173,6 +197,8 @@ class LearnedStepSizePass:
                         w, wc = op.inputs[1].value, op.config.input_quantization_config[1]
                         loss = loss + self._loss(w, PPQuantFunction(w, wc).detach()) * self.gamma
             loss.backward()
+            with torch.no_grad():
+                self._average([t.grad for t in uniq if t.grad is not None])
             opt.step()
         post_loss = block_loss()
         for cfg, d in delegators.items():

@@ -872,3 +872,68 @@ def test_channels_last_executor_calibrates_like_nchw():
     assert out1.is_contiguous(memory_format=torch.channels_last) and not out0.is_contiguous(memory_format=torch.channels_last)
     assert all(torch.equal(a, b) for a, b in zip(w0, w1))                    # weights: identical statistics
     assert act0 == pytest.approx(act1, rel=2e-2) and torch.allclose(out0, out1, rtol=1e-3, atol=1e-3)
+
+
+def _lsq_run(batches, group, steps=4):
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    from ppq_amd.lsq import LearnedStepSizePass
+    graph = harness.small_cnn_graph(seed=5, width=16)
+    harness.quantize_graph(graph, 'minmax')
+    for op in graph.operations.values():
+        for cfg, var in op.config_with_variable:
+            if var.is_parameter and cfg.state.value == 1: cfg.num_of_bits, cfg.quant_min, cfg.quant_max = 4, -8, 7
+    ex = harness.TorchExecutor(graph, DEV)
+    harness.ParameterQuantizePass().optimize(graph)
+    g = torch.Generator().manual_seed(7)
+    calib = [torch.rand(8, 3, 24, 24, generator=g).to(DEV) for _ in range(8)]       # same calibration on every rank
+    RuntimeCalibrationPass(check_steps=False).optimize(graph, dataloader=calib, executor=ex, calib_steps=8)
+    p = LearnedStepSizePass(steps=steps, lr=1e-2, optimizer=torch.optim.SGD, process_group=group)
+    pre, post = p.optimize(graph, [b.to(DEV) for b in batches], ex)
+    torch.cuda.synchronize()
+    # numpy (pickled by value): torch tensors on an mp.Queue travel as shared-memory handles that die with the worker
+    scales = [c.scale.detach().reshape(-1).cpu().numpy() for op in graph.operations.values()
+              for c, v in op.config_with_variable if c.state.value == 4]
+    weights = [v.value.detach().cpu().numpy() for v in graph.variables.values() if v.is_parameter and v.value.dim() == 4]
+    return pre, post, scales, weights
+
+
+def _lsq_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(77)
+        full = [torch.rand(8, 3, 24, 24, generator=g) for _ in range(4)]
+        shard = [b[rank * 4:(rank + 1) * 4] for b in full]                         # each rank: half of every batch
+        q.put((rank, _lsq_run(shard, dist.group.WORLD)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_lsq_equals_big_batch():
+    """LearnedStepSizePass(process_group=...): two ranks, each finetuning on half of every batch with ONE
+    flat gradient all-reduce per step, stay in lock step bit for bit and follow the trajectory of one
+    process on the full batches."""
+    import torch.multiprocessing as mp
+    g = torch.Generator().manual_seed(77)
+    full = [torch.rand(8, 3, 24, 24, generator=g) for _ in range(4)]
+    pre, post, scales, weights = _lsq_run(full, None)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 7) % 2000)
+    procs = [ctx.Process(target=_lsq_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs: p.join(timeout=60)
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]                       # averaged losses: same decision
+    assert res[0][0] == pytest.approx(pre, rel=1e-4)
+    # LSQ scales its step-size gradient by 1/sqrt(numel * qmax) (linear.cu:299,402), and an activation has
+    # half the elements on each rank: the data-parallel trajectory is the average of per-rank LSQ gradients,
+    # close to -- not identical with -- the big-batch one.  Weight gradients are plain means and agree.
+    assert res[0][1] <= res[0][0]
+    for r in (0, 1):
+        for a, b in zip(res[r][2], scales): assert np.allclose(a, b, rtol=2e-2, atol=1e-7)
+        for a, b in zip(res[r][3], weights): assert np.allclose(a, b, rtol=1e-2, atol=1e-4)
+    for a, b in zip(res[0][2], res[1][2]): assert np.array_equal(a, b)             # ranks stay in lock step
+    for a, b in zip(res[0][3], res[1][3]): assert np.array_equal(a, b)
