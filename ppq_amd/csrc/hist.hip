@@ -5,11 +5,12 @@
 // floor((x - min) / hist_scale) [asym] with the IEEE quotient and a saturating float->int
 // conversion (NaN -> bin 0); b > bins-1 (asym: or b < 0) is dropped (clip_outliers) or clamped.
 //
-// Design (the kernel is VALU-issue bound on gfx950, not LDS- or HBM-bound: every wave64 VALU
-// instruction occupies its SIMD for ~4 cycles, so the instruction count per element is what is
-// optimised):
-//   * one streaming pass, 16-B loads, software pipelined: the next trip's kHistU loads per lane are
-//     in flight while the current trip is binned (and while the LDS histogram is zeroed);
+// Design (PMC: VALU busy ~63 %, half of the wave cycles waiting on memory, LDS bank conflicts
+// irrelevant -- the kernel sits between VALU issue and memory latency, ~17 VALU instructions per
+// element, every wave64 VALU instruction occupying its SIMD for ~4 cycles):
+//   * one streaming pass, 16-B BRANCH-FREE loads (clamped index; a conditional load costs a branch
+//     and an immediate vmcnt(0)), two register tiles that ping-pong: the next tile's kHistU loads
+//     per lane are in flight while the current one is binned (and while the LDS histogram is zeroed);
 //   * the quotient comes from a reciprocal multiply with a provable exactness test and a rare
 //     true-division fallback (quotient_is_safe), ONE divergent region per float4;
 //   * every wavefront group owns a private LDS copy of the histogram (ds_add_u32); nothing is
@@ -21,7 +22,10 @@
 //   * no global atomics on the hot path: every workgroup stores its merged histogram to a scratch
 //     row with plain coalesced stores and hist_reduce_kernel adds the column sums into the caller's
 //     histogram (hundreds of workgroups x thousands of bins of same-line device atomics serialise
-//     at ~12 ns each and would cost more than the streaming pass).
+//     at ~12 ns each and would cost more than the streaming pass); observers that see many batches
+//     keep the rows resident instead (accumulate mode) and fold them once;
+//   * hist_t_multi_kernel bins MANY tensors in one launch (job table in the kernel arguments): what a
+//     calibration forward needs, where the tensors are 0.1 .. 100 MB and launch latency dominates.
 #include <cstdlib>
 
 #include "common.hpp"
