@@ -132,6 +132,14 @@ int ppqhip_hist_sym_c(const float* x, int64_t n, int64_t num_channel, int64_t el
                       float hist_scale, int clip_outliers, int32_t* hist, int64_t num_bins,
                       void* stream);
 
+/* MI355X-native extension: the same per-channel histogram with ONE hist_scale PER
+ * CHANNEL (device float[num_channel]) -- channel c is binned exactly as ppqhip_hist_sym_t would bin the
+ * slice of channel c with hist_scales[c].  Feeds the per-channel KL search the reference refuses
+ * (range.py:288-289). */
+int ppqhip_hist_sym_c_scales(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
+                             const float* hist_scales, int clip_outliers, int32_t* hist,
+                             int64_t num_bins, void* stream);
+
 /* order statistics ---------------------------------------------------------------------------- */
 /* replaces Quantile_T, sort.cu:42-59 (CUDA.Quantile ffi.py:171-176): dest[0] = sorted[rn(n*q)],
  * dest[1] = sorted[rn(n*(1-q))], indices clamped to [0, n-1].  Implemented as a radix select, not

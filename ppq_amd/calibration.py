@@ -259,7 +259,7 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         # remove one-phase observers (calibration.py:192-201)
         pop_list = []
         for op_name, observer in self._observers.items():
-            if all([type(var_observer) not in {TorchHistObserver, TorchMSEObserver}
+            if all([not isinstance(var_observer, TorchHistObserver)            # kl, mse, kl_channel: two-phase
                     for var_observer in observer.observers()]):
                 pop_list.append(op_name)
         for op_name in pop_list:

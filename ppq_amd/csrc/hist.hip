@@ -385,15 +385,17 @@ __global__ __launch_bounds__(kBlock) void hist_t_global_kernel(const float* __re
 template <bool CLIP>
 __global__ __launch_bounds__(kBlock) void hist_c_row_kernel(const float* __restrict__ x, uint32_t epc, FastDiv chunks,
                                                             FastDiv num_channel, uint32_t chunk_elems, BinRule rule,
-                                                            int copies, int* __restrict__ hist) {
+                                                            int copies, int* __restrict__ hist,
+                                                            const float* __restrict__ scales) {
     extern __shared__ int lds[];
     const int pitch = rule.bins + kTrash;
     lds_hist_zero(lds, copies * pitch);
-    WaveAcc<false, CLIP, true> acc;
-    acc.init(lds + ((threadIdx.x >> 6) % copies) * pitch, rule);
     const uint32_t row = fdiv(blockIdx.x, chunks);
     const uint32_t chunk = blockIdx.x - row * chunks.d;
     const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
+    if (scales != nullptr) { rule.hs = scales[c]; rule.rcp = 1.0f / rule.hs; }     // per-channel hist_scale
+    WaveAcc<false, CLIP, true> acc;
+    acc.init(lds + ((threadIdx.x >> 6) % copies) * pitch, rule);
     const uint32_t lo = chunk * chunk_elems;
     const uint32_t hi = min(lo + chunk_elems, epc);
     const float* xr = x + (size_t)row * epc;
@@ -411,15 +413,16 @@ __global__ __launch_bounds__(kBlock) void hist_c_row_kernel(const float* __restr
 
 __global__ __launch_bounds__(kBlock) void hist_c_global_kernel(const float* __restrict__ x, uint32_t n,
                                                                FastDiv elem_per_channel, FastDiv num_channel,
-                                                               BinRule rule, int* __restrict__ hist) {
+                                                               BinRule rule, int* __restrict__ hist,
+                                                               const float* __restrict__ scales) {
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
+        const uint32_t row = fdiv(i, elem_per_channel);
+        const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
+        BinRule r = rule;
+        if (scales != nullptr) r.hs = scales[c];
         int b;
-        if (bin_of(x[i], rule, &b)) {
-            const uint32_t row = fdiv(i, elem_per_channel);
-            const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
-            atomicAdd(&hist[(size_t)c * rule.bins + b], 1);
-        }
+        if (bin_of(x[i], r, &b)) atomicAdd(&hist[(size_t)c * rule.bins + b], 1);
     }
 }
 
@@ -640,8 +643,9 @@ int ppqhip_hist_rows_finish(const int32_t* rows, int64_t num_bins, int32_t* hist
     return finish_launch("hist_rows_finish");
 }
 
-int ppqhip_hist_sym_c(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
-                      float hist_scale, int clip_outliers, int32_t* hist, int64_t num_bins, void* stream) {
+static int hist_sym_c_impl(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
+                           float hist_scale, const float* scales, int clip_outliers, int32_t* hist, int64_t num_bins,
+                           void* stream) {
     if (int st = validate(n, num_bins, "hist_sym_c")) return st;
     if (num_channel <= 0 || elem_per_channel <= 0 || n % (num_channel * elem_per_channel) != 0) {
         set_error("hist_sym_c: Kernel Failure, Histogram shape is invalid."); return PPQHIP_ERR_INVALID_VALUE;
@@ -658,16 +662,28 @@ int ppqhip_hist_sym_c(const float* x, int64_t n, int64_t num_channel, int64_t el
         if (rule.clip)
             hipLaunchKernelGGL((hist_c_row_kernel<true>), dim3((uint32_t)(rows * chunks)), dim3(kBlock),
                                lds_bytes(rule.bins, copies), s, x, (uint32_t)elem_per_channel, make_fastdiv(chunks), nc,
-                               chunk_elems, rule, copies, hist);
+                               chunk_elems, rule, copies, hist, scales);
         else
             hipLaunchKernelGGL((hist_c_row_kernel<false>), dim3((uint32_t)(rows * chunks)), dim3(kBlock),
                                lds_bytes(rule.bins, copies), s, x, (uint32_t)elem_per_channel, make_fastdiv(chunks), nc,
-                               chunk_elems, rule, copies, hist);
+                               chunk_elems, rule, copies, hist, scales);
     } else {
         hipLaunchKernelGGL(hist_c_global_kernel, dim3(stream_grid(n, kBlock * 4)), dim3(kBlock), 0, s, x, (uint32_t)n,
-                           make_fastdiv((uint32_t)elem_per_channel), nc, rule, hist);
+                           make_fastdiv((uint32_t)elem_per_channel), nc, rule, hist, scales);
     }
     return finish_launch("hist_sym_c");
+}
+
+int ppqhip_hist_sym_c(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
+                      float hist_scale, int clip_outliers, int32_t* hist, int64_t num_bins, void* stream) {
+    return hist_sym_c_impl(x, n, num_channel, elem_per_channel, hist_scale, nullptr, clip_outliers, hist, num_bins, stream);
+}
+
+int ppqhip_hist_sym_c_scales(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
+                             const float* hist_scales, int clip_outliers, int32_t* hist, int64_t num_bins,
+                             void* stream) {
+    if (hist_scales == nullptr) { set_error("hist_sym_c_scales: hist_scales is null"); return PPQHIP_ERR_INVALID_VALUE; }
+    return hist_sym_c_impl(x, n, num_channel, elem_per_channel, 1.0f, hist_scales, clip_outliers, hist, num_bins, stream);
 }
 
 int ppqhip_fq_linear_t_hist_sym(const float* x, const float* scale, const float* offset, float* out, int64_t n,

@@ -325,6 +325,18 @@ class _HipExtension:
                                          int(bool(clip_outliers)), hist.data_ptr(), hist.numel() // C, _stream()))
 
     @ staticmethod
+    def Histogram_C_Scales(value, channel_axis: int, hist_scales, clip_outliers: bool, hist) -> None:
+        """Per-channel histogram with one hist_scale per channel (device float32 [C]); hist int32 [C, bins]."""
+        _f32(value, 'Value'); _f32(hist_scales, 'Hist scales'); _HipExtension._check_hist(hist)
+        v = value.contiguous()
+        C, epc = _geometry(v.shape, channel_axis)
+        if hist.numel() % C != 0 or hist_scales.numel() != C or not hist.is_contiguous():
+            raise RuntimeError(_KERNEL_FAILURE + 'Histogram shape is invalid.')
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_hist_sym_c_scales(v.data_ptr(), v.numel(), C, epc, hist_scales.contiguous().data_ptr(),
+                                                int(bool(clip_outliers)), hist.data_ptr(), hist.numel() // C, _stream()))
+
+    @ staticmethod
     def Quantile_T(source, q: float) -> torch.Tensor:
         _f32(source, 'Value')
         v = _dense(source)
@@ -672,6 +684,11 @@ class CUDA:
     @ staticmethod
     def Histogram_C(tensor, channel_axis: int, histogram, scale: float, clip_outliers: bool = True):
         HIP_EXTENSION.Histogram_C(tensor, channel_axis, scale, clip_outliers, histogram)
+        return histogram
+
+    @ staticmethod
+    def Histogram_C_Scales(tensor, channel_axis: int, histogram, scales, clip_outliers: bool = True):
+        HIP_EXTENSION.Histogram_C_Scales(tensor, channel_axis, scales, clip_outliers, histogram)
         return histogram
 
     @ staticmethod

@@ -415,6 +415,56 @@ class TorchHistObserver(TorchMinMaxObserver):
             _set_per_tensor(self._quant_cfg, scale, offset, self._hist.device)
 
 
+class ChannelwiseKLObserver(TorchHistObserver):
+    """SURVEY section 8f-4 -- a capability the reference lacks ('kl' refuses PER_CHANNEL configs,
+    range.py:288-289): the two-phase KL calibration PER CHANNEL.  Phase 1 = per-channel min/max
+    (MinMax_C), phase 2 = one histogram per channel binned with that channel's own hist_scale
+    (Histogram_C_Scales), render = the batched KLLosses search over the C histograms and the
+    reference's scale formula channel by channel.  By construction channel c gets exactly the scale the
+    per-tensor 'kl' observer renders for the slice of channel c.  Registered as 'kl_channel'."""
+    def __init__(self, watch_on, quant_cfg, hist_bins: int = OBSERVER_KL_HIST_BINS):
+        super().__init__(watch_on, quant_cfg, hist_bins)
+        if not quant_cfg.policy.has_property(P.PER_CHANNEL) or not quant_cfg.policy.has_property(P.SYMMETRICAL):
+            raise TypeError('ChannelwiseKLObserver needs a symmetrical per-channel config.')
+        self._scales_dev: Optional[torch.Tensor] = None
+
+    def observe(self, value: torch.Tensor):
+        if not is_initial(self._quant_cfg): return
+        assert value.numel() > 0, (f'You are observing an empty tensor({getattr(self._watch_on, "name", "")}).')
+        if self._phase == 'Detecting Minmax':
+            return TorchMinMaxObserver.observe(self, value)
+        C = value.shape[self._quant_cfg.channel_axis]
+        if self._hist is None:
+            self._hist = torch.zeros(size=(C, self._hist_bins), dtype=torch.int32, device=value.device)
+        CUDA.Histogram_C_Scales(value, self._quant_cfg.channel_axis, self._hist, self._scales_dev)
+
+    def histogram(self): return self._hist
+
+    def render_quantization_config(self):
+        cfg = self._quant_cfg
+        if not is_initial(cfg): return
+        if self._phase == 'Detecting Minmax':
+            r = self._range_on_host()                                      # [2, C]
+            hs = [float(max(abs(float(hi)), abs(float(lo)))) / self._hist_bins for lo, hi in zip(r[0], r[1])]
+            self._hist_scale = hs
+            self._scales_dev = torch.tensor(hs, dtype=torch.float32, device=self._range.device)
+            self._phase = 'Collating Hist'
+            return
+        if self._hist is None:
+            raise ValueError('Can not render quantization config yet, histogram is empty. '
+                             'Invoke observe() function before render config.')
+        losses = CUDA.KLLosses(self._hist, cfg.num_of_bits).cpu().numpy()  # [C, candidates], one launch
+        scales = []
+        for c in range(self._hist.shape[0]):
+            self._losses = losses[c]
+            scale, _ = self.hist_to_scale_offset(self._hist[c], self._hist_bins, self._hist_scale[c], cfg)
+            scales.append(scale)
+        self._losses = None
+        cfg.scale = torch.tensor(scales, dtype=torch.float32, device=self._hist.device)
+        cfg.offset = torch.zeros(len(scales), dtype=torch.float32, device=self._hist.device)
+        set_activated(cfg)
+
+
 class TorchPercentileObserver(BaseTensorObserver):
     """range.py:312-403.  Per batch: the two order statistics of ``CUDA.Quantile`` (index rule of the
     reference's CUDA path, sort.cu:13-19); render = mean over batches -> minmax_to_scale_offset."""
@@ -631,6 +681,7 @@ class DirectMSEObserver(BaseTensorObserver):
 OBSERVER_TABLE = {
     'minmax': TorchMinMaxObserver,
     'kl': TorchHistObserver,
+    'kl_channel': ChannelwiseKLObserver,       # extension, not in the reference's table
     'percentile': TorchPercentileObserver,
     'mse': TorchMSEObserver,
     'constant': ConstantObserver,

@@ -937,3 +937,48 @@ def test_data_parallel_lsq_equals_big_batch():
         for a, b in zip(res[r][3], weights): assert np.allclose(a, b, rtol=1e-2, atol=1e-4)
     for a, b in zip(res[0][2], res[1][2]): assert np.array_equal(a, b)             # ranks stay in lock step
     for a, b in zip(res[0][3], res[1][3]): assert np.array_equal(a, b)
+
+
+def test_channelwise_kl_observer_equals_per_tensor_kl_on_each_channel(CUDA):
+    """SURVEY 8f-4 extension: 'kl_channel' (per-channel two-phase KL; the reference's 'kl' refuses
+    PER_CHANNEL) gives every channel exactly the scale the per-tensor 'kl' observer renders on that
+    channel's slice; Histogram_C_Scales == Histogram_T per slice, bit for bit."""
+    from ppq_amd.observer import TensorObserverFactroy, OBSERVER_TABLE, ChannelwiseKLObserver
+    assert OBSERVER_TABLE['kl_channel'] is ChannelwiseKLObserver
+    g = torch.Generator().manual_seed(51)
+    C = 6
+    data = [(torch.randn(3, C, 40, 30, generator=g) * torch.arange(1, C + 1).view(1, C, 1, 1) * (1 + 0.1 * i)) for i in range(4)]
+    data = [torch.relu(d) if i % 2 else d for i, d in enumerate(data)]
+    # kernel level
+    scales = torch.tensor([0.01 * (c + 1) for c in range(C)])
+    hist = torch.zeros(C, 2048, dtype=torch.int32, device=DEV)
+    CUDA.Histogram_C_Scales(data[0].to(DEV), 1, hist, scales.to(DEV))
+    for c in range(C):
+        want = O.hist_sym_t(data[0][:, c].contiguous().numpy(), float(scales[c]), np.zeros(2048, np.int32), True)
+        assert np.array_equal(hist[c].cpu().numpy(), want), c
+    for shape, axis in (((5, 7, 9), 1), ((4, 3), 0), ((2, 3, 2000), 1)):               # short rows (global path), axis 0, long rows
+        x = torch.randn(*shape, generator=g)
+        Cx = shape[axis]
+        sc = torch.rand(Cx, generator=g) * 0.01 + 0.002
+        h = torch.zeros(Cx, 256, dtype=torch.int32, device=DEV)
+        CUDA.Histogram_C_Scales(x.to(DEV), axis, h, sc.to(DEV), clip_outliers=False)
+        for c in range(Cx):
+            sl = x.select(axis, c).contiguous().numpy()
+            assert np.array_equal(h[c].cpu().numpy(), O.hist_sym_t(sl, float(sc[c]), np.zeros(256, np.int32), False)), (shape, c)
+    # observer level
+    cfg = _cfg('kl_channel', per_channel_axis=1, bins=2048)
+    ob = TensorObserverFactroy.build_observer('x', cfg)
+    for _ in range(2):
+        for d in data: ob.observe(d.to(DEV))
+        ob.render_quantization_config()
+    assert cfg.state.value == 4 and cfg.scale.shape == (C,) and float(cfg.offset.abs().sum()) == 0
+    for c in range(C):
+        ref_cfg = _cfg('kl', bins=2048)
+        ref = TensorObserverFactroy.build_observer('x', ref_cfg)
+        for _ in range(2):
+            for d in data: ref.observe(d[:, c].contiguous().to(DEV))
+            ref.render_quantization_config()
+        assert float(ref_cfg.scale) == float(cfg.scale[c]), c
+    with pytest.raises(ValueError):                                          # the reference's 'kl' still refuses per-channel
+        bad = TensorObserverFactroy.build_observer('x', _cfg('kl', per_channel_axis=1, bins=2048))
+        bad.observe(data[0].to(DEV)); bad.render_quantization_config()
