@@ -307,7 +307,7 @@ __global__ __launch_bounds__(kHistMaxBlock) void hist_t_lds_kernel(const float* 
 // kernel arguments, job j owns workgroups [first_block[j], first_block[j+1]) and each of them streams
 // a contiguous chunk of its tensor into LDS and adds it to its own row of that job's persistent
 // rows buffer (same accumulate-mode contract as ppqhip_hist_*_t_rows).
-constexpr int kMultiMax = 64;                 // jobs per launch (2.6 KB of kernel arguments)
+constexpr int kMultiMax = 96;                 // jobs per launch (3.1 KB of kernel arguments; the limit is 4 KB)
 #ifndef PPQHIP_MULTI_CHUNK
 #define PPQHIP_MULTI_CHUNK (128u << 10)
 #endif
@@ -315,13 +315,12 @@ constexpr int kMultiMax = 64;                 // jobs per launch (2.6 KB of kern
 #define PPQHIP_MULTI_U kHistUBig     // MI355X sweep (tools/multi_bench.py): U=2 5.0 TB/s, U=1 4.8; chunk 512 KB > 256 KB, 1 MB, 2 MB
 #endif
 constexpr uint32_t kMultiChunk = PPQHIP_MULTI_CHUNK;  // elements per workgroup (512 KB): rows RMW is 3 % of the read
-struct HistJob {
+struct HistJob {                              // 32 B
     const float* x;
     int* rows;
     uint32_t n;
-    float a, hs, rcp;
+    float a, hs;
     uint32_t first_block;
-    uint32_t vec_ok;
 };
 struct HistJobs {
     HistJob job[kMultiMax];
@@ -341,8 +340,9 @@ __global__ __launch_bounds__(kHistMaxBlock) void hist_t_multi_kernel(const HistJ
     const uint32_t end = lo + 1 < jobs.count ? jobs.job[lo + 1].first_block : gridDim.x;
     const uint32_t bidx = blockIdx.x - j.first_block, nblk = end - j.first_block;
     BinRule rule;
-    rule.a = j.a; rule.hs = j.hs; rule.rcp = j.rcp; rule.bins = jobs.bins; rule.clip = jobs.clip; rule.asym = ASYM;
-    hist_stream<ASYM, CLIP, HOT, false, 0, false, U>(j.x, j.n, (int)j.vec_ok, rule, jobs.copies, lds, nullptr, 0.f, 0, 0,
+    rule.a = j.a; rule.hs = j.hs; rule.rcp = 1.0f / j.hs; rule.bins = jobs.bins; rule.clip = jobs.clip; rule.asym = ASYM;
+    const int vec_ok = (reinterpret_cast<uintptr_t>(j.x) & 15u) == 0;
+    hist_stream<ASYM, CLIP, HOT, false, 0, false, U>(j.x, j.n, vec_ok, rule, jobs.copies, lds, nullptr, 0.f, 0, 0,
                                                      0, 0, bidx, nblk);
     lds_hist_flush(lds, jobs.bins, jobs.copies, nullptr, j.rows, true, bidx);
 }
@@ -529,8 +529,6 @@ static int launch_hist_multi(const ppqhip_hist_job* jobs, int count, int bins, i
             d.x = src.x; d.rows = src.rows; d.n = (uint32_t)src.n;
             if (asym) { d.a = src.p0; d.hs = (src.p1 - src.p0) / (float)bins; }     // sort.cu:123
             else { d.a = 0.f; d.hs = src.p0; }
-            d.rcp = 1.0f / d.hs;
-            d.vec_ok = aligned16(src.x) ? 1u : 0u;
             d.first_block = blocks;
             uint32_t nb = (uint32_t)((src.n + kMultiChunk - 1) / kMultiChunk);
             if (nb > max_rows) nb = max_rows;

@@ -534,13 +534,13 @@ def test_bias_correction_pass():
 
 def test_multi_tensor_launches_equal_single(CUDA):
     """MinMax_T_Slots_Multi / Histogram_*_T_Rows_Multi: one launch over many tensors == one launch per
-    tensor (bit-exact after the fold) and == the oracle; covers > 64 jobs (several launches), a
+    tensor (bit-exact after the fold) and == the oracle; covers > 96 jobs (several launches), a
     1-element tensor, an unaligned view, accumulation over two rounds and a large tensor that needs
     more workgroups than there are rows."""
     g = torch.Generator().manual_seed(21)
-    sizes = [1, 5, 1000, 4097, 65536, 300001, 1 << 20] * 10 + [40 * (1 << 20)]
+    sizes = [1, 5, 1000, 4097, 65536, 300001, 1 << 20] * 14 + [40 * (1 << 20)]
     xs = [(torch.randn(n + 1, generator=g) * (1 + i % 5)).to(DEV)[(i % 2):][:n] for i, n in enumerate(sizes)]   # odd i: unaligned
-    assert len(xs) == 71
+    assert len(xs) == 99                                                  # > 96 jobs: two launches
     R, S, bins = CUDA.hist_rows(), CUDA.minmax_slots(), 2048
     # min / max -------------------------------------------------------------------------------
     seed = torch.tensor([float('inf'), float('-inf')], device=DEV)
