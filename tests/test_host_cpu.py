@@ -265,3 +265,55 @@ def test_merge_is_noop_without_process_group():
         def reducible(self): raise AssertionError('must not be touched when not distributed')
     assert merge_observers([Ob()]) == 0
     assert shard_batches([1, 2, 3]) == [1, 2, 3]
+
+
+def test_observation_queue_grouping_and_flush(monkeypatch):
+    """ObservationQueue host logic (no kernel runs here: the facade is replaced by a recorder): jobs are
+    grouped by statistic kind / bin count / symmetry, flushed as ONE call per group, automatically once the
+    pending bytes exceed the bound, and `recorder` keeps (observer, tensor) pairs for reuse_activations."""
+    from ppq_amd import observer as obs
+    calls = []
+
+    class FakeCUDA:
+        @staticmethod
+        def MinMax_T_Slots_Multi(values, slots): calls.append(('minmax', len(values)))
+        @staticmethod
+        def Histogram_T_Rows_Multi(values, rows, scales): calls.append(('hist_sym', len(values), rows[0].shape[1], list(scales)))
+        @staticmethod
+        def Histogram_Asymmetric_T_Rows_Multi(mins, maxs, values, rows): calls.append(('hist_asym', len(values), list(mins), list(maxs)))
+        @staticmethod
+        def Quantile_Multi(values, q, dests): calls.append(('quantile', len(values), q))
+    monkeypatch.setattr(obs, 'CUDA', FakeCUDA)
+    q = obs.ObservationQueue(max_pending_bytes=4 * 1000 * 3 + 1)          # room for three 1000-element tensors
+    t = [torch.zeros(1000) for _ in range(8)]
+    rows2048, rows512 = torch.zeros(4, 2048, dtype=torch.int32), torch.zeros(4, 512, dtype=torch.int32)
+    q.add_minmax(t[0], torch.zeros(4, 2)); q.add_hist(t[1], rows2048, False, 0.5); q.add_hist(t[2], rows512, False, 0.25)
+    assert len(q) == 3 and not calls
+    q.add_hist(t[3], rows2048, True, -1.0, 2.0)                           # 4th tensor: over the bound -> flush
+    assert len(q) == 0 and q.launches == 4
+    assert sorted(c[0] for c in calls) == ['hist_asym', 'hist_sym', 'hist_sym', 'minmax']
+    assert ('hist_sym', 1, 2048, [0.5]) in calls and ('hist_sym', 1, 512, [0.25]) in calls
+    assert ('hist_asym', 1, [-1.0], [2.0]) in calls
+    calls.clear()
+    d1, d2 = q.add_quantile(t[4], 0.9999), q.add_quantile(t[5], 0.9999)
+    q.add_quantile(t[6], 0.99)
+    assert d1.shape == (2,) and d1.data_ptr() != d2.data_ptr() and len(q) == 3
+    q.flush()
+    assert sorted(calls) == [('quantile', 1, 0.99), ('quantile', 2, 0.9999)] and len(q) == 0
+    q.flush()                                                             # empty: no calls
+    assert len(calls) == 2
+
+
+def test_dense_layout_rule():
+    """ffi._dense: which tensors the kernels may stream in storage order without a layout copy."""
+    from ppq_amd.ffi import _dense
+    x = torch.randn(2, 6, 5, 4)
+    xcl = x.contiguous(memory_format=torch.channels_last)
+    assert _dense(x) is x and _dense(xcl) is xcl                          # per-tensor: any dense layout
+    assert _dense(xcl, 0) is xcl and _dense(xcl, -4) is xcl               # per-channel on the outermost axis
+    y = _dense(xcl, 1)                                                    # per-channel on axis 1: NCHW copy
+    assert y is not xcl and y.is_contiguous() and torch.equal(y, x)
+    v = x[:, ::2]                                                         # strided view: copy
+    assert _dense(v).is_contiguous() and torch.equal(_dense(v), v)
+    x5 = torch.randn(2, 3, 4, 5, 6).contiguous(memory_format=torch.channels_last_3d)
+    assert _dense(x5) is x5
