@@ -8,8 +8,13 @@ collate_fn, **kwargs)``, same two-phase structure, same assertions on ``calib_st
 MI355X-first differences (results unchanged):
 
 * observers accumulate into device buffers through the HIP kernels (ppq_amd/observer.py);
+* ``batch_observations`` (default): the statistics of every tensor observed during a forward are
+  computed by ONE multi-tensor launch at the end of that forward (observer.ObservationQueue);
+* ``use_hip_graph`` (False | True | 'auto'): each phase's forward is captured once into a HIP graph
+  and replayed -- 'auto' times one eager step and captures only when it is launch-bound (small batches);
+* ``reuse_activations`` (opt-in): phase 2 bins the phase-1 activations kept in HBM instead of running
+  the forward again (valid while phase-1 rendering activates no activation config; checked);
 * optionally (``async_observe``) the observer kernels run on a side HIP stream (they only read);
-* optionally (``use_hip_graph``) each phase's forward is captured once into a HIP graph and replayed;
 * both render steps go through :func:`ppq_amd.observer.render_observers`: one device->host copy
   for all running ranges, one batched KL / MSE search launch per group of histograms;
 * data-parallel calibration: with ``torch.distributed`` initialised (one process per GPU, RCCL over
@@ -23,7 +28,7 @@ from typing import Callable, Dict, Iterable, List
 
 from .core import QuantizationStates, state_value
 from .distributed import merge_observers
-from .observer import OperationObserver, TorchHistObserver, TorchMSEObserver, render_observers
+from .observer import OperationObserver, TorchHistObserver, render_observers
 
 
 class QuantizationOptimizationPass:
