@@ -85,7 +85,7 @@ struct WaveAcc {
     int last;        // bins - 1
     int trash;       // bins + lane
     int hot_bin;     // wave-uniform, -1 = none
-    int hot_cnt;     // per lane
+    int hot_cnt;     // wave-uniform: hits are counted with ballot + s_bcnt1 (no VALU)
 
     __device__ __forceinline__ void init(int* copy, const BinRule& r) {
         h = copy; a0 = r.a; hs = r.hs; rcp = r.rcp; last = r.bins - 1;
@@ -103,13 +103,12 @@ struct WaveAcc {
         return b > last ? last : b;
     }
 
-    // (tried: counting hits with ballot + s_bcnt1, v_cvt_flr_i32_f32 for floor+convert, +inf padding
-    //  instead of the `in` select -- each within noise or slower on MI355X, and v_cvt_flr mis-bins
-    //  negative denormals; the kernel is not VALU-count bound.)
+    // (also tried: v_cvt_flr_i32_f32 for floor+convert -- 1 % and it mis-bins special values --, +inf padding
+    //  instead of the `in` select, a select-free path for full tiles: all within noise on MI355X.)
     __device__ __forceinline__ void commit(int slot) {
         if (HOT) {
             const bool hit = slot == hot_bin;
-            hot_cnt += hit ? 1 : 0;
+            hot_cnt += __popcll(__ballot(hit));     // wave-uniform count: s_bcnt1 + s_add, no VALU
             slot = hit ? trash : slot;
         }
         atomicAdd(&h[slot], 1);
@@ -147,8 +146,6 @@ struct WaveAcc {
     __device__ __forceinline__ void flush_hot() {
         if (!HOT) return;
         int c = hot_cnt;
-#pragma unroll
-        for (int m = 32; m > 0; m >>= 1) c += __shfl_xor(c, m, 64);
         if ((threadIdx.x & 63) == 0 && c != 0 && hot_bin >= 0) atomicAdd(&h[hot_bin], c);
         hot_cnt = 0;
     }
