@@ -196,6 +196,24 @@ def test_hist_rule_vs_histc():
     assert np.array_equal(h3, 2 * h)
 
 
+def test_asym_hist_rule_vs_histc():
+    """Histogram_Asymmetric_T has no test in the reference; its CPU twin is torch.histc(value, bins, min, max)
+    (range.py:182-184).  Same tolerance as the reference's own symmetric test (<100 counts/bin), with the one
+    documented divergence: histc counts x == max in the last bin, sort.cu:131-134 drops it."""
+    import torch
+    torch.manual_seed(3)
+    t = torch.randn(size=[4, 16, 56, 56]) * 2 + 0.3
+    lo, hi = float(t.min()), float(t.max())
+    ref = torch.histc(t, bins=2048, min=lo, max=hi).numpy()
+    h = O.hist_asym_t(t.numpy(), lo, hi, np.zeros(2048, np.int32))
+    assert np.abs(ref - h).max() < 100
+    assert int(ref.sum()) - int(h.sum()) in (0, 1, 2)          # the element(s) equal to max
+    inner = O.hist_asym_t(t.numpy(), lo / 2, hi / 2, np.zeros(512, np.int32))            # clip_outliers drops the tails
+    assert inner.sum() == int(((t >= lo / 2) & (t < hi / 2)).sum()) or abs(int(inner.sum()) - int(((t >= lo / 2) & (t < hi / 2)).sum())) <= 2
+    clamp = O.hist_asym_t(t.numpy(), lo / 2, hi / 2, np.zeros(512, np.int32), clip_outliers=False)
+    assert clamp.sum() == t.numel() and clamp[0] > inner[0] and clamp[-1] > inner[-1]
+
+
 def test_quantile_and_isotone_rules():
     x = np.arange(1000, dtype=np.float32)[::-1].copy()
     q = O.quantile_t(x, 0.999)
