@@ -214,6 +214,20 @@ def test_asym_hist_rule_vs_histc():
     assert clamp.sum() == t.numel() and clamp[0] > inner[0] and clamp[-1] > inner[-1]
 
 
+def test_hist_c_is_hist_t_per_channel():
+    """Histogram_C (sort.cu:167-218) is unused and untested in the reference: channel c of the [C, bins]
+    result must be Histogram_T (pinned above) of the slice of channel c -- same bin rule, same scale."""
+    rng = np.random.default_rng(5)
+    for shape, axis in (((3, 5, 7, 11), 1), ((6, 40), 0), ((2, 3, 4), 2)):
+        x = (rng.standard_normal(shape) * 2).astype(np.float32)
+        C = shape[axis]
+        for clip in (True, False):
+            h = O.hist_sym_c(x, axis, 0.013, np.zeros((C, 128), np.int32), clip)
+            for c in range(C):
+                sl = np.ascontiguousarray(np.take(x, c, axis=axis))
+                assert np.array_equal(h[c], O.hist_sym_t(sl, 0.013, np.zeros(128, np.int32), clip)), (shape, c, clip)
+
+
 def test_quantile_and_isotone_rules():
     x = np.arange(1000, dtype=np.float32)[::-1].copy()
     q = O.quantile_t(x, 0.999)
