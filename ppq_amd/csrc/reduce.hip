@@ -7,8 +7,9 @@
 //                        (ppq/quantization/observer/range.py:86-98).
 //   quantile_t           replaces Quantile_T (ppq/csrc/cuda/sort.cu:42-59): instead of a full
 //                        thrust::sort of a clone it radix-SELECTS the two order statistics on the
-//                        order-preserving uint32 key of the floats in three streaming passes
-//                        (12 + 12 + 8 bits, LDS histograms), no data movement.
+//                        order-preserving uint32 key of the floats (12 + 12 + 8 bits, LDS histograms),
+//                        no data movement; small buckets are compacted, so two streaming passes
+//                        usually suffice; many tensors per launch (quantile_multi_kernel).
 //   isotone_t            replaces Isotone_T (sort.cu:61-73): top-2 / bottom-2 reduction.
 #include <cmath>
 #include <cstdlib>
@@ -252,12 +253,24 @@ __device__ __forceinline__ float key2f(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
 
-// workspace layout (uint32 words)
+// workspace layout PER JOB (uint32 words)
 constexpr int kQ1 = 4096, kQ2 = 4096, kQ3 = 256;
+constexpr uint32_t kQCap = 8192;            // candidate keys kept per side when the selected bucket is small
 constexpr int kOffH1 = 0;                   // hist1[4096]        : key >> 20
 constexpr int kOffH2 = kOffH1 + kQ1;        // hist2[2][4096]     : (key >> 8) & 0xFFF | prefix12 match
 constexpr int kOffH3 = kOffH2 + 2 * kQ2;    // hist3[2][256]      : key & 0xFF        | prefix24 match
-constexpr int kQWords = kOffH3 + 2 * kQ3;
+constexpr int kOffSel = kOffH3 + 2 * kQ3;   // sel[2][8], side 0 = the q order statistic, side 1 = the (1-q) one:
+enum { kSTop = 0,     // 12-bit prefix of the bucket that holds the rank
+       kSRank = 1,    // rank inside that bucket
+       kSMode = 2,    // kModeHist (0, after the memset) | kModeCompact | kModeDone
+       kSCount = 3,   // COMPACT: candidates appended so far
+       kSMin = 4,     // HIST: smallest / largest key seen in the bucket (all equal -> done after pass 2)
+       kSMax = 5,
+       kSP24 = 6,     // HIST, after pass 2: 24-bit prefix and the rank inside it (pass 3)
+       kSR24 = 7 };
+enum { kModeHist = 0, kModeCompact = 1, kModeDone = 2 };
+constexpr int kOffCand = kOffSel + 16;      // cand[2][kQCap]: full keys of the bucket's elements
+constexpr int kQWords = kOffCand + 2 * (int)kQCap;
 
 // find the bin of `hist[0..nbins)` that holds rank k (0-based) and the rank inside it.
 // All threads of the workgroup call this (blockDim.x == 256, nbins in {256, 4096}); thread t owns
@@ -303,145 +316,232 @@ __device__ void select_bin(const uint32_t* __restrict__ hist, int nbins, uint32_
 
 constexpr int kQTrash = 64;
 
-__device__ __forceinline__ void quantile_pass1_body(const float* __restrict__ x, uint32_t n, bool vec_ok,
-                                                    uint32_t* __restrict__ ws, uint32_t bidx, uint32_t nblk) {
+// Radix select of two order statistics without sorting or moving data (replaces the clone + full
+// thrust::sort of Quantile_T, sort.cu:42-59), for MANY tensors per launch:
+//   pass 1   (all data)   histogram of the top 12 key bits
+//   select A (1 wg/job)   bucket + rank of both targets; a bucket of <= kQCap elements is COMPACTED
+//   pass 2   (all data)   COMPACT: append the bucket's keys to a candidate list (a few thousand global
+//                         atomics); else histogram of the middle 12 bits + min / max key of the bucket
+//   select B (1 wg/job)   COMPACT: finish on the candidate list in LDS -> done.  Else: all keys equal
+//                         (ReLU zeros, saturated values) -> done; otherwise 24-bit prefix for pass 3
+//   pass 3   (all data)   only for sides still open (workgroups of finished jobs return at once)
+//   pick     (1 wg/job)   last 8 bits
+// Typical activations (0.9999 quantile: a few thousand elements in the selected bucket; the low side of
+// a ReLU output: all zeros) finish after TWO passes over the data instead of three.
+struct QuantileCtx {
+    const float* x;
+    uint32_t* ws;
+    float* dest;
+    uint32_t n, k_hi, k_lo;
+};
+
+__device__ __forceinline__ void quantile_pass1_body(const QuantileCtx& c, uint32_t bidx, uint32_t nblk) {
     __shared__ uint32_t h[kQ1 + kQTrash];
     for (int i = threadIdx.x; i < kQ1; i += kBlock) h[i] = 0;
     __syncthreads();
     HotCounter hc;
     hc.init(h, kQ1);
-    stream_tiles<4>(x, n, vec_ok,
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(c.x) & 15u) == 0;
+    stream_tiles<4>(c.x, c.n, vec_ok,
                     [&](float v, bool in) { hc.elect((int)(f2key(v) >> 20), in); },
                     [&](float v, bool in) { hc.add(in ? (int)(f2key(v) >> 20) : hc.trash()); }, bidx, nblk);
     hc.flush();
     __syncthreads();
     for (int i = threadIdx.x; i < kQ1; i += kBlock)
-        if (h[i]) atomicAdd(&ws[kOffH1 + i], h[i]);
+        if (h[i]) atomicAdd(&c.ws[kOffH1 + i], h[i]);
 }
 
-__global__ __launch_bounds__(kBlock) void quantile_pass1_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
-                                                                uint32_t* __restrict__ ws) {
-    quantile_pass1_body(x, n, vec_ok, ws, blockIdx.x, gridDim.x);
-}
-
-__device__ __forceinline__ void quantile_pass2_body(const float* __restrict__ x, uint32_t n, bool vec_ok,
-                                                    uint32_t k_hi, uint32_t k_lo, uint32_t* __restrict__ ws,
-                                                    uint32_t bidx, uint32_t nblk) {
-    __shared__ uint32_t h[2 * (kQ2 + kQTrash)];
+__device__ __forceinline__ void quantile_select_a_body(const QuantileCtx& c) {
     __shared__ uint32_t scratch[kBlock];
     __shared__ uint32_t sel[2];
-    select_bin(ws + kOffH1, kQ1, k_hi, scratch, sel);
-    const uint32_t p_hi = sel[0];
-    __syncthreads();
-    select_bin(ws + kOffH1, kQ1, k_lo, scratch, sel);
-    const uint32_t p_lo = sel[0];
+    const uint32_t ks[2] = {c.k_hi, c.k_lo};
+    for (int w = 0; w < 2; w++) {
+        select_bin(c.ws + kOffH1, kQ1, ks[w], scratch, sel);
+        if (threadIdx.x == 0) {
+            uint32_t* S = c.ws + kOffSel + 8 * w;
+            const uint32_t top = sel[0];
+            S[kSTop] = top; S[kSRank] = sel[1];
+            S[kSMode] = c.ws[kOffH1 + top] <= kQCap ? kModeCompact : kModeHist;
+            S[kSCount] = 0; S[kSMin] = 0xFFFFFFFFu; S[kSMax] = 0u;
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void quantile_pass2_body(const QuantileCtx& c, uint32_t bidx, uint32_t nblk) {
+    __shared__ uint32_t h[2 * (kQ2 + kQTrash)];
+    __shared__ uint32_t red[4][kBlock / kWave];
+    // COMPACT sides stage their candidates in LDS and reserve their slice of the global list with ONE
+    // atomic per workgroup: appending element by element would put thousands of same-address device
+    // atomics (~12 ns each, serialised) on the critical path of a single large tensor
+    constexpr uint32_t kLocalCap = 512;
+    __shared__ uint32_t staged[2][kLocalCap];
+    __shared__ uint32_t staged_n[2], staged_base[2];
+    if (threadIdx.x < 2) staged_n[threadIdx.x] = 0;
+    uint32_t* S_hi = c.ws + kOffSel;
+    uint32_t* S_lo = c.ws + kOffSel + 8;
+    const uint32_t p_hi = S_hi[kSTop], p_lo = S_lo[kSTop];
+    const bool compact_hi = S_hi[kSMode] == kModeCompact, compact_lo = S_lo[kSMode] == kModeCompact;
+    uint32_t* cand_hi = c.ws + kOffCand;
+    uint32_t* cand_lo = c.ws + kOffCand + kQCap;
     for (int i = threadIdx.x; i < 2 * (kQ2 + kQTrash); i += kBlock) h[i] = 0;
     __syncthreads();
     HotCounter hi_c, lo_c;
     hi_c.init(h, kQ2);
     lo_c.init(h + kQ2 + kQTrash, kQ2);
-    stream_tiles<4>(x, n, vec_ok,
+    uint32_t mn_hi = 0xFFFFFFFFu, mx_hi = 0u, mn_lo = 0xFFFFFFFFu, mx_lo = 0u;
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(c.x) & 15u) == 0;
+    stream_tiles<4>(c.x, c.n, vec_ok,
                     [&](float v, bool in) {
                         const uint32_t key = f2key(v);
-                        hi_c.elect((int)((key >> 8) & 0xFFFu), in && (key >> 20) == p_hi);
-                        lo_c.elect((int)((key >> 8) & 0xFFFu), in && (key >> 20) == p_lo);
+                        hi_c.elect((int)((key >> 8) & 0xFFFu), in && !compact_hi && (key >> 20) == p_hi);
+                        lo_c.elect((int)((key >> 8) & 0xFFFu), in && !compact_lo && (key >> 20) == p_lo);
                     },
                     [&](float v, bool in) {
                         const uint32_t key = f2key(v);
                         const uint32_t top = key >> 20;
                         const int mid = (int)((key >> 8) & 0xFFFu);
-                        if (in && top == p_hi) hi_c.add(mid);      // rare unless the bin is hot (then it is
-                        if (in && top == p_lo) lo_c.add(mid);      // absorbed by the hot register)
+                        if (in && top == p_hi) {
+                            if (compact_hi) {
+                                const uint32_t at = atomicAdd(&staged_n[0], 1u);
+                                if (at < kLocalCap) staged[0][at] = key;
+                                else { const uint32_t g = atomicAdd(&S_hi[kSCount], 1u); if (g < kQCap) cand_hi[g] = key; }
+                            } else { hi_c.add(mid); mn_hi = min(mn_hi, key); mx_hi = max(mx_hi, key); }
+                        }
+                        if (in && top == p_lo) {
+                            if (compact_lo) {
+                                const uint32_t at = atomicAdd(&staged_n[1], 1u);
+                                if (at < kLocalCap) staged[1][at] = key;
+                                else { const uint32_t g = atomicAdd(&S_lo[kSCount], 1u); if (g < kQCap) cand_lo[g] = key; }
+                            } else { lo_c.add(mid); mn_lo = min(mn_lo, key); mx_lo = max(mx_lo, key); }
+                        }
                     }, bidx, nblk);
     hi_c.flush(); lo_c.flush();
+    // workgroup min / max of the bucket keys -> one atomic pair per side
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        mn_hi = min(mn_hi, (uint32_t)__shfl_xor((int)mn_hi, m, 64)); mx_hi = max(mx_hi, (uint32_t)__shfl_xor((int)mx_hi, m, 64));
+        mn_lo = min(mn_lo, (uint32_t)__shfl_xor((int)mn_lo, m, 64)); mx_lo = max(mx_lo, (uint32_t)__shfl_xor((int)mx_lo, m, 64));
+    }
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { red[0][wid] = mn_hi; red[1][wid] = mx_hi; red[2][wid] = mn_lo; red[3][wid] = mx_lo; }
     __syncthreads();
-    for (int i = threadIdx.x; i < kQ2; i += kBlock) {
-        if (h[i]) atomicAdd(&ws[kOffH2 + i], h[i]);
-        if (h[kQ2 + kQTrash + i]) atomicAdd(&ws[kOffH2 + kQ2 + i], h[kQ2 + kQTrash + i]);
+    if (threadIdx.x < 2) {                                         // reserve this workgroup's slice of the global lists
+        const uint32_t cnt = min(staged_n[threadIdx.x], kLocalCap);
+        staged_base[threadIdx.x] = cnt ? atomicAdd(&(threadIdx.x ? S_lo : S_hi)[kSCount], cnt) : 0u;
     }
-}
-
-__global__ __launch_bounds__(kBlock) void quantile_pass2_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
-                                                                uint32_t k_hi, uint32_t k_lo,
-                                                                uint32_t* __restrict__ ws) {
-    quantile_pass2_body(x, n, vec_ok, k_hi, k_lo, ws, blockIdx.x, gridDim.x);
-}
-
-// shared by pass 3 and the final pick: 24-bit prefixes and residual ranks of both targets
-__device__ void select_prefix24(const uint32_t* __restrict__ ws, uint32_t k_hi, uint32_t k_lo, uint32_t* scratch,
-                                uint32_t* sel, uint32_t* p24, uint32_t* r24) {
-    const uint32_t ks[2] = {k_hi, k_lo};
+    __syncthreads();
     for (int w = 0; w < 2; w++) {
-        select_bin(ws + kOffH1, kQ1, ks[w], scratch, sel);
-        const uint32_t top = sel[0], r1 = sel[1];
-        __syncthreads();
-        select_bin(ws + kOffH2 + w * kQ2, kQ2, r1, scratch, sel);
-        p24[w] = (top << 12) | sel[0];
-        r24[w] = sel[1];
-        __syncthreads();
+        const uint32_t cnt = min(staged_n[w], kLocalCap), at = staged_base[w];
+        uint32_t* cand = w ? cand_lo : cand_hi;
+        for (uint32_t i = threadIdx.x; i < cnt; i += kBlock)
+            if (at + i < kQCap) cand[at + i] = staged[w][i];
+    }
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / kWave; w++) {
+            mn_hi = min(mn_hi, red[0][w]); mx_hi = max(mx_hi, red[1][w]);
+            mn_lo = min(mn_lo, red[2][w]); mx_lo = max(mx_lo, red[3][w]);
+        }
+        if (!compact_hi && mn_hi <= mx_hi) { atomicMin(&S_hi[kSMin], mn_hi); atomicMax(&S_hi[kSMax], mx_hi); }
+        if (!compact_lo && mn_lo <= mx_lo) { atomicMin(&S_lo[kSMin], mn_lo); atomicMax(&S_lo[kSMax], mx_lo); }
+    }
+    for (int i = threadIdx.x; i < kQ2; i += kBlock) {
+        if (!compact_hi && h[i]) atomicAdd(&c.ws[kOffH2 + i], h[i]);
+        if (!compact_lo && h[kQ2 + kQTrash + i]) atomicAdd(&c.ws[kOffH2 + kQ2 + i], h[kQ2 + kQTrash + i]);
     }
 }
 
-__device__ __forceinline__ void quantile_pass3_body(const float* __restrict__ x, uint32_t n, bool vec_ok,
-                                                    uint32_t k_hi, uint32_t k_lo, uint32_t* __restrict__ ws,
-                                                    uint32_t bidx, uint32_t nblk) {
-    __shared__ uint32_t h[2 * (kQ3 + kQTrash)];
+// rank-th smallest (0-based) of cand[0..count): two LDS radix rounds over the low 20 key bits (all
+// candidates share the top 12).  Every thread of the workgroup calls it; result in sel[0].
+__device__ void select_in_candidates(const uint32_t* __restrict__ cand, uint32_t count, uint32_t rank, uint32_t top,
+                                     uint32_t* h, uint32_t* scratch, uint32_t* sel) {
+    for (int i = threadIdx.x; i < kQ2; i += kBlock) h[i] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < count; i += kBlock) atomicAdd(&h[(cand[i] >> 8) & 0xFFFu], 1u);
+    __syncthreads();
+    select_bin(h, kQ2, rank, scratch, sel);
+    const uint32_t mid = sel[0], r2 = sel[1];
+    __syncthreads();
+    for (int i = threadIdx.x; i < kQ3; i += kBlock) h[i] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < count; i += kBlock)
+        if (((cand[i] >> 8) & 0xFFFu) == mid) atomicAdd(&h[cand[i] & 0xFFu], 1u);
+    __syncthreads();
+    select_bin(h, kQ3, r2, scratch, sel);
+    const uint32_t low = sel[0];
+    __syncthreads();
+    if (threadIdx.x == 0) sel[0] = (top << 20) | (mid << 8) | low;
+    __syncthreads();
+}
+
+__device__ __forceinline__ void quantile_select_b_body(const QuantileCtx& c) {
+    __shared__ uint32_t h[kQ2];
     __shared__ uint32_t scratch[kBlock];
     __shared__ uint32_t sel[2];
-    uint32_t p24[2], r24[2];
-    select_prefix24(ws, k_hi, k_lo, scratch, sel, p24, r24);
+    for (int w = 0; w < 2; w++) {
+        uint32_t* S = c.ws + kOffSel + 8 * w;
+        const uint32_t mode = S[kSMode], top = S[kSTop], rank = S[kSRank];
+        if (mode == kModeCompact) {
+            const uint32_t count = min(S[kSCount], kQCap);
+            select_in_candidates(c.ws + kOffCand + w * kQCap, count, rank, top, h, scratch, sel);
+            if (threadIdx.x == 0) { c.dest[w] = key2f(sel[0]); S[kSMode] = kModeDone; }
+        } else if (S[kSMin] == S[kSMax]) {                         // every element of the bucket is the same value
+            if (threadIdx.x == 0) { c.dest[w] = key2f(S[kSMin]); S[kSMode] = kModeDone; }
+        } else {
+            select_bin(c.ws + kOffH2 + w * kQ2, kQ2, rank, scratch, sel);
+            if (threadIdx.x == 0) { S[kSP24] = (top << 12) | sel[0]; S[kSR24] = sel[1]; }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void quantile_pass3_body(const QuantileCtx& c, uint32_t bidx, uint32_t nblk) {
+    const uint32_t* S_hi = c.ws + kOffSel;
+    const uint32_t* S_lo = c.ws + kOffSel + 8;
+    const bool need_hi = S_hi[kSMode] == kModeHist, need_lo = S_lo[kSMode] == kModeHist;
+    if (!need_hi && !need_lo) return;                              // the usual case: nothing left for this job
+    __shared__ uint32_t h[2 * (kQ3 + kQTrash)];
+    const uint32_t p_hi = S_hi[kSP24], p_lo = S_lo[kSP24];
     for (int i = threadIdx.x; i < 2 * (kQ3 + kQTrash); i += kBlock) h[i] = 0;
     __syncthreads();
     HotCounter hi_c, lo_c;
     hi_c.init(h, kQ3);
     lo_c.init(h + kQ3 + kQTrash, kQ3);
-    stream_tiles<4>(x, n, vec_ok,
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(c.x) & 15u) == 0;
+    stream_tiles<4>(c.x, c.n, vec_ok,
                     [&](float v, bool in) {
                         const uint32_t key = f2key(v);
-                        hi_c.elect((int)(key & 0xFFu), in && (key >> 8) == p24[0]);
-                        lo_c.elect((int)(key & 0xFFu), in && (key >> 8) == p24[1]);
+                        hi_c.elect((int)(key & 0xFFu), in && need_hi && (key >> 8) == p_hi);
+                        lo_c.elect((int)(key & 0xFFu), in && need_lo && (key >> 8) == p_lo);
                     },
                     [&](float v, bool in) {
                         const uint32_t key = f2key(v);
                         const int low = (int)(key & 0xFFu);
-                        if (in && (key >> 8) == p24[0]) hi_c.add(low);
-                        if (in && (key >> 8) == p24[1]) lo_c.add(low);
+                        if (in && need_hi && (key >> 8) == p_hi) hi_c.add(low);
+                        if (in && need_lo && (key >> 8) == p_lo) lo_c.add(low);
                     }, bidx, nblk);
     hi_c.flush(); lo_c.flush();
     __syncthreads();
     for (int i = threadIdx.x; i < kQ3; i += kBlock) {
-        if (h[i]) atomicAdd(&ws[kOffH3 + i], h[i]);
-        if (h[kQ3 + kQTrash + i]) atomicAdd(&ws[kOffH3 + kQ3 + i], h[kQ3 + kQTrash + i]);
+        if (h[i]) atomicAdd(&c.ws[kOffH3 + i], h[i]);
+        if (h[kQ3 + kQTrash + i]) atomicAdd(&c.ws[kOffH3 + kQ3 + i], h[kQ3 + kQTrash + i]);
     }
 }
 
-__global__ __launch_bounds__(kBlock) void quantile_pass3_kernel(const float* __restrict__ x, uint32_t n, bool vec_ok,
-                                                                uint32_t k_hi, uint32_t k_lo,
-                                                                uint32_t* __restrict__ ws) {
-    quantile_pass3_body(x, n, vec_ok, k_hi, k_lo, ws, blockIdx.x, gridDim.x);
-}
-
-__device__ __forceinline__ void quantile_pick_body(uint32_t k_hi, uint32_t k_lo, const uint32_t* __restrict__ ws,
-                                                   float* __restrict__ dest) {
+__device__ __forceinline__ void quantile_pick_body(const QuantileCtx& c) {
     __shared__ uint32_t scratch[kBlock];
     __shared__ uint32_t sel[2];
-    uint32_t p24[2], r24[2];
-    select_prefix24(ws, k_hi, k_lo, scratch, sel, p24, r24);
     for (int w = 0; w < 2; w++) {
-        select_bin(ws + kOffH3 + w * kQ3, kQ3, r24[w], scratch, sel);
-        if (threadIdx.x == 0) dest[w] = key2f((p24[w] << 8) | sel[0]);
+        const uint32_t* S = c.ws + kOffSel + 8 * w;
+        if (S[kSMode] == kModeHist) {
+            select_bin(c.ws + kOffH3 + w * kQ3, kQ3, S[kSR24], scratch, sel);
+            if (threadIdx.x == 0) c.dest[w] = key2f((S[kSP24] << 8) | sel[0]);
+        }
         __syncthreads();
     }
 }
 
-__global__ __launch_bounds__(kBlock) void quantile_pick_kernel(uint32_t k_hi, uint32_t k_lo,
-                                                               const uint32_t* __restrict__ ws,
-                                                               float* __restrict__ dest) {
-    quantile_pick_body(k_hi, k_lo, ws, dest);
-}
-
-// many tensors, one launch per pass (see hist_t_multi_kernel): job j owns workgroups
-// [first_block[j], first_block[j+1]) and its own kQWords-word slice of the workspace.
+// job j owns workgroups [first_block[j], first_block[j+1]) and its own kQWords-word slice of the workspace
 constexpr int kQuantileMultiMax = 64;                  // jobs per launch (2.6 KB of kernel arguments)
 constexpr uint32_t kQuantileMultiChunk = 32u << 10;    // elements per workgroup (128 KB)
 constexpr uint32_t kQuantileMultiCap = 1024;           // workgroups per job at most
@@ -455,26 +555,27 @@ struct QuantileJobs {
     QuantileJob job[kQuantileMultiMax];
     uint32_t count;
 };
+enum { kQPass1 = 1, kQSelectA, kQPass2, kQSelectB, kQPass3, kQPick };
 
-template <int PASS>
+template <int STEP>
 __global__ __launch_bounds__(kBlock) void quantile_multi_kernel(const QuantileJobs jobs) {
-    if (PASS == 4) {                                   // pick: one workgroup per job
-        const QuantileJob& j = jobs.job[blockIdx.x];
-        quantile_pick_body(j.k_hi, j.k_lo, j.ws, j.dest);
-        return;
-    }
-    uint32_t lo = 0, hi = jobs.count;
-    while (hi - lo > 1) {
+    constexpr bool per_job = STEP == kQSelectA || STEP == kQSelectB || STEP == kQPick;     // one workgroup per job
+    uint32_t lo = per_job ? blockIdx.x : 0, hi = jobs.count;
+    while (!per_job && hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (jobs.job[mid].first_block <= blockIdx.x) lo = mid; else hi = mid;
     }
     const QuantileJob& j = jobs.job[lo];
+    QuantileCtx c;
+    c.x = j.x; c.ws = j.ws; c.dest = j.dest; c.n = j.n; c.k_hi = j.k_hi; c.k_lo = j.k_lo;
     const uint32_t end = lo + 1 < jobs.count ? jobs.job[lo + 1].first_block : gridDim.x;
     const uint32_t bidx = blockIdx.x - j.first_block, nblk = end - j.first_block;
-    const bool vec_ok = (reinterpret_cast<uintptr_t>(j.x) & 15u) == 0;
-    if (PASS == 1) quantile_pass1_body(j.x, j.n, vec_ok, j.ws, bidx, nblk);
-    if (PASS == 2) quantile_pass2_body(j.x, j.n, vec_ok, j.k_hi, j.k_lo, j.ws, bidx, nblk);
-    if (PASS == 3) quantile_pass3_body(j.x, j.n, vec_ok, j.k_hi, j.k_lo, j.ws, bidx, nblk);
+    if (STEP == kQPass1) quantile_pass1_body(c, bidx, nblk);
+    if (STEP == kQSelectA) quantile_select_a_body(c);
+    if (STEP == kQPass2) quantile_pass2_body(c, bidx, nblk);
+    if (STEP == kQSelectB) quantile_select_b_body(c);
+    if (STEP == kQPass3) quantile_pass3_body(c, bidx, nblk);
+    if (STEP == kQPick) quantile_pick_body(c);
 }
 
 // ------------------------------------------------------------------------------------ isotone
@@ -681,29 +782,52 @@ int64_t ppqhip_quantile_workspace_bytes(int64_t n) {
     return q > iso ? q : iso;
 }
 
+static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, float q, void* workspace, hipStream_t s,
+                               const char* what) {
+    uint32_t* ws = (uint32_t*)workspace;
+    if (int st = check_hip(hipMemsetAsync(ws, 0, (size_t)num_jobs * kQWords * 4, s), "memset quantile workspace"))
+        return st;
+    for (int base = 0; base < num_jobs; base += kQuantileMultiMax) {
+        QuantileJobs args;
+        args.count = (uint32_t)((num_jobs - base) < kQuantileMultiMax ? (num_jobs - base) : kQuantileMultiMax);
+        uint32_t blocks = 0;
+        for (uint32_t k = 0; k < args.count; k++) {
+            const ppqhip_quantile_job& src = jobs[base + k];
+            const int64_t n = src.n;
+            // index rule of _Quantile_T, sort.cu:13-19: __float2int_rn(num_of_elements * q), clipped to [0, n-1]
+            auto pos = [n](float f) -> uint32_t {
+                float p = nearbyintf((float)n * f);
+                if (!(p > 0.f)) return 0u;                      // also NaN
+                if (p >= (float)(n - 1)) return (uint32_t)(n - 1);
+                return (uint32_t)p;
+            };
+            QuantileJob& d = args.job[k];
+            d.x = src.x; d.dest = src.dest; d.n = (uint32_t)n; d.ws = ws + (size_t)(base + k) * kQWords;
+            d.k_hi = pos(q); d.k_lo = pos(1 - q); d.first_block = blocks;
+            uint32_t nb = (uint32_t)((n + kQuantileMultiChunk - 1) / kQuantileMultiChunk);
+            if (nb > kQuantileMultiCap) nb = kQuantileMultiCap;
+            if (nb < 1) nb = 1;
+            blocks += nb;
+        }
+        const dim3 all(blocks), one(args.count), wg(kBlock);
+        hipLaunchKernelGGL(quantile_multi_kernel<kQPass1>, all, wg, 0, s, args);
+        hipLaunchKernelGGL(quantile_multi_kernel<kQSelectA>, one, wg, 0, s, args);
+        hipLaunchKernelGGL(quantile_multi_kernel<kQPass2>, all, wg, 0, s, args);
+        hipLaunchKernelGGL(quantile_multi_kernel<kQSelectB>, one, wg, 0, s, args);
+        hipLaunchKernelGGL(quantile_multi_kernel<kQPass3>, all, wg, 0, s, args);
+        hipLaunchKernelGGL(quantile_multi_kernel<kQPick>, one, wg, 0, s, args);
+    }
+    return finish_launch(what);
+}
+
 int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, void* workspace, void* stream) {
     if (int st = validate(n, "quantile_t")) return st;
     if (workspace == nullptr) { set_error("quantile_t: workspace is null"); return PPQHIP_ERR_INVALID_VALUE; }
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_QUANTILE, 4.0 * (double)n, s);
-    // index rule of _Quantile_T, sort.cu:13-19: __float2int_rn(num_of_elements * q), clipped to [0, n-1]
-    auto pos = [n](float f) -> uint32_t {
-        float p = nearbyintf((float)n * f);
-        if (!(p > 0.f)) return 0u;                      // also NaN
-        if (p >= (float)(n - 1)) return (uint32_t)(n - 1);
-        return (uint32_t)p;
-    };
-    const uint32_t k_hi = pos(q), k_lo = pos(1 - q);
-    uint32_t* ws = (uint32_t*)workspace;
-    if (int st = check_hip(hipMemsetAsync(ws, 0, (size_t)kQWords * 4, s), "memset quantile workspace")) return st;
-    static const int qpc = getenv("PPQHIP_Q_PER_CU") ? atoi(getenv("PPQHIP_Q_PER_CU")) : 4;
-    const int grid = stream_grid(n, kBlock * 16, kNumCU * qpc);
-    const bool vec_ok = aligned16(x);
-    hipLaunchKernelGGL(quantile_pass1_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, vec_ok, ws);
-    hipLaunchKernelGGL(quantile_pass2_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, vec_ok, k_hi, k_lo, ws);
-    hipLaunchKernelGGL(quantile_pass3_kernel, dim3(grid), dim3(kBlock), 0, s, x, (uint32_t)n, vec_ok, k_hi, k_lo, ws);
-    hipLaunchKernelGGL(quantile_pick_kernel, dim3(1), dim3(kBlock), 0, s, k_hi, k_lo, ws, dest);
-    return finish_launch("quantile_t");
+    ppqhip_quantile_job job;
+    job.x = x; job.dest = dest; job.n = n;
+    return quantile_multi_impl(&job, 1, q, workspace, s, "quantile_t");
 }
 
 int64_t ppqhip_quantile_multi_workspace_bytes(int num_jobs) {
@@ -725,36 +849,7 @@ int ppqhip_quantile_t_multi(const ppqhip_quantile_job* jobs, int num_jobs, float
     }
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_QUANTILE, bytes, s);
-    uint32_t* ws = (uint32_t*)workspace;
-    if (int st = check_hip(hipMemsetAsync(ws, 0, (size_t)num_jobs * kQWords * 4, s), "memset quantile workspace"))
-        return st;
-    for (int base = 0; base < num_jobs; base += kQuantileMultiMax) {
-        QuantileJobs args;
-        args.count = (uint32_t)((num_jobs - base) < kQuantileMultiMax ? (num_jobs - base) : kQuantileMultiMax);
-        uint32_t blocks = 0;
-        for (uint32_t k = 0; k < args.count; k++) {
-            const ppqhip_quantile_job& src = jobs[base + k];
-            const int64_t n = src.n;
-            auto pos = [n](float f) -> uint32_t {               // sort.cu:13-19, as in ppqhip_quantile_t
-                float p = nearbyintf((float)n * f);
-                if (!(p > 0.f)) return 0u;
-                if (p >= (float)(n - 1)) return (uint32_t)(n - 1);
-                return (uint32_t)p;
-            };
-            QuantileJob& d = args.job[k];
-            d.x = src.x; d.dest = src.dest; d.n = (uint32_t)n; d.ws = ws + (size_t)(base + k) * kQWords;
-            d.k_hi = pos(q); d.k_lo = pos(1 - q); d.first_block = blocks;
-            uint32_t nb = (uint32_t)((n + kQuantileMultiChunk - 1) / kQuantileMultiChunk);
-            if (nb > kQuantileMultiCap) nb = kQuantileMultiCap;
-            if (nb < 1) nb = 1;
-            blocks += nb;
-        }
-        hipLaunchKernelGGL(quantile_multi_kernel<1>, dim3(blocks), dim3(kBlock), 0, s, args);
-        hipLaunchKernelGGL(quantile_multi_kernel<2>, dim3(blocks), dim3(kBlock), 0, s, args);
-        hipLaunchKernelGGL(quantile_multi_kernel<3>, dim3(blocks), dim3(kBlock), 0, s, args);
-        hipLaunchKernelGGL(quantile_multi_kernel<4>, dim3(args.count), dim3(kBlock), 0, s, args);
-    }
-    return finish_launch("quantile_t_multi");
+    return quantile_multi_impl(jobs, num_jobs, q, workspace, s, "quantile_t_multi");
 }
 
 int ppqhip_isotone_t(const float* x, int64_t n, float* dest, void* workspace, void* stream) {
