@@ -317,3 +317,29 @@ def test_dense_layout_rule():
     assert _dense(v).is_contiguous() and torch.equal(_dense(v), v)
     x5 = torch.randn(2, 3, 4, 5, 6).contiguous(memory_format=torch.channels_last_3d)
     assert _dense(x5) is x5
+
+
+def test_harness_topologies():
+    """The synthetic topologies the measurements run on: ResNet-50 (53 Conv + 1 Gemm, 25.5 M parameters
+    with BN folded) and ViT-B/16 (86.6 M parameters, 197 tokens); both run an FP32 forward on the CPU."""
+    from ppq_amd import harness
+    g = harness.resnet50_graph(seed=0)
+    types = [op.type for op in g.operations.values()]
+    assert types.count('Conv') == 53 and types.count('Gemm') == 1 and len(types) == 122
+    n_params = sum(v.value.numel() for v in g.variables.values() if v.is_parameter)
+    assert 25.4e6 < n_params < 25.7e6
+    y = harness.TorchExecutor(g, 'cpu').forward(torch.rand(1, 3, 64, 64))[0]
+    assert y.shape == (1, 1000) and torch.isfinite(y).all()
+    harness.quantize_graph(g, 'kl', hist_bins=2048)
+    observed = sum(1 for op in g.operations.values() for c, v in op.config_with_variable
+                   if not v.is_parameter and c.state.value == 1)
+    assert observed == 72                                                  # the 72 activation tensors of the bench
+    v = harness.vit_graph(seed=0, depth=2, dim=64, heads=4, mlp_dim=128, patch=16, image=64, num_classes=10)
+    y = harness.TorchExecutor(v, 'cpu').forward(torch.randn(2, 3, 64, 64))[0]
+    assert y.shape == (2, 10) and torch.isfinite(y).all()
+    full = harness.vit_graph(seed=0)
+    assert abs(sum(p.value.numel() for p in full.variables.values() if p.is_parameter) - 86_567_656) == 0
+    harness.quantize_graph_fp8(full)
+    acts = sum(1 for op in full.operations.values() for c, p in op.config_with_variable if not p.is_parameter and c.state.value == 1)
+    weights = sum(1 for op in full.operations.values() for c, p in op.config_with_variable if p.is_parameter and c.state.value == 1)
+    assert (acts, weights) == (98, 50)
