@@ -180,6 +180,41 @@ def test_fp8_known_answers():
     assert list(y) == [1.125, -3.25, 96.0] or np.allclose(y, [1.1875 // 0.0625 * 0.0625, -3.25, 96.0])
 
 
+def test_fp8_matches_native_float8_cast_away_from_ties():
+    """An independent pin for the FP8 restatement (the reference has no CPU twin): PyTorch's own
+    float8_e4m3fn / float8_e5m2 conversion is IEEE round-to-nearest-even, and QuantizeScalarFloating
+    (common.cuh:154-226) differs from it ONLY on exact mantissa ties of normal numbers, where the
+    reference rounds toward zero (nearbyint(0.5) == 0).  So: bit-equal on random data (a tie has
+    probability 2^-20), and on every constructed tie the oracle returns the smaller-magnitude neighbour."""
+    import torch
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal(400_000) * rng.choice([1e-3, 0.02, 0.3, 4, 60, 300, 5000], 400_000)).astype(np.float32)
+    one, zero = np.ones(1, np.float32), np.zeros(1, np.float32)
+    for e, m, clip, dt in ((4, 3, 448.0, torch.float8_e4m3fn), (5, 2, 57344.0, torch.float8_e5m2)):
+        y = O.fq_float_t(x, one, zero, e, m, -clip, clip, 0)
+        t = torch.from_numpy(x).clamp(-clip, clip).to(dt).float().numpy()
+        assert np.array_equal(y, t), (e, m)                      # value equality: the sign of an underflowed zero is not compared
+        # scaled: fq(x, s) == s * fq(x / s, 1) for power-of-two s (exact scaling)
+        y4 = O.fq_float_t(x, 4 * one, zero, e, m, -clip, clip, 0)
+        t4 = (torch.from_numpy(x / 4).clamp(-clip, clip).to(dt).float() * 4).numpy()
+        assert np.array_equal(y4, t4), (e, m)
+        # every tie between adjacent normal grid points
+        bias = 2 ** (e - 1) - 1
+        ties, lower = [], []
+        for ex in range(1 - bias, 8 if e == 4 else 15):
+            for k in range(2 ** m):
+                a = (1 + k / 2 ** m) * 2.0 ** ex
+                b = (1 + (k + 1) / 2 ** m) * 2.0 ** ex
+                if b > clip: continue
+                ties.append((a + b) / 2); lower.append(a)
+        ties = np.array(ties, np.float32); lower = np.array(lower, np.float32)
+        got = O.fq_float_t(ties, one, zero, e, m, -clip, clip, 0)
+        assert np.array_equal(got, lower), (e, m)
+        assert np.array_equal(O.fq_float_t(-ties, one, zero, e, m, -clip, clip, 0), -lower)
+        native = torch.from_numpy(ties).to(dt).float().numpy()
+        assert (native != lower).sum() == len(ties) // 2           # IEEE picks the even neighbour: the upper one half the time
+
+
 def test_hist_rule_vs_histc():
     """tests/test_cuda_kernel.py:198-208: Histogram_T within 100 counts/bin of torch.histc."""
     import torch
