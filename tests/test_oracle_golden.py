@@ -263,6 +263,22 @@ def test_hist_c_is_hist_t_per_channel():
                 assert np.array_equal(h[c], O.hist_sym_t(sl, 0.013, np.zeros(128, np.int32), clip)), (shape, c, clip)
 
 
+def test_quantile_is_sort_and_index():
+    """Quantile_T (sort.cu:6-59) = thrust::sort + index __float2int_rn(n * q) clipped to [0, n-1] (the
+    reference's CPU path indexes torch.kthvalue with int(n * q) instead, range.py:341): the oracle's select
+    equals sort-and-index with the CUDA rule."""
+    rng = np.random.default_rng(9)
+    for n in (1, 2, 17, 1000, 65537, 300001):
+        x = (rng.standard_normal(n) * 3).astype(np.float32)
+        srt = np.sort(x)
+        for q in (0.9999, 0.99, 0.75, 0.5):
+            def pos(f):
+                p = np.rint(np.float32(n) * np.float32(f))
+                return int(min(max(p, 0), n - 1))
+            got = O.quantile_t(x, q)
+            assert got[0] == srt[pos(q)] and got[1] == srt[pos(np.float32(1) - np.float32(q))], (n, q)
+
+
 def test_quantile_and_isotone_rules():
     x = np.arange(1000, dtype=np.float32)[::-1].copy()
     q = O.quantile_t(x, 0.999)
