@@ -263,6 +263,42 @@ def test_hist_c_is_hist_t_per_channel():
                 assert np.array_equal(h[c], O.hist_sym_t(sl, 0.013, np.zeros(128, np.int32), clip)), (shape, c, clip)
 
 
+def test_lsq_backward_matches_reference_formula():
+    """QuantizeTensor_LT_B / _LC_B (linear.cu:235-433) against the closed form the reference's own test
+    checks them with (tests/test_cuda_kernel.py:67-78, 104-119), evaluated here in float64: the
+    straight-through grad_x exactly; grad_s = sum of ((q - o) s - x) / s * dy inside the range,
+    (qmax - o) dy above, (qmin - o) dy below, scaled by 1/sqrt(n (qmax - qmin)) per tensor and by
+    1/sqrt(n qmax) per channel (linear.cu:299, 402)."""
+    rng = np.random.default_rng(13)
+    for sym in (True, False):
+        qmin, qmax = (-128, 127) if sym else (0, 255)
+        x = (rng.random((4, 6, 50)) * 50 - (25 if sym else 0)).astype(np.float32)
+        dy = rng.random(x.shape).astype(np.float32)
+        # per tensor
+        s = np.float32(rng.random() * 0.5 + 0.05); o = np.float32(0 if sym else rng.integers(0, 255))
+        q = np.rint(x / s) + o                                      # float32 divide + RNE, as the kernel
+        inside = (q >= qmin) & (q <= qmax)
+        gx, gs = O.fq_linear_t_bwd(x, [s], [o], dy, qmin, qmax)
+        assert np.array_equal(gx, np.where(inside, dy, np.float32(0)))
+        x64, dy64, q64 = x.astype(np.float64), dy.astype(np.float64), q.astype(np.float64)
+        term = np.where(inside, ((q64 - float(o)) * float(s) - x64) / float(s) * dy64, 0.0)
+        term += np.where(q > qmax, (qmax - float(o)) * dy64, 0.0) + np.where(q < qmin, (qmin - float(o)) * dy64, 0.0)
+        assert float(gs[0]) == pytest.approx(term.sum() / np.sqrt(x.size * (qmax - qmin)), rel=2e-4, abs=1e-6)
+        # per channel (axis 1)
+        sc = (rng.random(6) * 0.5 + 0.05).astype(np.float32)
+        oc = (np.zeros(6) if sym else rng.integers(0, 255, 6)).astype(np.float32)
+        S, Oc = sc.reshape(1, 6, 1), oc.reshape(1, 6, 1)
+        q = np.rint(x / S) + Oc
+        inside = (q >= qmin) & (q <= qmax)
+        gx, gs = O.fq_linear_c_bwd(x, sc, oc, dy, 1, qmin, qmax)
+        assert np.array_equal(gx, np.where(inside, dy, np.float32(0)))
+        q64 = q.astype(np.float64)
+        term = np.where(inside, ((q64 - Oc) * S.astype(np.float64) - x64) / S * dy64, 0.0)
+        term += np.where(q > qmax, (qmax - Oc) * dy64, 0.0) + np.where(q < qmin, (qmin - Oc) * dy64, 0.0)
+        want = term.sum(axis=(0, 2)) / np.sqrt(x.size * qmax)
+        assert np.allclose(gs, want, rtol=2e-4, atol=1e-6)
+
+
 def test_quantile_is_sort_and_index():
     """Quantile_T (sort.cu:6-59) = thrust::sort + index __float2int_rn(n * q) clipped to [0, n-1] (the
     reference's CPU path indexes torch.kthvalue with int(n * q) instead, range.py:341): the oracle's select
