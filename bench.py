@@ -120,7 +120,7 @@ def pmc_traffic(kernel_name: str):
     return (round(tot / n), 'profiles/r01_bench_pmc_bytes.json') if n else (None, None)
 
 
-def cpu_baseline(bins, batch_samples=2, n_batches=2):
+def cpu_baseline(bins, batch_samples=2, n_batches=4):
     """The same two-phase KL calibration on the host cores, through the CPU oracle."""
     from ppq_amd import harness
     from oracle.cpu_calibration import timed_calibrate_cpu
