@@ -273,6 +273,13 @@ int ppqhip_fq_linear_t_hist_sym(const float* x, const float* scale, const float*
                                 float* out, int64_t n, int clip_min, int clip_max, int rounding,
                                 float hist_scale, int clip_outliers, int32_t* hist,
                                 int64_t num_bins, void* workspace, void* stream);
+/* the same step for an observer that keeps persistent rows (see ppqhip_hist_sym_t_rows): what the
+ * executor-side delegate of a config that is ACTIVATED upstream and still observed downstream calls
+ * (ppq/executor/torch.py:296-323, 516-550: quantize, then the hook observes the same fp32 value). */
+int ppqhip_fq_linear_t_hist_sym_rows(const float* x, const float* scale, const float* offset,
+                                     float* out, int64_t n, int clip_min, int clip_max, int rounding,
+                                     float hist_scale, int clip_outliers, int32_t* rows,
+                                     int64_t num_bins, void* stream);
 
 /* profiling aid used by bench.py: when enabled, every kernel launch made through this library
  * on this thread is bracketed by hipEvents on its own stream; ppqhip_prof_collect() synchronises

@@ -78,6 +78,7 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         self._recording = False
         self.graph_replays = 0
         self.graph_decisions = []      # use_hip_graph='auto': one record per phase
+        self.merge_stats = []          # data-parallel runs: one record per phase (collectives, bytes, ms)
         self._side_stream = None
 
     def _batches(self, dataloader: Iterable) -> list:
@@ -194,7 +195,9 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         if self._side_stream is not None:          # join the observer stream before reading statistics
             import torch
             torch.cuda.current_stream().wait_stream(self._side_stream)
-        merge_observers(observers, group=self._process_group)
+        if merge_observers(observers, group=self._process_group):
+            from . import distributed
+            self.merge_stats.append(dict(distributed.last_merge_stats))
         render_observers(observers)
 
     def optimize(self, graph, dataloader: Iterable, executor, calib_steps: int = 32,

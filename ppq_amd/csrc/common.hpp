@@ -148,13 +148,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// float atomic min / max on plain float storage (no NaNs): sign-split integer atomics.
+// float atomic min / max on plain float storage (no NaNs): sign-split integer atomics.  The split is
+// on the SIGN BIT, not on `v >= 0`: -0.0f compares >= 0 but its pattern 0x80000000 is INT_MIN, and a
+// signed atomicMin with it would overwrite any stored negative minimum.
 __device__ __forceinline__ void atomic_min_f32(float* addr, float v) {
-    if (v >= 0) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+    if (__float_as_int(v) >= 0) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
     else atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 __device__ __forceinline__ void atomic_max_f32(float* addr, float v) {
-    if (v >= 0) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    if (__float_as_int(v) >= 0) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
     else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
 }
 

@@ -5,57 +5,74 @@
 // floor((x - min) / hist_scale) [asym] with the IEEE quotient and a saturating float->int
 // conversion (NaN -> bin 0); b > bins-1 (asym: or b < 0) is dropped (clip_outliers) or clamped.
 //
-// Design (PMC: VALU busy ~63 %, half of the wave cycles waiting on memory, LDS bank conflicts
-// irrelevant -- the kernel sits between VALU issue and memory latency, ~17 VALU instructions per
-// element, every wave64 VALU instruction occupying its SIMD for ~4 cycles):
-//   * one streaming pass, 16-B BRANCH-FREE loads (clamped index; a conditional load costs a branch
-//     and an immediate vmcnt(0)), two register tiles that ping-pong: the next tile's kHistU loads
-//     per lane are in flight while the current one is binned (and while the LDS histogram is zeroed);
+// Design (round 2; round 1's kernel was VALU-issue bound at ~17 VALU instructions per element):
+//   * ONE persistent kernel serves every entry point: the work is the concatenated list of TILES
+//     (kHistBlock * kHistU float4) of all jobs of the launch, split evenly over a chip-sized grid
+//     (kHistWgPerCu co-resident workgroups per CU, so one workgroup's start-up / flush hides behind
+//     its neighbour's streaming); a workgroup walks its contiguous tile range, keeps counting in LDS
+//     and flushes ONCE per job it touches -- the per-launch row traffic drops from one flush per
+//     512 KB chunk to (grid + jobs) flushes;
+//   * full tiles only in the main loop: no bounds logic, 16-B loads at a wave-uniform base +
+//     constant lane offset, two register tiles that ping-pong (the next tile is in flight while the
+//     current one is binned); the (at most one) ragged tail tile of a job takes a masked scalar path;
+//   * ~8 VALU per element: packed-f32 (v_pk_mul/add) quotient + exactness test on float2 pairs,
+//     floor+convert in ONE instruction (|t| truncation for the symmetric rule, v_cvt_flr for the
+//     asymmetric one), predicated ds_add instead of trash-slot selects;
 //   * the quotient comes from a reciprocal multiply with a provable exactness test and a rare
-//     true-division fallback (quotient_is_safe), ONE divergent region per float4;
-//   * every wavefront group owns a private LDS copy of the histogram (ds_add_u32); nothing is
-//     predicated: clipped / out-of-range / hot values are redirected to a per-lane "trash" slot
-//     behind the histogram, so the ds_add is unconditional and conflict free;
+//     true-division fallback (quot4), ONE divergent region per float4;
 //   * heavily repeated values (ReLU zeros, saturated or already-quantised activations) would
 //     serialise the LDS atomic unit (a k-way same-address ds_add costs ~k cycles): each wave keeps
-//     one wave-uniform "hot bin" whose hits are counted in a VGPR instead (WaveAcc);
-//   * no global atomics on the hot path: every workgroup stores its merged histogram to a scratch
-//     row with plain coalesced stores and hist_reduce_kernel adds the column sums into the caller's
-//     histogram (hundreds of workgroups x thousands of bins of same-line device atomics serialise
-//     at ~12 ns each and would cost more than the streaming pass); observers that see many batches
-//     keep the rows resident instead (accumulate mode) and fold them once;
-//   * hist_t_multi_kernel bins MANY tensors in one launch (job table in the kernel arguments): what a
-//     calibration forward needs, where the tensors are 0.1 .. 100 MB and launch latency dominates.
-#include <cstdlib>
-
+//     one wave-uniform "hot bin" whose hits are counted on the scalar unit (ballot + s_bcnt1);
+//   * no global atomics on the hot path: a workgroup adds its LDS histogram into ITS OWN row of the
+//     caller's persistent [rows][bins] accumulator (plain stream-ordered read-modify-write), folded
+//     once at render; the one-shot entry points store rows to scratch + one reduce launch, or use
+//     device atomics when only a handful of workgroups run (small tensors: one launch).
 #include "common.hpp"
 
 namespace ppqhip {
 
 constexpr int kMaxLdsBins = 16384;     // 64 KiB of int32 per copy at most
-constexpr int kLdsBudgetInts = 8192;   // target: copies * bins <= 8192 ints (32 KiB) per workgroup
-#ifndef PPQHIP_HIST_UBIG
-#define PPQHIP_HIST_UBIG 2   // sweep on MI355X (tools/variants.sh): 2 > 3 > 4 > 1 > 8 with the ping-pong loop
+#ifndef PPQHIP_HIST_LDS_INTS
+#define PPQHIP_HIST_LDS_INTS 2048      // copies * bins <= this many ints: ONE copy at >= 2048 bins (more copies cost
+                                       // zeroing / flush time and buy nothing: LDS conflicts arise within a wave only)
 #endif
-constexpr int kHistUBig = PPQHIP_HIST_UBIG;           // float4 loads in flight per lane (large tensors)
-constexpr int kHistUSmall = 1;         // small tensors: less code to fetch, more workgroups
-constexpr int kHistMaxBlock = 1024;    // histogram workgroups: 256 .. 1024 threads (runtime)
-constexpr int kTrash = 64;             // per-lane trash slots behind every histogram copy
+#ifndef PPQHIP_HIST_BLOCK
+#define PPQHIP_HIST_BLOCK 512
+#endif
+#ifndef PPQHIP_HIST_WGPC
+#define PPQHIP_HIST_WGPC 2
+#endif
+#ifndef PPQHIP_HIST_U
+#define PPQHIP_HIST_U 2               // MI355X sweep (tools/hist_variants.py, profiles/r02_hist_variants.txt): in situ
+#endif                                // 512x2/CU: U=2 327 us, U=1 333, U=3 330, U=4 345; 1024x1 339; 256x4 332; 768x1 328
+#ifndef PPQHIP_HIST_MIN_TILES
+#define PPQHIP_HIST_MIN_TILES 2        // a workgroup is worth launching for at least this many tiles
+#endif
+#ifndef PPQHIP_HIST_ATOMIC_MAX_WG
+#define PPQHIP_HIST_ATOMIC_MAX_WG 64   // one-shot entry points: flush with device atomics up to this grid
+#endif
+#ifndef PPQHIP_HIST_ASM
+#define PPQHIP_HIST_ASM 1              // EXEC-mask commits in inline assembly (Binner::commit4_exec); 0 = compiler-generated
+#endif
+#ifndef PPQHIP_HIST_NT_ELEMS
+#define PPQHIP_HIST_NT_ELEMS (48ll << 20)   // streaming (nontemporal) loads beyond cache residency
+#endif
+constexpr int kLdsBudgetInts = PPQHIP_HIST_LDS_INTS;
+constexpr int kHistBlock = PPQHIP_HIST_BLOCK;          // threads per histogram workgroup (multiple of 64)
+constexpr int kHistWgPerCu = PPQHIP_HIST_WGPC;         // co-resident workgroups per CU
+constexpr int kHistU = PPQHIP_HIST_U;                  // float4 loads in flight per lane and register tile
+constexpr int kHistRows = kNumCU * kHistWgPerCu;       // grid limit == rows of a persistent accumulator
+constexpr uint32_t kTileVec = (uint32_t)kHistBlock * kHistU;   // float4 per tile
+constexpr uint32_t kTileElems = kTileVec * 4;
 constexpr int kHotMin = 12;            // lanes that must share the candidate bin to make it hot
+static_assert(kHistBlock % 64 == 0 && kHistBlock >= 64 && kHistBlock <= 1024, "histogram workgroup: whole waves");
 
-static int env_int(const char* name, int dflt) {
-    const char* v = getenv(name);
-    return v ? atoi(v) : dflt;
-}
-static int hist_blocks_per_cu() { static int v = env_int("PPQHIP_HIST_BLOCKS_PER_CU", 1); return v; }
-static int hist_block() { static int v = env_int("PPQHIP_HIST_BLOCK", 1024); return v; }
-static int hist_hot() { static int v = env_int("PPQHIP_HIST_HOT", 1); return v; }
-static int hist_copies() { static int v = env_int("PPQHIP_HIST_COPIES", 0); return v; }
+typedef float v2f __attribute__((ext_vector_type(2)));
 
 struct BinRule {
     float a;      // sym: unused; asym: min
     float hs;     // hist_scale
-    float rcp;    // RN(1 / hs), see quotient_is_safe
+    float rcp;    // RN(1 / hs), see quot4
     int bins;
     int clip;     // clip_outliers
     int asym;
@@ -72,123 +89,171 @@ static BinRule make_rule(float a, float hs, int bins, int clip, int asym) {
 //   difference is exact and the bound is a power-of-two scaling) the floors are provably equal;
 //   otherwise (a few lanes in 10^4, plus every inf / NaN / huge outlier / degenerate hs) the lane
 //   takes the true division.  The result is therefore ALWAYS the reference's floor(a / hs).
+//   (The test is sign symmetric, so the symmetric rule may run it on x * rcp and use |t| afterwards.)
 __device__ __forceinline__ bool quotient_is_safe(float t) {
     return __builtin_fabsf(t - __builtin_rintf(t)) >= __builtin_fabsf(t) * 0x1p-22f;
 }
 
-// Per-wavefront accumulator.  h points at this wave's histogram copy: bins counters followed by
-// kTrash per-lane trash slots.  ASYM / CLIP specialise the bin rule, HOT enables the hot-bin register.
+// truncation of |t|: == floor for the symmetric rule's non-negative quotient (saturating, NaN -> 0)
+__device__ __forceinline__ int f2i_abs(float t) {
+    int r;
+    asm("v_cvt_i32_f32_e64 %0, |%1|" : "=v"(r) : "v"(t));
+    return r;
+}
+// floor + convert in one instruction; only ever sees finite |t| < 2^23 (everything else took the
+// true-division path, which converts with floorf + v_cvt_i32_f32 like round 1)
+__device__ __forceinline__ int f2i_floor(float t) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(t));
+    return r;
+}
+
+// Per-wavefront accumulator over one LDS histogram copy.  ASYM / CLIP specialise the bin rule, HOT
+// enables the hot-bin register.
 template <bool ASYM, bool CLIP, bool HOT>
-struct WaveAcc {
+struct Binner {
     int* h;
     float a0, hs, rcp;
     int last;        // bins - 1
-    int trash;       // bins + lane
     int hot_bin;     // wave-uniform, -1 = none
     int hot_cnt;     // wave-uniform: hits are counted with ballot + s_bcnt1 (no VALU)
 
-    __device__ __forceinline__ void init(int* copy, const BinRule& r) {
-        h = copy; a0 = r.a; hs = r.hs; rcp = r.rcp; last = r.bins - 1;
-        trash = r.bins + (int)(threadIdx.x & 63);
-        hot_bin = -1; hot_cnt = 0;
+    __device__ __forceinline__ void init(int* copy, int bins) { h = copy; last = bins - 1; hot_bin = -1; hot_cnt = 0; }
+    __device__ __forceinline__ void set_rule(float a, float scale) { a0 = a; hs = scale; rcp = 1.0f / scale; }
+
+    // slots of four values.  Returns bins with the reference's conversion semantics; `exact` lanes
+    // (special values) already went through floorf + saturating convert.
+    __device__ __forceinline__ void bins4(const float4& v, int (&b)[4]) const {
+        v2f x01 = {v.x, v.y}, x23 = {v.z, v.w};
+        if (ASYM) { x01 = x01 - a0; x23 = x23 - a0; }
+        const v2f t01 = x01 * rcp, t23 = x23 * rcp;
+        const v2f r01 = {__builtin_rintf(t01.x), __builtin_rintf(t01.y)};
+        const v2f r23 = {__builtin_rintf(t23.x), __builtin_rintf(t23.y)};
+        const v2f d01 = t01 - r01, d23 = t23 - r23;
+        const v2f e01 = t01 * 0x1p-22f, e23 = t23 * 0x1p-22f;
+        // u_k: lane k is NOT provably safe (also true for NaN: the comparison is unordered)
+        const bool u0 = !(__builtin_fabsf(d01.x) >= __builtin_fabsf(e01.x));
+        const bool u1 = !(__builtin_fabsf(d01.y) >= __builtin_fabsf(e01.y));
+        const bool u2 = !(__builtin_fabsf(d23.x) >= __builtin_fabsf(e23.x));
+        const bool u3 = !(__builtin_fabsf(d23.y) >= __builtin_fabsf(e23.y));
+        b[0] = ASYM ? f2i_floor(t01.x) : f2i_abs(t01.x);
+        b[1] = ASYM ? f2i_floor(t01.y) : f2i_abs(t01.y);
+        b[2] = ASYM ? f2i_floor(t23.x) : f2i_abs(t23.x);
+        b[3] = ASYM ? f2i_floor(t23.y) : f2i_abs(t23.y);
+        if (u0 | u1 | u2 | u3) {                // rare: some lane sits next to a bin boundary
+            if (u0) b[0] = exact_bin(ASYM ? x01.x : __builtin_fabsf(v.x));
+            if (u1) b[1] = exact_bin(ASYM ? x01.y : __builtin_fabsf(v.y));
+            if (u2) b[2] = exact_bin(ASYM ? x23.x : __builtin_fabsf(v.z));
+            if (u3) b[3] = exact_bin(ASYM ? x23.y : __builtin_fabsf(v.w));
+        }
+    }
+    __device__ __forceinline__ int exact_bin(float a) const { return f2i_sat(__builtin_floorf(a / hs)); }
+
+    __device__ __forceinline__ int bin1(float v) const {
+        const float a = ASYM ? (v - a0) : __builtin_fabsf(v);
+        const float t = a * rcp;
+        if (quotient_is_safe(t)) return ASYM ? f2i_floor(t) : f2i_abs(t);
+        return exact_bin(a);
     }
 
-    __device__ __forceinline__ float arg(float v) const { return ASYM ? (v - a0) : __builtin_fabsf(v); }
-
-    // quotient -> effective slot (bin, or the lane's trash slot when the reference skips the value)
-    __device__ __forceinline__ int slot_of(float t) const {
-        const int b = f2i_sat(__builtin_floorf(t));
-        if (CLIP) return ((unsigned)b > (unsigned)last) ? trash : b;      // b < 0 wraps above `last`
-        if (ASYM) return b < 0 ? 0 : (b > last ? last : b);
-        return b > last ? last : b;
+    // population count of a lane mask as a 32-bit SCALAR (two s_bcnt1_i32_b32: a 64-bit count would be
+    // compared / selected on the vector unit, which drags hot_bin / hot_cnt into VGPRs)
+    static __device__ __forceinline__ int popc_mask(unsigned long long m) {
+        return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32));
     }
 
-    // (also tried: v_cvt_flr_i32_f32 for floor+convert -- 1 % and it mis-bins special values --, +inf padding
-    //  instead of the `in` select, a select-free path for full tiles: all within noise on MI355X.)
-    __device__ __forceinline__ void commit(int slot) {
+    // count one value in bin b (as produced by bins4 / bin1); `in` = the value exists.
+    template <bool IN_ALWAYS>
+    __device__ __forceinline__ void commit(int b, bool in) {
+        bool ok = IN_ALWAYS ? true : in;
+        if (CLIP) ok = ok && (unsigned)b <= (unsigned)last;            // b < 0 wraps above `last`
+        else b = ASYM ? (b < 0 ? 0 : (b > last ? last : b)) : (b > last ? last : b);
         if (HOT) {
-            const bool hit = slot == hot_bin;
-            hot_cnt += __popcll(__ballot(hit));     // wave-uniform count: s_bcnt1 + s_add, no VALU
-            slot = hit ? trash : slot;
+            const bool hit = b == hot_bin;
+            // wave-uniform count on the scalar unit: s_and + s_bcnt1 + s_add, no VALU
+            hot_cnt += popc_mask(__builtin_amdgcn_ballot_w64(ok) & __builtin_amdgcn_ballot_w64(hit));
+            if (ok && !hit) atomicAdd(&h[b], 1);
+        } else {
+            if (ok) atomicAdd(&h[b], 1);
         }
-        atomicAdd(&h[slot], 1);
     }
 
-    __device__ __forceinline__ void add4(const float4& v, bool in) {
-        const float ax = arg(v.x), ay = arg(v.y), az = arg(v.z), aw = arg(v.w);
-        float tx = ax * rcp, ty = ay * rcp, tz = az * rcp, tw = aw * rcp;
-        const bool sx = quotient_is_safe(tx), sy = quotient_is_safe(ty), sz = quotient_is_safe(tz),
-                   sw = quotient_is_safe(tw);
-        if (!(sx && sy && sz && sw)) {          // rare: some lane sits next to a bin boundary
-            if (!sx) tx = ax / hs;
-            if (!sy) ty = ay / hs;
-            if (!sz) tz = az / hs;
-            if (!sw) tw = aw / hs;
-        }
-        int bx = slot_of(tx), by = slot_of(ty), bz = slot_of(tz), bw = slot_of(tw);
-        if (!in) { bx = trash; by = trash; bz = trash; bw = trash; }   // CLIP: padded with +inf
-        commit(bx); commit(by); commit(bz); commit(bw);
-    }
-
-    __device__ __forceinline__ int slot1(float v) const {
-        const float a = arg(v);
-        float t = a * rcp;
-        if (!quotient_is_safe(t)) t = a / hs;
-        return slot_of(t);
-    }
-
-    __device__ __forceinline__ void add1(float v, bool in) {
-        int b = slot1(v);
-        if (!in) b = trash;
-        commit(b);
+    // Four full-wave commits (CLIP && HOT, every lane holds a value) with the EXEC mask doing the
+    // predication: per element v_cmpx (b <= last narrows EXEC), v_cmp (hot hits -> VCC, counted with
+    // s_bcnt1 on the scalar unit and removed from EXEC), v_lshl_add (LDS address), ds_add_u32 --
+    // 3 VALU + 4 SALU instead of the ~6 + ~8 the compiler needs for the same logic through lane masks.
+    // Only SGPR / VCC / EXEC hand-offs that the hardware interlocks are used (VALU-written VCC is read by
+    // SALU only; EXEC is restored from an SGPR pair before control returns to compiled code).
+    __device__ __forceinline__ void commit4_exec(const int (&b)[4]) {
+#if PPQHIP_HIST_ASM
+        unsigned long long save;
+        int t0, a0r;
+        int cnt = __builtin_amdgcn_readfirstlane(hot_cnt);
+        const int hot = __builtin_amdgcn_readfirstlane(hot_bin), lastu = __builtin_amdgcn_readfirstlane(last);
+        const unsigned base = (unsigned)(uintptr_t)h;
+        asm volatile(
+            "s_mov_b64 %[sv], exec\n\t"
+            "v_cmpx_ge_u32_e32 vcc, %[last], %[b0]\n\t"
+            "v_cmp_eq_u32_e32 vcc, %[hot], %[b0]\n\t"
+            "s_bcnt1_i32_b64 %[t], vcc\n\t"
+            "s_andn2_b64 exec, exec, vcc\n\t"
+            "s_add_i32 %[cnt], %[cnt], %[t]\n\t"
+            "v_lshl_add_u32 %[a], %[b0], 2, %[base]\n\t"
+            "ds_add_u32 %[a], %[one]\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            "v_cmpx_ge_u32_e32 vcc, %[last], %[b1]\n\t"
+            "v_cmp_eq_u32_e32 vcc, %[hot], %[b1]\n\t"
+            "s_bcnt1_i32_b64 %[t], vcc\n\t"
+            "s_andn2_b64 exec, exec, vcc\n\t"
+            "s_add_i32 %[cnt], %[cnt], %[t]\n\t"
+            "v_lshl_add_u32 %[a], %[b1], 2, %[base]\n\t"
+            "ds_add_u32 %[a], %[one]\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            "v_cmpx_ge_u32_e32 vcc, %[last], %[b2]\n\t"
+            "v_cmp_eq_u32_e32 vcc, %[hot], %[b2]\n\t"
+            "s_bcnt1_i32_b64 %[t], vcc\n\t"
+            "s_andn2_b64 exec, exec, vcc\n\t"
+            "s_add_i32 %[cnt], %[cnt], %[t]\n\t"
+            "v_lshl_add_u32 %[a], %[b2], 2, %[base]\n\t"
+            "ds_add_u32 %[a], %[one]\n\t"
+            "s_mov_b64 exec, %[sv]\n\t"
+            "v_cmpx_ge_u32_e32 vcc, %[last], %[b3]\n\t"
+            "v_cmp_eq_u32_e32 vcc, %[hot], %[b3]\n\t"
+            "s_bcnt1_i32_b64 %[t], vcc\n\t"
+            "s_andn2_b64 exec, exec, vcc\n\t"
+            "s_add_i32 %[cnt], %[cnt], %[t]\n\t"
+            "v_lshl_add_u32 %[a], %[b3], 2, %[base]\n\t"
+            "ds_add_u32 %[a], %[one]\n\t"
+            "s_mov_b64 exec, %[sv]"
+            : [cnt] "+s"(cnt), [sv] "=&s"(save), [t] "=&s"(t0), [a] "=&v"(a0r)
+            : [last] "s"(lastu), [hot] "s"(hot), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]),
+              [base] "v"(base), [one] "v"(1)
+            : "vcc", "scc", "memory");
+        hot_cnt = cnt;
+#else
+        commit<true>(b[0], true); commit<true>(b[1], true); commit<true>(b[2], true); commit<true>(b[3], true);
+#endif
     }
 
     __device__ __forceinline__ void flush_hot() {
         if (!HOT) return;
-        int c = hot_cnt;
-        if ((threadIdx.x & 63) == 0 && c != 0 && hot_bin >= 0) atomicAdd(&h[hot_bin], c);
+        if ((threadIdx.x & 63) == 0 && hot_cnt != 0 && hot_bin >= 0) atomicAdd(&h[hot_bin], hot_cnt);
         hot_cnt = 0;
     }
 
-    // Re-elect the hot bin from one sample value per lane; all lanes of the wave call this together.
-    // The bin of the first in-range lane becomes hot when at least kHotMin lanes share it.
-    __device__ __forceinline__ void elect(float v, bool in) {
+    // Re-elect the hot bin from one bin per lane; all lanes of the wave call this together.  The bin of
+    // the first valid lane becomes hot when at least kHotMin lanes share it.
+    __device__ __forceinline__ void elect(int b, bool in) {
         if (!HOT) return;
-        const int b = slot1(v);
-        const bool valid = in && b <= last;
-        const unsigned long long act = __ballot(valid);
+        const bool valid = in && (unsigned)b <= (unsigned)last;
+        const unsigned long long act = __builtin_amdgcn_ballot_w64(valid);
         if (act == 0ull) return;
-        const int leader = __ffsll((long long)act) - 1;
-        const int cand = __builtin_amdgcn_readlane(b, leader);
+        const int cand = __builtin_amdgcn_readlane(b, __builtin_ctzll(act));
         if (cand == hot_bin) return;
-        const int cnt = __popcll(__ballot(valid && b == cand));
-        if (cnt >= kHotMin) { flush_hot(); hot_bin = cand; }
+        const int share = popc_mask(act & __builtin_amdgcn_ballot_w64(b == cand));
+        if (share >= kHotMin) { flush_hot(); hot_bin = cand; }
     }
 };
-
-__device__ __forceinline__ void lds_hist_zero(int* lds, int total) {
-    for (int i = threadIdx.x; i < total; i += blockDim.x) lds[i] = 0;
-    __syncthreads();
-}
-
-// partial == nullptr: merge the copies and flush the non-zero bins with global atomics (few
-// workgroups).  Otherwise store this workgroup's merged histogram to partial[blockIdx.x][bins].
-// accumulate == true: partial is a persistent [workgroups][bins] accumulator owned by the caller
-// (one row per workgroup, so a plain read-modify-write is race free and stream ordered): nothing is
-// reduced per launch, ppqhip_hist_rows_finish sums the rows once, when the histogram is needed.
-__device__ __forceinline__ void lds_hist_flush(const int* lds, int bins, int copies, int* __restrict__ hist,
-                                               int* __restrict__ partial = nullptr, bool accumulate = false,
-                                               uint32_t row = blockIdx.x) {
-    __syncthreads();
-    const int pitch = bins + kTrash;
-    int* dst = partial ? partial + (size_t)row * bins : nullptr;
-    for (int b = threadIdx.x; b < bins; b += blockDim.x) {
-        int s = 0;
-        for (int c = 0; c < copies; c++) s += lds[c * pitch + b];
-        if (dst) { if (accumulate) { if (s) dst[b] += s; } else dst[b] = s; }
-        else if (s) atomicAdd(&hist[b], s);
-    }
-}
 
 // column sums of partial[count][bins] into hist.  grid = (ceil(bins / 256), slices): each thread
 // sums its bin over one slice of the partial histograms (coalesced 1-KiB rows, 8 loads in flight)
@@ -212,150 +277,151 @@ __global__ __launch_bounds__(kBlock) void hist_reduce_kernel(const int* __restri
     if (s) atomicAdd(&hist[b], s);
 }
 
-// Shared streaming loop.  FQ = true additionally writes out = fake_quant(x) (fused calibration step).
-template <bool ASYM, bool CLIP, bool HOT, bool FQ, int R, bool NT, int kHistU>
-__device__ __forceinline__ void hist_stream(const float* __restrict__ x, uint32_t n, int vec_ok, const BinRule& rule,
-                                            int copies, int* lds, float* __restrict__ out, float s, int o, int qmin,
-                                            int qmax, int rounding, uint32_t bidx, uint32_t nblk) {
-    // bidx / nblk: this workgroup's index among the workgroups that share the tensor (== blockIdx.x /
-    // gridDim.x for the single-tensor kernels; a sub-range of the grid for hist_t_multi_kernel)
-    const uint32_t stride = nblk * blockDim.x;
-    const uint32_t nvec = vec_ok ? (n >> 2) : 0u;
-    const float4* xv = reinterpret_cast<const float4*>(x);
-    float4* ov = reinterpret_cast<float4*>(out);
-    // Every workgroup owns one contiguous chunk of `trips` tiles (blockDim * kHistU float4 each): better
-    // DRAM-page / TLB locality than a grid-strided interleave.  The trip count is uniform over the
-    // whole grid, so the ballots of WaveAcc::elect always see whole wavefronts.
-    const uint32_t bd = blockDim.x;
-    const uint32_t tile = bd * kHistU;
-    const uint32_t trips = ((nvec + tile - 1) / tile + nblk - 1) / nblk;
-    const uint32_t hi = min((bidx + 1) * trips * tile, nvec);
-    uint32_t v = bidx * trips * tile + threadIdx.x;
-    const uint32_t last_v = nvec ? nvec - 1 : 0u;
-    float4 bufa[kHistU], bufb[kHistU];
-    auto fetch = [&](float4 (&buf)[kHistU], uint32_t at) {
-        // branch-free: out-of-range lanes re-read the tensor's last float4 (their values are ignored
-        // through `in`), so the loads stay straight-line code and remain in flight while the
-        // previous tile is binned -- a conditional load costs a branch and an immediate vmcnt(0).
-#pragma unroll
-        for (int k = 0; k < kHistU; k++) buf[k] = load4<NT>(&xv[min(at + k * bd, last_v)]);
-    };
-    if (trips) fetch(bufa, v);
-    const int pitch = rule.bins + kTrash;
-    lds_hist_zero(lds, copies * pitch);          // first trip's loads are in flight meanwhile
-    WaveAcc<ASYM, CLIP, HOT> acc;
-    acc.init(lds + ((threadIdx.x >> 6) % copies) * pitch, rule);
-    auto consume = [&](const float4 (&buf)[kHistU], uint32_t at) {
-        acc.elect(buf[0].x, at < hi);
-#pragma unroll
-        for (int k = 0; k < kHistU; k++) {
-            const bool in = at + k * bd < hi;
-            if (FQ && in) {
-                float4 r;
-                r.x = fq_linear_scalar<R>(buf[k].x, s, o, qmin, qmax, rounding);
-                r.y = fq_linear_scalar<R>(buf[k].y, s, o, qmin, qmax, rounding);
-                r.z = fq_linear_scalar<R>(buf[k].z, s, o, qmin, qmax, rounding);
-                r.w = fq_linear_scalar<R>(buf[k].w, s, o, qmin, qmax, rounding);
-                ov[at + k * bd] = r;
-            }
-            acc.add4(buf[k], in);
-        }
-    };
-    // two trips per iteration, ping-ponging between the register tiles (no tile-sized copy); the
-    // next tile's loads are issued before the current tile is binned.
-    for (uint32_t t = 0; t < trips; t += 2, v += 2 * tile) {
-        fetch(bufb, v + tile);
-        consume(bufa, v);
-        if (t + 1 < trips) {
-            fetch(bufa, v + 2 * tile);
-            consume(bufb, v + tile);
-        }
-    }
-    {   // scalar remainder (the whole tensor when it is not 16-B aligned)
-        const uint32_t done = nvec << 2;
-        const uint32_t rem = n - done;
-        const uint32_t rtrips = (rem + stride - 1) / stride;
-        uint32_t i = bidx * blockDim.x + threadIdx.x;
-        for (uint32_t t = 0; t < rtrips; t++, i += stride) {
-            const bool in = i < rem;
-            const float a = in ? x[done + i] : 0.f;
-            if (FQ && in) out[done + i] = fq_linear_scalar<R>(a, s, o, qmin, qmax, rounding);
-            if ((t & 15u) == 0) acc.elect(a, in);
-            acc.add1(a, in);
-        }
-    }
-    acc.flush_hot();
-}
-
-template <bool ASYM, bool CLIP, bool HOT, bool NT, int U>
-__global__ __launch_bounds__(kHistMaxBlock) void hist_t_lds_kernel(const float* __restrict__ x, uint32_t n, int vec_ok,
-                                                                   BinRule rule, int copies, int* __restrict__ hist,
-                                                                   int* __restrict__ partial, int accumulate) {
-    extern __shared__ int lds[];
-    hist_stream<ASYM, CLIP, HOT, false, 0, NT, U>(x, n, vec_ok, rule, copies, lds, nullptr, 0.f, 0, 0, 0, 0, blockIdx.x,
-                                                  gridDim.x);
-    lds_hist_flush(lds, rule.bins, copies, hist, partial, accumulate != 0);
-}
-
-// ---- many tensors, one launch --------------------------------------------------------------------
-// A calibration forward observes ~70 activation tensors of 3..100 MB; launched one by one every
-// histogram pays ~5 us of launch / fill / drain latency on top of its streaming time.  The observers
-// therefore queue their tensors and ONE launch bins them all: the job table travels by value in the
-// kernel arguments, job j owns workgroups [first_block[j], first_block[j+1]) and each of them streams
-// a contiguous chunk of its tensor into LDS and adds it to its own row of that job's persistent
-// rows buffer (same accumulate-mode contract as ppqhip_hist_*_t_rows).
-constexpr int kMultiMax = 96;                 // jobs per launch (3.1 KB of kernel arguments; the limit is 4 KB)
-#ifndef PPQHIP_MULTI_CHUNK
-#define PPQHIP_MULTI_CHUNK (128u << 10)
-#endif
-#ifndef PPQHIP_MULTI_U
-#define PPQHIP_MULTI_U kHistUBig     // MI355X sweep (tools/multi_bench.py): U=2 5.0 TB/s, U=1 4.8; chunk 512 KB > 256 KB, 1 MB, 2 MB
-#endif
-constexpr uint32_t kMultiChunk = PPQHIP_MULTI_CHUNK;  // elements per workgroup (512 KB): rows RMW is 3 % of the read
+// ---- the persistent kernel ---------------------------------------------------------------------
+constexpr int kMultiMax = 96;          // jobs per launch (3.1 KB of kernel arguments; the limit is 4 KB)
+enum FlushMode : int {
+    FLUSH_ROWS_ADD = 0,     // job.rows[blockIdx.x][bins] += (persistent accumulator, race free: one row per workgroup)
+    FLUSH_ROWS_STORE = 1,   // job.rows[blockIdx.x][bins]  = (scratch for hist_reduce_kernel)
+    FLUSH_ATOMIC = 2        // atomicAdd into job.rows[bins] (== the caller's histogram; few workgroups)
+};
 struct HistJob {                              // 32 B
     const float* x;
     int* rows;
     uint32_t n;
     float a, hs;
-    uint32_t first_block;
+    uint32_t first_tile;                      // prefix sum of tiles over the jobs of the launch
 };
 struct HistJobs {
     HistJob job[kMultiMax];
     uint32_t count;
-    int bins, clip, copies;
+    uint32_t total_tiles;
+    int bins, copies, mode;
+};
+struct FqArgs {                               // fused fake-quant of the (single) job: out = fq_linear_t(x)
+    const float* scale;
+    const float* offset;
+    float* out;
+    int qmin, qmax, rounding;
 };
 
-template <bool ASYM, bool CLIP, bool HOT, int U>
-__global__ __launch_bounds__(kHistMaxBlock) void hist_t_multi_kernel(const HistJobs jobs) {
-    extern __shared__ int lds[];
-    uint32_t lo = 0, hi = jobs.count;          // largest lo with first_block[lo] <= blockIdx.x (uniform)
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (jobs.job[mid].first_block <= blockIdx.x) lo = mid; else hi = mid;
-    }
-    const HistJob& j = jobs.job[lo];
-    const uint32_t end = lo + 1 < jobs.count ? jobs.job[lo + 1].first_block : gridDim.x;
-    const uint32_t bidx = blockIdx.x - j.first_block, nblk = end - j.first_block;
-    BinRule rule;
-    rule.a = j.a; rule.hs = j.hs; rule.rcp = 1.0f / j.hs; rule.bins = jobs.bins; rule.clip = jobs.clip; rule.asym = ASYM;
-    const int vec_ok = (reinterpret_cast<uintptr_t>(j.x) & 15u) == 0;
-    hist_stream<ASYM, CLIP, HOT, false, 0, false, U>(j.x, j.n, vec_ok, rule, jobs.copies, lds, nullptr, 0.f, 0, 0,
-                                                     0, 0, bidx, nblk);
-    lds_hist_flush(lds, jobs.bins, jobs.copies, nullptr, j.rows, true, bidx);
+__host__ __device__ inline uint32_t job_tiles(uint32_t n, bool vec_ok) {
+    if (!vec_ok) return (n + kTileElems - 1) / kTileElems;          // every tile through the scalar path
+    const uint32_t full = (n >> 2) / kTileVec;
+    return full + (n > full * kTileElems ? 1u : 0u);                 // + one ragged tail tile
 }
 
-// fused: out = fake_quant(x) (== fq_linear_t) and hist += histogram(x) (== hist_sym_t), one read
-template <int R, bool CLIP, bool HOT>
-__global__ __launch_bounds__(kHistMaxBlock) void fq_linear_t_hist_kernel(
-    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
-    float* __restrict__ out, uint32_t n, int vec_ok, int qmin, int qmax, int rounding, BinRule rule, int copies,
-    int* __restrict__ hist, int* __restrict__ partial) {
+// merge this workgroup's LDS copies into its destination and leave the copies zeroed
+__device__ __forceinline__ void lds_hist_flush(int* lds, int bins, int copies, int* __restrict__ dst, int mode) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the inline-assembly ds_adds are invisible to the compiler's counters
+    __syncthreads();
+    for (int b = threadIdx.x; b < bins; b += kHistBlock) {
+        int s = 0;
+        for (int c = 0; c < copies; c++) { s += lds[c * bins + b]; lds[c * bins + b] = 0; }
+        if (mode == FLUSH_ROWS_STORE) dst[b] = s;
+        else if (s) {
+            if (mode == FLUSH_ROWS_ADD) dst[b] += s;
+            else atomicAdd(&dst[b], s);
+        }
+    }
+    __syncthreads();
+}
+
+template <bool ASYM, bool CLIP, bool HOT, bool NT, bool FQ, int R>
+__global__ __launch_bounds__(kHistBlock, (kHistBlock * kHistWgPerCu + 255) / 256)
+void hist_persistent_kernel(const HistJobs jobs, const FqArgs fq) {
     extern __shared__ int lds[];
-    const float s = scale[0];
-    const int o = round_offset(offset[0]);
-    hist_stream<false, CLIP, HOT, true, R, false, kHistUBig>(x, n, vec_ok, rule, copies, lds, out, s, o, qmin, qmax, rounding,
-                                                             blockIdx.x, gridDim.x);
-    lds_hist_flush(lds, rule.bins, copies, hist, partial);
+    const uint32_t G = gridDim.x, g = blockIdx.x;
+    uint32_t t = (uint32_t)(((uint64_t)g * jobs.total_tiles) / G);
+    const uint32_t t_end = (uint32_t)(((uint64_t)(g + 1) * jobs.total_tiles) / G);
+    const int bins = jobs.bins, copies = jobs.copies;
+    for (int i = threadIdx.x; i < copies * bins; i += kHistBlock) lds[i] = 0;
+    __syncthreads();
+    if (t >= t_end) {                       // more workgroups than tiles: nothing to bin
+        if (jobs.mode == FLUSH_ROWS_STORE) for (int b = threadIdx.x; b < bins; b += kHistBlock) jobs.job[0].rows[(size_t)g * bins + b] = 0;
+        return;
+    }
+    uint32_t lo = 0, hi = jobs.count;       // largest lo with first_tile[lo] <= t (wave uniform)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (jobs.job[mid].first_tile <= t) lo = mid; else hi = mid;
+    }
+    Binner<ASYM, CLIP, HOT> acc;
+    acc.init(lds + ((threadIdx.x >> 6) % copies) * bins, bins);
+    float fs = 0.f; int fo = 0;
+    if (FQ) { fs = fq.scale[0]; fo = round_offset(fq.offset[0]); }
+
+    for (uint32_t j = lo; t < t_end; j++) {
+        const HistJob& job = jobs.job[j];
+        const uint32_t j_end = (j + 1 < jobs.count) ? jobs.job[j + 1].first_tile : jobs.total_tiles;
+        uint32_t k = t - job.first_tile;                                   // tiles [k, k1) of this job
+        const uint32_t k1 = min(t_end, j_end) - job.first_tile;
+        t = min(t_end, j_end);
+        acc.set_rule(job.a, job.hs);
+        const float* __restrict__ x = job.x;
+        const uint32_t n = job.n;
+        const bool vec_ok = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (!FQ || (reinterpret_cast<uintptr_t>(fq.out) & 15u) == 0);
+        const uint32_t full = vec_ok ? (n >> 2) / kTileVec : 0u;
+        const uint32_t kf = min(k1, full);                                 // full tiles [k, kf)
+        if (k < kf) {
+            const float4* xv = reinterpret_cast<const float4*>(x) + threadIdx.x;
+            float4* ov = FQ ? reinterpret_cast<float4*>(fq.out) + threadIdx.x : nullptr;
+            float4 bufa[kHistU], bufb[kHistU];
+            auto fetch = [&](float4 (&buf)[kHistU], uint32_t tile) {
+                const float4* p = xv + (size_t)tile * kTileVec;
+#pragma unroll
+                for (int u = 0; u < kHistU; u++) buf[u] = load4<NT>(p + u * kHistBlock);
+            };
+            auto consume = [&](const float4 (&buf)[kHistU], uint32_t tile) {
+#pragma unroll
+                for (int u = 0; u < kHistU; u++) {
+                    if (FQ) {
+                        float4 r;
+                        r.x = fq_linear_scalar<R>(buf[u].x, fs, fo, fq.qmin, fq.qmax, fq.rounding);
+                        r.y = fq_linear_scalar<R>(buf[u].y, fs, fo, fq.qmin, fq.qmax, fq.rounding);
+                        r.z = fq_linear_scalar<R>(buf[u].z, fs, fo, fq.qmin, fq.qmax, fq.rounding);
+                        r.w = fq_linear_scalar<R>(buf[u].w, fs, fo, fq.qmin, fq.qmax, fq.rounding);
+                        ov[(size_t)tile * kTileVec + u * kHistBlock] = r;
+                    }
+                    int b[4];
+                    acc.bins4(buf[u], b);
+                    if (u == 0) acc.elect(b[0], true);
+                    if (CLIP && HOT) acc.commit4_exec(b);
+                    else {
+                        acc.template commit<true>(b[0], true); acc.template commit<true>(b[1], true);
+                        acc.template commit<true>(b[2], true); acc.template commit<true>(b[3], true);
+                    }
+                }
+            };
+            // ping-pong between two register tiles; the prefetch index is clamped (wave uniform), so the
+            // loads stay unconditional straight-line code: the last tile of the range is fetched twice.
+            fetch(bufa, k);
+            for (;;) {
+                fetch(bufb, min(k + 1, kf - 1));
+                consume(bufa, k);
+                if (++k >= kf) break;
+                fetch(bufa, min(k + 1, kf - 1));
+                consume(bufb, k);
+                if (++k >= kf) break;
+            }
+        }
+        for (; k < k1; k++) {             // ragged tail tile (or a tensor that is not 16-B aligned): masked 4-B loads
+            const uint32_t e0 = k * kTileElems + threadIdx.x;
+#pragma unroll 4
+            for (int r = 0; r < 4 * kHistU; r++) {
+                const uint32_t i = e0 + r * kHistBlock;
+                const bool in = i < n;
+                const float a = in ? x[i] : 0.f;
+                if (FQ && in) fq.out[i] = fq_linear_scalar<R>(a, fs, fo, fq.qmin, fq.qmax, fq.rounding);
+                const int b = acc.bin1(a);
+                if ((r & 3) == 0) acc.elect(b, in);
+                acc.template commit<false>(b, in);
+            }
+        }
+        acc.flush_hot();
+        acc.hot_bin = -1;
+        int* dst = jobs.mode == FLUSH_ATOMIC ? job.rows : job.rows + (size_t)g * bins;
+        lds_hist_flush(lds, bins, copies, dst, jobs.mode);
+    }
 }
 
 // histograms too large for LDS: global atomics (the reference's strategy)
@@ -385,14 +451,14 @@ __global__ __launch_bounds__(kBlock) void hist_c_row_kernel(const float* __restr
                                                             int copies, int* __restrict__ hist,
                                                             const float* __restrict__ scales) {
     extern __shared__ int lds[];
-    const int pitch = rule.bins + kTrash;
-    lds_hist_zero(lds, copies * pitch);
+    for (int i = threadIdx.x; i < copies * rule.bins; i += kBlock) lds[i] = 0;
+    __syncthreads();
     const uint32_t row = fdiv(blockIdx.x, chunks);
     const uint32_t chunk = blockIdx.x - row * chunks.d;
     const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
-    if (scales != nullptr) { rule.hs = scales[c]; rule.rcp = 1.0f / rule.hs; }     // per-channel hist_scale
-    WaveAcc<false, CLIP, true> acc;
-    acc.init(lds + ((threadIdx.x >> 6) % copies) * pitch, rule);
+    Binner<false, CLIP, true> acc;
+    acc.init(lds + ((threadIdx.x >> 6) % copies) * rule.bins, rule.bins);
+    acc.set_rule(0.f, scales != nullptr ? scales[c] : rule.hs);          // per-channel hist_scale
     const uint32_t lo = chunk * chunk_elems;
     const uint32_t hi = min(lo + chunk_elems, epc);
     const float* xr = x + (size_t)row * epc;
@@ -400,12 +466,18 @@ __global__ __launch_bounds__(kBlock) void hist_c_row_kernel(const float* __restr
     uint32_t j = lo + threadIdx.x;
     for (uint32_t t = 0; t < trips; t++, j += kBlock) {
         const bool in = j < hi;
-        const float a = in ? xr[j] : 0.f;
-        if ((t & 15u) == 0) acc.elect(a, in);
-        acc.add1(a, in);
+        const int b = acc.bin1(in ? xr[j] : 0.f);
+        if ((t & 15u) == 0) acc.elect(b, in);
+        acc.template commit<false>(b, in);
     }
     acc.flush_hot();
-    lds_hist_flush(lds, rule.bins, copies, hist + (size_t)c * rule.bins);
+    __syncthreads();
+    int* dst = hist + (size_t)c * rule.bins;
+    for (int b = threadIdx.x; b < rule.bins; b += kBlock) {
+        int sum = 0;
+        for (int k = 0; k < copies; k++) sum += lds[k * rule.bins + b];
+        if (sum) atomicAdd(&dst[b], sum);
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void hist_c_global_kernel(const float* __restrict__ x, uint32_t n,
@@ -434,35 +506,68 @@ static int validate(int64_t n, int64_t bins, const char* what) {
 
 static int pick_copies(int bins, int block) {
     int c = kLdsBudgetInts / bins;
-    if (hist_copies() > 0) c = hist_copies();
     if (c < 1) c = 1;
     if (c > block / kWave) c = block / kWave;
     return c;
 }
 
-static size_t lds_bytes(int bins, int copies) { return sizeof(int) * (size_t)copies * (bins + kTrash); }
-
-static int hist_grid(int64_t n, int u) {
-    // one trip (u float4 per lane) per workgroup at least; bounded workgroup count: every
-    // workgroup pays LDS zeroing + a flush of `bins` counters
-    return stream_grid(n, (int64_t)hist_block() * 4 * u, kNumCU * hist_blocks_per_cu());
-}
-
-constexpr int kAtomicFlushMaxBlocks = 8;
-
-// scratch for the two-stage flush, or nullptr when the launch is small enough for atomics
-static int* partial_for(int grid, int bins, hipStream_t s, bool* failed, void* workspace) {
-    *failed = false;
-    if (grid <= kAtomicFlushMaxBlocks) return nullptr;
-    if (workspace) return (int*)workspace;
-    int* p = (int*)scratch(s, sizeof(int) * (size_t)grid * bins);
-    if (p == nullptr) *failed = true;
-    return p;
-}
+static size_t lds_bytes(int bins, int copies) { return sizeof(int) * (size_t)copies * bins; }
 
 static void launch_reduce(const int* partial, int grid, int bins, int32_t* hist, hipStream_t s) {
     hipLaunchKernelGGL(hist_reduce_kernel, dim3((bins + kBlock - 1) / kBlock, kReduceSlices), dim3(kBlock), 0, s,
                        partial, grid, bins, hist);
+}
+
+template <bool FQ, int R>
+static void launch_persistent(const HistJobs& args, const FqArgs& fq, int grid, int asym, int clip, bool nt, hipStream_t s) {
+    const size_t lds = lds_bytes(args.bins, args.copies);
+#define PPQ_LAUNCH_HIST(A, C)                                                                                         \
+    do {                                                                                                              \
+        if (nt) hipLaunchKernelGGL((hist_persistent_kernel<A, C, true, true, FQ, R>), dim3(grid), dim3(kHistBlock),  \
+                                   lds, s, args, fq);                                                                 \
+        else hipLaunchKernelGGL((hist_persistent_kernel<A, C, true, false, FQ, R>), dim3(grid), dim3(kHistBlock),    \
+                                lds, s, args, fq);                                                                    \
+    } while (0)
+    switch ((asym ? 2 : 0) | (clip ? 1 : 0)) {
+        case 0: PPQ_LAUNCH_HIST(false, false); break;
+        case 1: PPQ_LAUNCH_HIST(false, true); break;
+        case 2: PPQ_LAUNCH_HIST(true, false); break;
+        default: PPQ_LAUNCH_HIST(true, true); break;
+    }
+#undef PPQ_LAUNCH_HIST
+}
+
+// grid for `tiles` tiles: every workgroup gets at least kMinTiles of them, at most kHistRows workgroups
+static int persistent_grid(uint32_t tiles) {
+    uint32_t g = tiles / PPQHIP_HIST_MIN_TILES;
+    if (g < 1) g = 1;
+    if (g > (uint32_t)kHistRows) g = kHistRows;
+    return (int)g;
+}
+
+// one-shot histogram of one tensor, accumulated into hist[bins] (rows == nullptr) or into the caller's
+// persistent rows[kHistRows][bins]
+template <bool FQ, int R>
+static int launch_hist_one(const float* x, int64_t n, BinRule rule, int32_t* hist, void* workspace, hipStream_t s,
+                           int32_t* rows, const FqArgs& fq) {
+    HistJobs args;
+    args.count = 1; args.bins = rule.bins; args.copies = pick_copies(rule.bins, kHistBlock);
+    HistJob& d = args.job[0];
+    d.x = x; d.n = (uint32_t)n; d.a = rule.a; d.hs = rule.hs; d.first_tile = 0;
+    const bool vec_ok = aligned16(x) && (!FQ || aligned16(fq.out));
+    args.total_tiles = job_tiles((uint32_t)n, vec_ok);
+    const int grid = persistent_grid(args.total_tiles);
+    int* partial = nullptr;
+    if (rows) { args.mode = FLUSH_ROWS_ADD; d.rows = rows; }
+    else if (grid <= PPQHIP_HIST_ATOMIC_MAX_WG) { args.mode = FLUSH_ATOMIC; d.rows = hist; }
+    else {
+        partial = workspace ? (int*)workspace : (int*)scratch(s, sizeof(int) * (size_t)grid * rule.bins);
+        if (partial == nullptr) return PPQHIP_ERR_HIP;
+        args.mode = FLUSH_ROWS_STORE; d.rows = partial;
+    }
+    launch_persistent<FQ, R>(args, fq, grid, rule.asym, rule.clip, n >= PPQHIP_HIST_NT_ELEMS, s);
+    if (partial) launch_reduce(partial, grid, rule.bins, hist, s);
+    return PPQHIP_OK;
 }
 
 static int launch_hist_t(const float* x, int64_t n, BinRule rule, int32_t* hist, void* workspace, hipStream_t s,
@@ -472,80 +577,29 @@ static int launch_hist_t(const float* x, int64_t n, BinRule rule, int32_t* hist,
                            rule, hist);
         return PPQHIP_OK;
     }
-    const int block = hist_block();
-    const int copies = pick_copies(rule.bins, block);
-    const size_t lds = lds_bytes(rule.bins, copies);
-    const int vec_ok = aligned16(x) ? 1 : 0;
-    static const int small_elems = env_int("PPQHIP_HIST_SMALL_ELEMS", 48 << 20);   // sweep: U=1 wins up to ~100 MB
-    const bool small = n < small_elems;
-    const int grid = hist_grid(n, small ? kHistUSmall : kHistUBig);
-    bool failed = false;
-    const int accumulate = rows != nullptr;
-    int* partial = rows ? rows : partial_for(grid, rule.bins, s, &failed, workspace);
-    if (failed) return PPQHIP_ERR_HIP;
-#define PPQ_LAUNCH_HIST(A, C, H)                                                                                  \
-    do {                                                                                                          \
-        if (small) hipLaunchKernelGGL((hist_t_lds_kernel<A, C, H, false, kHistUSmall>), dim3(grid), dim3(block), \
-                                      lds, s, x, (uint32_t)n, vec_ok, rule, copies, hist, partial, accumulate);  \
-        else if (nt) hipLaunchKernelGGL((hist_t_lds_kernel<A, C, H, true, kHistUBig>), dim3(grid), dim3(block),  \
-                                        lds, s, x, (uint32_t)n, vec_ok, rule, copies, hist, partial, accumulate);\
-        else hipLaunchKernelGGL((hist_t_lds_kernel<A, C, H, false, kHistUBig>), dim3(grid), dim3(block), lds, s, \
-                                x, (uint32_t)n, vec_ok, rule, copies, hist, partial, accumulate);                \
-    } while (0)
-    static const int nt_env = env_int("PPQHIP_HIST_NT", -1);
-    const bool nt = nt_env >= 0 ? nt_env != 0 : n >= (48ll << 20);    // streaming loads beyond cache residency
-    const int sel = (rule.asym ? 4 : 0) | (rule.clip ? 2 : 0) | (hist_hot() ? 1 : 0);
-    switch (sel) {
-        case 0: PPQ_LAUNCH_HIST(false, false, false); break;
-        case 1: PPQ_LAUNCH_HIST(false, false, true); break;
-        case 2: PPQ_LAUNCH_HIST(false, true, false); break;
-        case 3: PPQ_LAUNCH_HIST(false, true, true); break;
-        case 4: PPQ_LAUNCH_HIST(true, false, false); break;
-        case 5: PPQ_LAUNCH_HIST(true, false, true); break;
-        case 6: PPQ_LAUNCH_HIST(true, true, false); break;
-        default: PPQ_LAUNCH_HIST(true, true, true); break;
-    }
-#undef PPQ_LAUNCH_HIST
-    if (partial && !accumulate) launch_reduce(partial, grid, rule.bins, hist, s);
-    return PPQHIP_OK;
+    return launch_hist_one<false, 0>(x, n, rule, hist, workspace, s, rows, FqArgs{});
 }
 
 static int launch_hist_multi(const ppqhip_hist_job* jobs, int count, int bins, int clip, int asym, hipStream_t s) {
-    const int block = hist_block();
-    const int copies = pick_copies(bins, block);
-    const size_t lds = lds_bytes(bins, copies);
-    const uint32_t max_rows = (uint32_t)(kNumCU * hist_blocks_per_cu());
+    const int copies = pick_copies(bins, kHistBlock);
     for (int base = 0; base < count; base += kMultiMax) {
         HistJobs args;
         args.count = (uint32_t)((count - base) < kMultiMax ? (count - base) : kMultiMax);
-        args.bins = bins; args.clip = clip; args.copies = copies;
-        uint32_t blocks = 0;
+        args.bins = bins; args.copies = copies; args.mode = FLUSH_ROWS_ADD;
+        uint32_t tiles = 0;
+        int64_t elems = 0;
         for (uint32_t k = 0; k < args.count; k++) {
             const ppqhip_hist_job& src = jobs[base + k];
             HistJob& d = args.job[k];
             d.x = src.x; d.rows = src.rows; d.n = (uint32_t)src.n;
             if (asym) { d.a = src.p0; d.hs = (src.p1 - src.p0) / (float)bins; }     // sort.cu:123
             else { d.a = 0.f; d.hs = src.p0; }
-            d.first_block = blocks;
-            uint32_t nb = (uint32_t)((src.n + kMultiChunk - 1) / kMultiChunk);
-            if (nb > max_rows) nb = max_rows;
-            if (nb < 1) nb = 1;
-            blocks += nb;
+            d.first_tile = tiles;
+            tiles += job_tiles(d.n, aligned16(src.x));
+            elems += src.n;
         }
-#define PPQ_LAUNCH_MULTI(A, C, H)                                                                              \
-        hipLaunchKernelGGL((hist_t_multi_kernel<A, C, H, PPQHIP_MULTI_U>), dim3(blocks), dim3(block), lds, s, args)
-        const int sel = (asym ? 4 : 0) | (clip ? 2 : 0) | (hist_hot() ? 1 : 0);
-        switch (sel) {
-            case 0: PPQ_LAUNCH_MULTI(false, false, false); break;
-            case 1: PPQ_LAUNCH_MULTI(false, false, true); break;
-            case 2: PPQ_LAUNCH_MULTI(false, true, false); break;
-            case 3: PPQ_LAUNCH_MULTI(false, true, true); break;
-            case 4: PPQ_LAUNCH_MULTI(true, false, false); break;
-            case 5: PPQ_LAUNCH_MULTI(true, false, true); break;
-            case 6: PPQ_LAUNCH_MULTI(true, true, false); break;
-            default: PPQ_LAUNCH_MULTI(true, true, true); break;
-        }
-#undef PPQ_LAUNCH_MULTI
+        args.total_tiles = tiles;
+        launch_persistent<false, 0>(args, FqArgs{}, persistent_grid(tiles), asym, clip, elems >= PPQHIP_HIST_NT_ELEMS, s);
     }
     return PPQHIP_OK;
 }
@@ -559,7 +613,7 @@ extern "C" {
 int64_t ppqhip_hist_workspace_bytes(int64_t n, int64_t num_bins) {
     (void)n;
     if (num_bins <= 0 || num_bins > kMaxLdsBins) return 0;
-    return (int64_t)sizeof(int) * kNumCU * hist_blocks_per_cu() * num_bins;
+    return (int64_t)sizeof(int) * kHistRows * num_bins;
 }
 
 int ppqhip_hist_sym_t(const float* x, int64_t n, float hist_scale, int clip_outliers, int32_t* hist,
@@ -585,7 +639,7 @@ int ppqhip_hist_asym_t(const float* x, int64_t n, float min_value, float max_val
 }
 
 /* ---- persistent-row variants (MI355X-native: the observer keeps [rows][bins] resident) ---- */
-int64_t ppqhip_hist_rows(void) { return (int64_t)kNumCU * hist_blocks_per_cu(); }
+int64_t ppqhip_hist_rows(void) { return (int64_t)kHistRows; }
 
 int ppqhip_hist_sym_t_rows(const float* x, int64_t n, float hist_scale, int clip_outliers, int32_t* rows,
                            int64_t num_bins, void* stream) {
@@ -691,31 +745,33 @@ int ppqhip_fq_linear_t_hist_sym(const float* x, const float* scale, const float*
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_FQ_HIST_FUSED, 8.0 * (double)n, s);
     BinRule rule = make_rule(0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, 0);
-    const int block = hist_block();
-    const int copies = pick_copies(rule.bins, block);
-    const size_t lds = lds_bytes(rule.bins, copies);
-    const int vec_ok = (aligned16(x) && aligned16(out)) ? 1 : 0;
-    const int grid = hist_grid(n, kHistUBig);
-    bool failed;
-    int* partial = partial_for(grid, rule.bins, s, &failed, workspace);
-    if (failed) return PPQHIP_ERR_HIP;
-#define PPQ_LAUNCH_FUSED(R, C, H)                                                                                   \
-    hipLaunchKernelGGL((fq_linear_t_hist_kernel<R, C, H>), dim3(grid), dim3(block), lds, s, x, scale, offset, out,  \
-                       (uint32_t)n, vec_ok, clip_min, clip_max, rounding, rule, copies, hist, partial)
-    const int sel = (rounding == ROUND_HALF_EVEN ? 4 : 0) | (rule.clip ? 2 : 0) | (hist_hot() ? 1 : 0);
-    switch (sel) {
-        case 0: PPQ_LAUNCH_FUSED(-1, false, false); break;
-        case 1: PPQ_LAUNCH_FUSED(-1, false, true); break;
-        case 2: PPQ_LAUNCH_FUSED(-1, true, false); break;
-        case 3: PPQ_LAUNCH_FUSED(-1, true, true); break;
-        case 4: PPQ_LAUNCH_FUSED(ROUND_HALF_EVEN, false, false); break;
-        case 5: PPQ_LAUNCH_FUSED(ROUND_HALF_EVEN, false, true); break;
-        case 6: PPQ_LAUNCH_FUSED(ROUND_HALF_EVEN, true, false); break;
-        default: PPQ_LAUNCH_FUSED(ROUND_HALF_EVEN, true, true); break;
-    }
-#undef PPQ_LAUNCH_FUSED
-    if (partial) launch_reduce(partial, grid, rule.bins, hist, s);
+    FqArgs fq;
+    fq.scale = scale; fq.offset = offset; fq.out = out; fq.qmin = clip_min; fq.qmax = clip_max; fq.rounding = rounding;
+    int st;
+    if (rounding == ROUND_HALF_EVEN) st = launch_hist_one<true, ROUND_HALF_EVEN>(x, n, rule, hist, workspace, s, nullptr, fq);
+    else st = launch_hist_one<true, -1>(x, n, rule, hist, workspace, s, nullptr, fq);
+    if (st) return st;
     return finish_launch("fq_linear_t_hist_sym");
+}
+
+/* the same, accumulating into the caller's persistent rows[ppqhip_hist_rows()][num_bins] (no per-launch reduce) */
+int ppqhip_fq_linear_t_hist_sym_rows(const float* x, const float* scale, const float* offset, float* out, int64_t n,
+                                     int clip_min, int clip_max, int rounding, float hist_scale, int clip_outliers,
+                                     int32_t* rows, int64_t num_bins, void* stream) {
+    if (int st = validate(n, num_bins, "fq_linear_t_hist_sym_rows")) return st;
+    if (num_bins > kMaxLdsBins) {
+        set_error("fq_linear_t_hist_sym_rows: at most %d bins", kMaxLdsBins); return PPQHIP_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_FQ_HIST_FUSED, 8.0 * (double)n, s);
+    BinRule rule = make_rule(0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, 0);
+    FqArgs fq;
+    fq.scale = scale; fq.offset = offset; fq.out = out; fq.qmin = clip_min; fq.qmax = clip_max; fq.rounding = rounding;
+    int st;
+    if (rounding == ROUND_HALF_EVEN) st = launch_hist_one<true, ROUND_HALF_EVEN>(x, n, rule, nullptr, nullptr, s, rows, fq);
+    else st = launch_hist_one<true, -1>(x, n, rule, nullptr, nullptr, s, rows, fq);
+    if (st) return st;
+    return finish_launch("fq_linear_t_hist_sym_rows");
 }
 
 }  // extern "C"

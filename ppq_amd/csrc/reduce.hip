@@ -61,43 +61,109 @@ __global__ __launch_bounds__(kBlock) void minmax_t_kernel(const float* __restric
     }
 }
 
-// many tensors, one launch (see hist_t_multi_kernel): job j owns workgroups [first_block[j],
-// first_block[j+1]); workgroup b of a job folds its chunk into slot b of that job's persistent slots.
+// many tensors, one launch -- the persistent design of hist_persistent_kernel (hist.hip): the work is the
+// concatenated list of tiles (kMMBlock * kMMU float4) of all jobs, split evenly over a chip-sized grid;
+// a workgroup walks its contiguous tile range with two ping-pong register tiles and folds its running
+// (min, max) into ITS OWN slot of every job it touches (plain stream-ordered read-modify-write).
 constexpr int kMinMaxMultiMax = 96;              // jobs per launch (2.3 KB of kernel arguments)
-constexpr uint32_t kMinMaxMultiChunk = 64u << 10;   // elements per workgroup (256 KB)
+#ifndef PPQHIP_MM_BLOCK
+#define PPQHIP_MM_BLOCK 256
+#endif
+#ifndef PPQHIP_MM_WGPC
+#define PPQHIP_MM_WGPC 8
+#endif
+#ifndef PPQHIP_MM_U
+#define PPQHIP_MM_U 2
+#endif
+constexpr int kMMBlock = PPQHIP_MM_BLOCK, kMMU = PPQHIP_MM_U;
+constexpr int kMMGrid = kNumCU * PPQHIP_MM_WGPC;                 // <= ppqhip_minmax_slots()
+constexpr uint32_t kMMTileVec = (uint32_t)kMMBlock * kMMU, kMMTileElems = kMMTileVec * 4;
+static_assert(kMMGrid <= kNumCU * 8, "one slot per workgroup");
 struct MinMaxJob {
     const float* x;
     float* slots;
     uint32_t n;
-    uint32_t first_block;
+    uint32_t first_tile;
 };
 struct MinMaxJobs {
     MinMaxJob job[kMinMaxMultiMax];
     uint32_t count;
+    uint32_t total_tiles;
 };
+__host__ __device__ inline uint32_t mm_job_tiles(uint32_t n, bool vec_ok) {
+    if (!vec_ok) return (n + kMMTileElems - 1) / kMMTileElems;
+    const uint32_t full = (n >> 2) / kMMTileVec;
+    return full + (n > full * kMMTileElems ? 1u : 0u);
+}
 
-__global__ __launch_bounds__(kBlock) void minmax_t_multi_kernel(const MinMaxJobs jobs) {
-    __shared__ float lds[16];
+template <bool NT>
+__global__ __launch_bounds__(kMMBlock) void minmax_persistent_kernel(const MinMaxJobs jobs) {
+    __shared__ float lds[32];
+    const uint32_t G = gridDim.x, g = blockIdx.x;
+    uint32_t t = (uint32_t)(((uint64_t)g * jobs.total_tiles) / G);
+    const uint32_t t_end = (uint32_t)(((uint64_t)(g + 1) * jobs.total_tiles) / G);
+    if (t >= t_end) return;
     uint32_t lo = 0, hi = jobs.count;
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (jobs.job[mid].first_block <= blockIdx.x) lo = mid; else hi = mid;
+        if (jobs.job[mid].first_tile <= t) lo = mid; else hi = mid;
     }
-    const MinMaxJob& j = jobs.job[lo];
-    const uint32_t end = lo + 1 < jobs.count ? jobs.job[lo + 1].first_block : gridDim.x;
-    const uint32_t bidx = blockIdx.x - j.first_block, nblk = end - j.first_block;
-    float mn = INFINITY, mx = -INFINITY;
-    const bool vec_ok = (reinterpret_cast<uintptr_t>(j.x) & 15u) == 0;
-    stream_elems<4, false>(j.x, j.n, vec_ok, [&](float a) { mn = fminf(mn, a); mx = fmaxf(mx, a); }, bidx, nblk);
-    mn = wave_min(mn);
-    mx = wave_max(mx);
-    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (lane == 0) { lds[wid] = mn; lds[8 + wid] = mx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < kBlock / kWave; w++) { mn = fminf(mn, lds[w]); mx = fmaxf(mx, lds[8 + w]); }
-        j.slots[2 * bidx] = fminf(mn, j.slots[2 * bidx]);
-        j.slots[2 * bidx + 1] = fmaxf(mx, j.slots[2 * bidx + 1]);
+    for (uint32_t j = lo; t < t_end; j++) {
+        const MinMaxJob& job = jobs.job[j];
+        const uint32_t j_end = (j + 1 < jobs.count) ? jobs.job[j + 1].first_tile : jobs.total_tiles;
+        uint32_t k = t - job.first_tile;
+        const uint32_t k1 = min(t_end, j_end) - job.first_tile;
+        t = min(t_end, j_end);
+        const float* __restrict__ x = job.x;
+        const uint32_t n = job.n;
+        const bool vec_ok = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+        const uint32_t full = vec_ok ? (n >> 2) / kMMTileVec : 0u;
+        const uint32_t kf = min(k1, full);
+        float mn = INFINITY, mx = -INFINITY;
+        if (k < kf) {
+            const float4* xv = reinterpret_cast<const float4*>(x) + threadIdx.x;
+            float4 bufa[kMMU], bufb[kMMU];
+            auto fetch = [&](float4 (&buf)[kMMU], uint32_t tile) {
+                const float4* p = xv + (size_t)tile * kMMTileVec;
+#pragma unroll
+                for (int u = 0; u < kMMU; u++) buf[u] = load4<NT>(p + u * kMMBlock);
+            };
+            auto consume = [&](const float4 (&buf)[kMMU]) {
+#pragma unroll
+                for (int u = 0; u < kMMU; u++) {
+                    mn = fminf(fminf(mn, buf[u].x), fminf(buf[u].y, fminf(buf[u].z, buf[u].w)));
+                    mx = fmaxf(fmaxf(mx, buf[u].x), fmaxf(buf[u].y, fmaxf(buf[u].z, buf[u].w)));
+                }
+            };
+            fetch(bufa, k);
+            for (;;) {
+                fetch(bufb, min(k + 1, kf - 1));
+                consume(bufa);
+                if (++k >= kf) break;
+                fetch(bufa, min(k + 1, kf - 1));
+                consume(bufb);
+                if (++k >= kf) break;
+            }
+        }
+        for (; k < k1; k++) {             // ragged tail tile / unaligned tensor: masked 4-B loads
+            const uint32_t e0 = k * kMMTileElems + threadIdx.x;
+#pragma unroll 4
+            for (int r = 0; r < 4 * kMMU; r++) {
+                const uint32_t i = e0 + r * kMMBlock;
+                if (i < n) { const float a = x[i]; mn = fminf(mn, a); mx = fmaxf(mx, a); }
+            }
+        }
+        mn = wave_min(mn);
+        mx = wave_max(mx);
+        const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        if (lane == 0) { lds[wid] = mn; lds[16 + wid] = mx; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < kMMBlock / kWave; w++) { mn = fminf(mn, lds[w]); mx = fmaxf(mx, lds[16 + w]); }
+            job.slots[2 * g] = fminf(mn, job.slots[2 * g]);
+            job.slots[2 * g + 1] = fmaxf(mx, job.slots[2 * g + 1]);
+        }
+        __syncthreads();
     }
 }
 
@@ -680,9 +746,26 @@ int ppqhip_minmax_t(const float* x, int64_t n, float* minmax, void* workspace, v
 /* persistent-slot variant: slots is float[ppqhip_minmax_slots()][2], seeded with {+inf, -inf} */
 int64_t ppqhip_minmax_slots(void) { return (int64_t)kNumCU * 8; }
 
+static void launch_minmax_persistent(const MinMaxJobs& args, int64_t elems, hipStream_t s) {
+    uint32_t grid = args.total_tiles / 2;                       // at least two tiles per workgroup
+    if (grid < 1) grid = 1;
+    if (grid > (uint32_t)kMMGrid) grid = kMMGrid;
+    // streaming (nontemporal) loads once the data cannot be cache resident
+    if (elems >= (48ll << 20)) hipLaunchKernelGGL((minmax_persistent_kernel<true>), dim3(grid), dim3(kMMBlock), 0, s, args);
+    else hipLaunchKernelGGL((minmax_persistent_kernel<false>), dim3(grid), dim3(kMMBlock), 0, s, args);
+}
+
 int ppqhip_minmax_t_slots(const float* x, int64_t n, float* slots, void* stream) {
     if (slots == nullptr) { set_error("minmax_t_slots: slots is null"); return PPQHIP_ERR_INVALID_VALUE; }
-    return minmax_t_impl(x, n, nullptr, nullptr, slots, stream);
+    if (int st = validate(n, "minmax_t_slots")) return st;
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_MINMAX_T, 4.0 * (double)n, s);
+    MinMaxJobs args;
+    args.count = 1;
+    args.job[0].x = x; args.job[0].slots = slots; args.job[0].n = (uint32_t)n; args.job[0].first_tile = 0;
+    args.total_tiles = mm_job_tiles((uint32_t)n, aligned16(x));
+    launch_minmax_persistent(args, n, s);
+    return finish_launch("minmax_t_slots");
 }
 
 int ppqhip_minmax_t_slots_multi(const ppqhip_minmax_job* jobs, int num_jobs, void* stream) {
@@ -698,21 +781,20 @@ int ppqhip_minmax_t_slots_multi(const ppqhip_minmax_job* jobs, int num_jobs, voi
     }
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_MINMAX_T, bytes, s);
-    const uint32_t max_slots = (uint32_t)ppqhip_minmax_slots();
     for (int base = 0; base < num_jobs; base += kMinMaxMultiMax) {
         MinMaxJobs args;
         args.count = (uint32_t)((num_jobs - base) < kMinMaxMultiMax ? (num_jobs - base) : kMinMaxMultiMax);
-        uint32_t blocks = 0;
+        uint32_t tiles = 0;
+        int64_t elems = 0;
         for (uint32_t k = 0; k < args.count; k++) {
             const ppqhip_minmax_job& src = jobs[base + k];
             args.job[k].x = src.x; args.job[k].slots = src.slots; args.job[k].n = (uint32_t)src.n;
-            args.job[k].first_block = blocks;
-            uint32_t nb = (uint32_t)((src.n + kMinMaxMultiChunk - 1) / kMinMaxMultiChunk);
-            if (nb > max_slots) nb = max_slots;
-            if (nb < 1) nb = 1;
-            blocks += nb;
+            args.job[k].first_tile = tiles;
+            tiles += mm_job_tiles((uint32_t)src.n, aligned16(src.x));
+            elems += src.n;
         }
-        hipLaunchKernelGGL(minmax_t_multi_kernel, dim3(blocks), dim3(kBlock), 0, s, args);
+        args.total_tiles = tiles;
+        launch_minmax_persistent(args, elems, s);
     }
     return finish_launch("minmax_t_slots_multi");
 }

@@ -26,11 +26,30 @@ def is_distributed(group=None) -> bool:
     return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
 
 
+last_merge_stats: dict = {}     # what the most recent merge_observers() moved (bench.py reports it)
+
+
+def _check_layout(dist, lengths: List[int], device, group) -> None:
+    """Every rank must bring the same flat layout: an observer that saw no batch on one rank (fewer
+    batches than ranks, uneven shards) declares nothing, and all-reducing buffers of different length
+    hangs or corrupts.  ONE tiny MAX all-reduce over [len, -len, ...] detects it on every rank."""
+    probe = torch.tensor([v for n in lengths for v in (n, -n)], dtype=torch.int64, device=device)
+    dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
+    got = probe.tolist()
+    if any(got[2 * i] != -got[2 * i + 1] for i in range(len(lengths))):
+        raise RuntimeError('merge_observers: the ranks declare different statistics layouts '
+                           f'(this rank: {lengths}, max over ranks: {got[0::2]}); every rank must observe at '
+                           'least one batch with every observer before a merge (calib_steps >= world_size)')
+
+
 def merge_observers(observers: Sequence, group=None) -> int:
     """All-reduce, in place, every buffer the observers declare ``reducible()``.  Returns the number
-    of collectives issued (0 when not distributed)."""
+    of data collectives issued (0 when not distributed); sizes and time land in ``last_merge_stats``."""
+    global last_merge_stats
     if not is_distributed(group):
+        last_merge_stats = {}
         return 0
+    import time
     import torch.distributed as dist
     mins: List[torch.Tensor] = []     # reduced with MIN ('max' buffers are negated into this list)
     maxs: List[torch.Tensor] = []
@@ -42,23 +61,41 @@ def merge_observers(observers: Sequence, group=None) -> int:
             elif kind == 'max': maxs.append(buf)
             elif kind == 'sum': sums.setdefault(buf.dtype, []).append(buf)
             else: raise ValueError(f'unknown reduction {kind}')
+    t0 = time.perf_counter()
+    sum_dtypes = (torch.int32, torch.float32, torch.float64, torch.int64)
+    for dt in sums:
+        if dt not in sum_dtypes: raise ValueError(f'merge_observers: unsupported sum dtype {dt}')
+    lengths = [sum(b.numel() for b in mins), sum(b.numel() for b in maxs)] + \
+              [sum(b.numel() for b in sums.get(dt, [])) for dt in sum_dtypes]
+    some = (mins + maxs + [b for v in sums.values() for b in v])
+    backend = dist.get_backend(group)
+    device = some[0].device if some else torch.device('cuda' if backend == 'nccl' else 'cpu')
+    _check_layout(dist, lengths, device, group)
     issued = 0
+    moved = {}
     if mins or maxs:
         flat = torch.cat([b.reshape(-1) for b in mins] + [-b.reshape(-1) for b in maxs])
         dist.all_reduce(flat, op=dist.ReduceOp.MIN, group=group)
         issued += 1
+        moved['min_f32_bytes'] = flat.numel() * flat.element_size()
         pos = 0
         for b in mins:
             n = b.numel(); b.copy_(flat[pos: pos + n].reshape(b.shape)); pos += n
         for b in maxs:
             n = b.numel(); b.copy_((-flat[pos: pos + n]).reshape(b.shape)); pos += n
-    for dtype, bufs in sums.items():
+    for dtype in sum_dtypes:
+        bufs = sums.get(dtype)
+        if not bufs: continue
         flat = torch.cat([b.reshape(-1) for b in bufs])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         issued += 1
+        moved[f'sum_{str(dtype).split(".")[-1]}_bytes'] = flat.numel() * flat.element_size()
         pos = 0
         for b in bufs:
             n = b.numel(); b.copy_(flat[pos: pos + n].reshape(b.shape)); pos += n
+    if some and some[0].is_cuda: torch.cuda.synchronize(some[0].device)
+    last_merge_stats = {'collectives': issued, 'ms': (time.perf_counter() - t0) * 1e3, 'world_size': dist.get_world_size(group),
+                        'backend': backend, **moved}
     return issued
 
 

@@ -138,7 +138,16 @@ class LinearQuantizePlan:
     ``(value, scale, offset, channel_axis | None, quant_min, quant_max)`` items that share a rounding
     policy; ``run()`` re-quantises all of them into one resident arena and returns views shaped like
     the inputs -- values identical to ``CUDA.LinearQuantize_C`` / ``_T`` per item.  The device job
-    table is uploaded at construction; ``signature()`` lets the owner detect replaced tensors."""
+    table holds POINTERS to the callers' tensors and is uploaded by the first ``run()``: in-place updates
+    of a value / scale / offset are seen by later runs, a REPLACED tensor needs a new plan (the owner keys
+    on ``data_ptr()``, harness._fused_parameters).  An item whose value is not dense in storage order, or
+    whose scale / offset is not contiguous, would need a private copy that later in-place updates never
+    reach: such items are refused (``accepts()``) and go through the per-tensor entry points instead."""
+    @ staticmethod
+    def accepts(value, scale, offset, axis) -> bool:
+        """True when the plan can point at these tensors themselves (no layout copy needed)."""
+        return _dense(value, axis) is value and scale.is_contiguous() and offset.is_contiguous()
+
     def __init__(self, items, rounding: int = 0):
         if not items: raise ValueError('LinearQuantizePlan needs at least one item')
         self._keep = []                       # the tensors the device table points at
@@ -148,14 +157,17 @@ class LinearQuantizePlan:
             _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset')
             if value.device != dev or scale.device != dev or offset.device != dev:
                 raise RuntimeError(_KERNEL_FAILURE + 'LinearQuantizePlan: every tensor must live on one device')
+            if not LinearQuantizePlan.accepts(value, scale, offset, axis):
+                raise RuntimeError(_KERNEL_FAILURE + 'LinearQuantizePlan: value must be dense in storage order and '
+                                   'scale / offset contiguous (a private copy would go stale); see accepts()')
             total += (value.numel() + 3) // 4 * 4
         self._arena = torch.empty(total, dtype=torch.float32, device=dev)
         self._jobs = np.zeros(len(items), dtype=_FQ_JOB)
         self._outs = []
         at = 0
         for k, (value, scale, offset, axis, qmin, qmax) in enumerate(items):
-            v = _dense(value, axis)
-            sc, of = scale.contiguous().reshape(-1), offset.contiguous().reshape(-1)
+            v = value
+            sc, of = scale.reshape(-1), offset.reshape(-1)          # views: accepts() guarantees contiguity
             if axis is None: C, epc = 1, v.numel()
             else: C, epc = _geometry(v.shape, axis)
             if sc.numel() != C or of.numel() != C:

@@ -241,6 +241,7 @@ class TorchExecutor:
         weights / scales need no rebuild; replaced tensors or edited configs do (signature check)."""
         self._fused = {}
         if not self.fuse_parameter_quantization or self._default_quant_fn is not PPQuantFunction: return
+        from .ffi import LinearQuantizePlan
         todo, sig = [], []
         for op in self._graph.operations.values():
             if not isinstance(op, QuantableOperation): continue
@@ -252,6 +253,7 @@ class TorchExecutor:
                 if v.value.dtype != torch.float32 or v.value.requires_grad or v.value.numel() == 0: continue
                 if not (isinstance(c.scale, torch.Tensor) and isinstance(c.offset, torch.Tensor)): continue
                 axis = c.channel_axis if pol.has_property(P.PER_CHANNEL) else None
+                if not LinearQuantizePlan.accepts(v.value, c.scale, c.offset, axis): continue   # per-tensor launch instead
                 rnd = int(getattr(c.rounding, 'value', c.rounding))
                 todo.append((v, c, axis, rnd))
                 sig.append((v.name, id(c), v.value.data_ptr(), c.scale.data_ptr(), c.offset.data_ptr(), tuple(v.value.shape), c.scale.numel(),
@@ -260,7 +262,6 @@ class TorchExecutor:
             self._plans, self._plan_signature = [], None
             return
         if sig != self._plan_signature:
-            from .ffi import LinearQuantizePlan
             groups: Dict[int, list] = {}
             for item in todo: groups.setdefault(item[3], []).append(item)
             self._plans = []

@@ -352,6 +352,9 @@ class TorchHistObserver(TorchMinMaxObserver):
             self._drain()
             CUDA.Histogram_Rows_Finish(self._rows, self._hist)
             self._rows_dirty = False
+            # the rows may have been allocated while a side stream was current (async_observe): tell the
+            # caching allocator that the finish kernel on THIS stream still reads them before they go back
+            if self._rows.is_cuda: self._rows.record_stream(torch.cuda.current_stream(self._rows.device))
             self._rows = None
 
     def histogram(self) -> Optional[torch.Tensor]:
