@@ -1,7 +1,9 @@
 """bench.py -- calibration samples/s of RuntimeCalibrationPass (KL, 2048 bins) on ResNet-50 INT8.
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (for N > 1 launched by
-torch.distributed.run, one rank per GPU over RCCL).  A *step* is one calibration batch
+Contract: `python bench.py --gpus N --steps K --warmup W`.  For N > 1 the ranks are either launched
+by torch.distributed.run (RANK / WORLD_SIZE in the environment) or -- when bench.py is started plainly
+with --gpus N -- spawned by bench.py itself (it re-executes itself under torch.distributed.run on
+127.0.0.1), one rank per GPU over RCCL.  A *step* is one calibration batch
 (`--batch` samples, default 32) taken through BOTH phases of the pass; the timed region is exactly
 one `RuntimeCalibrationPass.optimize(...)` with `calib_steps = K` (phase 1 range collection, render,
 phase 2 histogram collection incl. the per-forward weight fake-quant the reference performs, batched
@@ -10,16 +12,27 @@ Inputs (K batches of torch.rand(batch,3,224,224)) are resident in HBM before the
 Weak scaling: every rank calibrates K batches of its own; statistics merge with one RCCL all-reduce
 per phase (ppq_amd/distributed.py); value = N*K*batch / time.
 
+The timed pass is repeated `--repeats` times (default 3, each on a freshly built graph, each timing
+exactly K steps); `value` is the MEDIAN pass and `values` / `spread_pct` report all of them.
+
 Rank 0 prints ONE JSON line; `roofline` describes the dominant ppq_amd kernel of the timed workload
-(hipEvent pairs on the launch stream, collected in a second identical pass), `cpu_baseline` is the
-CPU oracle (oracle/cpu_calibration.py: torch-CPU dense ops + the C restatement of the kernels) on a
-bounded sample of the same workload (N == 1 only).
+(hipEvent pairs on the launch stream, collected in one more identical pass; `traffic` = HBM bytes per
+launch from rocprofv3 PMC passes of this very command run as child processes, FETCH_SIZE and WRITE_SIZE
+separately, gfx950 correction applied -- null when rocprofv3 is unavailable), `cpu_baseline` is PPQ's
+USING_CUDA_KERNEL=False PyTorch-CPU path (oracle/torch_cpu_path.py, or the reference itself when a staged
+copy is importable) on a bounded sample of the same workload, `cpu_ops` the per-op table of BASELINE.md
+section 3 (N == 1 only).
 """
 import argparse
-import ctypes
+import csv
+import glob
 import json
 import os
+import shutil
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -30,8 +43,25 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def maybe_spawn(args) -> None:
+    """`python bench.py --gpus N` from a plain shell: run the N ranks ourselves (one per GPU) by
+    re-executing this file under torch.distributed.run on the loopback interface."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ or 'RANK' in os.environ: return
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0)); port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL / cross-process sharing needs it here
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def setup_dist(n_gpus: int, backend: str = 'nccl', single_device: bool = False):
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != max(1, n_gpus):
+        raise SystemExit(f'bench.py: --gpus {n_gpus} but WORLD_SIZE={world}: launch one rank per GPU '
+                         f'(or start bench.py plainly and let it spawn the ranks)')
     local = 0 if single_device else int(os.environ.get('LOCAL_RANK', 0))
     torch.cuda.set_device(local)
     if world > 1:
@@ -41,6 +71,46 @@ def setup_dist(n_gpus: int, backend: str = 'nccl', single_device: bool = False):
         else:                     # debugging aid: several ranks on one GPU (RCCL refuses duplicate devices)
             dist.init_process_group(backend)
     return rank, world, local
+
+
+def host_selftest(args) -> None:
+    """`--host-selftest`: the multi-process plumbing WITHOUT a GPU -- spawn, rendezvous on 127.0.0.1, the flat
+    per-phase merge of ppq_amd.distributed over `gloo` on CPU buffers shaped like the ResNet-50 statistics
+    (72 ranges, 72 x bins int32 histograms), MAX-over-ranks timing, one JSON line from rank 0.  What the CPU
+    suite runs (tests/test_host_cpu.py); the data path itself needs the GPU."""
+    import torch.distributed as dist
+    from ppq_amd.distributed import last_merge_stats, merge_observers  # noqa: F401
+    from ppq_amd import distributed as D
+    rank, world = int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1))
+    if world != max(1, args.gpus): raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if world > 1: dist.init_process_group('gloo')
+
+    class Stat:
+        def __init__(self, bufs): self.bufs = bufs
+        def reducible(self): return self.bufs
+    g = torch.Generator().manual_seed(99 + rank)
+    rngs = [torch.stack([-torch.rand(1, generator=g), torch.rand(1, generator=g)]).reshape(2) for _ in range(72)]
+    hists = [torch.randint(0, 1000, [args.bins], generator=g, dtype=torch.int32) for _ in range(72)]
+    total_before = sum(int(h.sum()) for h in hists)
+    t0 = time.perf_counter()
+    merge_observers([Stat([(r[0:1], 'min'), (r[1:2], 'max')]) for r in rngs])
+    phase1 = dict(D.last_merge_stats)
+    merge_observers([Stat([(h, 'sum')]) for h in hists])
+    phase2 = dict(D.last_merge_stats)
+    elapsed = time.perf_counter() - t0
+    ok = True
+    if world > 1:
+        t = torch.tensor([elapsed, float(total_before)], dtype=torch.float64)
+        m = t.clone(); dist.all_reduce(m, op=dist.ReduceOp.MAX); elapsed = float(m[0])
+        tot = t[1:2].clone(); dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        ok = int(tot[0]) == sum(int(h.sum()) for h in hists)          # merged histograms == sum of the shards
+    if rank == 0:
+        print(json.dumps({'metric': 'host selftest of the data-parallel merge (no GPU work)', 'value': round(elapsed * 1e3, 3),
+                          'unit': 'ms', 'n_gpus': world, 'rccl_ranks': world, 'backend': 'gloo', 'selftest': True,
+                          'merged_counts_ok': ok,
+                          'merge': [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in m.items()} for m in (phase1, phase2)]}),
+              flush=True)
+    if world > 1: dist.destroy_process_group()
 
 
 def barrier(world):
@@ -99,41 +169,94 @@ def collect_prof():
              'total_bytes': float(arr[i].total_bytes)} for i in range(n)]
 
 
-def pmc_traffic(kernel_name: str):
-    """HBM bytes per launch of `kernel_name` from the committed PMC summary (separate rocprofv3
-    `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of THIS command, FETCH_SIZE doubled per the gfx950
-    correction of MI355X_MICROARCH.md; tools/summarize_profile.py).  None when no summary is present."""
-    path = os.path.join(ROOT, 'profiles', 'r01_bench_pmc_bytes.json')
-    if not os.path.exists(path): return None, None
-    data = json.load(open(path))
-    keys = {'hist_sym_t': ('hist_t_multi_kernel<false', 'hist_t_lds_kernel<false'),
-            'hist_asym_t': ('hist_t_multi_kernel<true', 'hist_t_lds_kernel<true'),
-            'minmax_t': ('minmax_t_multi_kernel', 'minmax_t_kernel'),
-            'fq_linear_c': ('fq_linear_multi_kernel', 'fq_linear_c_tile_kernel'),
-            'fq_linear_t': ('fq_linear_t_tile_kernel',)}.get(kernel_name)
-    if keys is None: return None, None
-    tot = n = 0
-    for k, v in data.items():
-        if k.startswith(keys) and 'launches' in v:
-            tot += v['launches'] * (v.get('hbm_read_bytes_per_launch_corrected', 0) + v.get('hbm_write_bytes_per_launch', 0))
-            n += v['launches']
-    return (round(tot / n), 'profiles/r01_bench_pmc_bytes.json') if n else (None, None)
+# device kernels that implement each logical library kernel (prefixes of the demangled names rocprofv3 prints)
+DEVICE_KERNELS = {'hist_sym_t': ('ppqhip::hist_persistent_kernel<false',), 'hist_asym_t': ('ppqhip::hist_persistent_kernel<true',),
+                  'minmax_t': ('ppqhip::minmax_persistent_kernel', 'ppqhip::minmax_t_kernel'),
+                  'fq_linear_c': ('ppqhip::fq_linear_multi_kernel', 'ppqhip::fq_linear_c_tile_kernel'),
+                  'fq_linear_t': ('ppqhip::fq_linear_t_tile_kernel',)}
 
 
-def cpu_baseline(bins, batch_samples=2, n_batches=4):
-    """The same two-phase KL calibration on the host cores, through the CPU oracle."""
+def pmc_traffic(kernel_name: str, child_args: list, timeout_s: float = 240.0):
+    """HBM bytes per launch of the device kernel(s) behind `kernel_name`, MEASURED NOW: this command is
+    run twice more as a child under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE`
+    (separate passes, nothing but kernel tracing next to the counters), a reduced step count, no
+    baselines.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE tallies the 128-B requests of a
+    wide coalesced stream at 64 B -> doubled; WRITE_SIZE is taken as reported (KB).  Returns
+    (bytes per launch | None, note)."""
+    prefixes = DEVICE_KERNELS.get(kernel_name)
+    rocprof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if prefixes is None or rocprof is None: return None, 'rocprofv3 not available'
+    per_launch = {}
+    work = tempfile.mkdtemp(prefix='ppq_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    try:
+        for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+            out = os.path.join(work, counter)
+            cmd = [rocprof, '--output-format', 'csv', '--kernel-trace', '--pmc', counter, '-d', out, '-o', 'pmc', '--',
+                   sys.executable, os.path.abspath(__file__)] + child_args
+            try:
+                subprocess.run(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            except (subprocess.TimeoutExpired, OSError) as e:
+                return None, f'{counter} pass failed: {type(e).__name__}'
+            files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
+            if not files: return None, f'{counter} pass wrote no counter_collection.csv'
+            tot = n = 0
+            for r in csv.DictReader(open(files[0])):
+                if r['Counter_Name'] == counter and r['Kernel_Name'].replace('void ', '').startswith(prefixes):
+                    tot += float(r['Counter_Value']); n += 1
+            if n == 0: return None, f'{counter}: kernel not found in the trace'
+            per_launch[counter] = tot / n * 1024.0        # the counters report KB
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return round(2.0 * per_launch['FETCH_SIZE'] + per_launch['WRITE_SIZE']), \
+        'live rocprofv3 --pmc passes of this command (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE)'
+
+
+def staged_reference():
+    """A staged, importable copy of the reference (tools/stage_reference.py -> oracle/_ref/ppq_stage, git-ignored):
+    returns its path or None.  /root/reference itself is never read here."""
+    path = os.path.join(ROOT, 'oracle', '_ref', 'ppq_stage')
+    return path if os.path.isdir(os.path.join(path, 'ppq')) else None
+
+
+def cpu_baseline(bins, target_samples=32, batch_samples=4, budget_s=30.0):
+    """PPQ's USING_CUDA_KERNEL=False path on the host cores: the same two-phase KL calibration of the same
+    ResNet-50 graph, torch-CPU ops on all host threads (torch.histc / min / max / round, range.py:86-98,
+    175-188, qfunction/linear.py:27-32).  The reference's own classes when a staged copy is importable
+    (kind "reference"), otherwise their line-by-line restatement oracle/torch_cpu_path.py ("reference-path").
+    The single-threaded C oracle (round 1's baseline) is reported next to it on a smaller sample."""
     from ppq_amd import harness
+    from oracle import torch_cpu_path as T
     from oracle.cpu_calibration import timed_calibrate_cpu
-    graph = harness.resnet50_graph(seed=0)
-    harness.quantize_graph(graph, 'kl', hist_bins=bins)
     g = torch.Generator().manual_seed(1)
+    kind, runner = 'reference-path', T.timed_calibrate
+    stage = staged_reference()
+    if stage is not None:
+        try:
+            from oracle import reference_import as RI
+            RI.load(stage)
+            kind, runner = 'reference', RI.timed_calibrate
+        except Exception as e:        # a broken stage must not cost the bench line
+            print(f'[bench] staged reference not usable ({e}); timing the restated path', file=sys.stderr)
+
+    def graph():
+        gr = harness.resnet50_graph(seed=0)
+        harness.quantize_graph(gr, 'kl', hist_bins=bins)
+        return gr
+    # one warm batch sizes the sample: ~budget_s of host work, at least target_samples when that fits
+    warm = [torch.rand(batch_samples, 3, 224, 224, generator=g)]
+    secs1, _ = runner(graph(), warm, bins)
+    n_batches = max(1, min(target_samples // batch_samples, int(budget_s / max(secs1, 1e-3))))
     batches = [torch.rand(batch_samples, 3, 224, 224, generator=g) for _ in range(n_batches)]
-    secs, _ = timed_calibrate_cpu(graph, batches, bins)
+    secs, _ = runner(graph(), batches, bins)
     n = batch_samples * n_batches
-    return {'value': round(n / secs, 3), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': f'{n} samples ({n_batches} batches of {batch_samples}) of the same ResNet-50 KL calibration: '
-                      f'torch-CPU dense ops on {torch.get_num_threads()} threads + single-threaded C oracle kernels; '
-                      f'{secs:.1f} s'}
+    small = [torch.rand(2, 3, 224, 224, generator=g) for _ in range(2)]
+    psecs, _ = timed_calibrate_cpu(graph(), small, bins)
+    return {'value': round(n / secs, 3), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': kind,
+            'sample': f'{n} samples ({n_batches} batches of {batch_samples}) of the same ResNet-50 KL-{bins} calibration, '
+                      f"PPQ's USING_CUDA_KERNEL=False torch-CPU path on {torch.get_num_threads()} threads; {secs:.1f} s",
+            'port_c_oracle': {'value': round(4 / psecs, 3), 'unit': 'samples/s', 'cores': 1,
+                              'sample': f'4 samples, torch-CPU dense ops + single-threaded C restatement of the kernels; {psecs:.1f} s'}}
 
 
 def main():
@@ -144,11 +267,17 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--bins', type=int, default=2048)
     ap.add_argument('--method', type=str, default='kl')
+    ap.add_argument('--repeats', type=int, default=3, help='timed passes (each exactly K steps); value = median')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-cpu-ops', action='store_true')
+    ap.add_argument('--pmc', type=int, default=1, help='measure roofline.traffic with two rocprofv3 --pmc child passes of this command')
+    ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--host-selftest', action='store_true', help='CPU-only check of spawn + rendezvous + merge (gloo); no GPU work')
     ap.add_argument('--backend', type=str, default='nccl')
     ap.add_argument('--single-device', type=int, default=0, help='debug: put every rank on cuda:0 (use with --backend gloo)')
     ap.add_argument('--hip-graph', default='auto', choices=['0', '1', 'auto'],
-                    help="replay each phase's forward as a HIP graph: never / always / when one timed eager step is launch-bound")
+                    help="replay each phase's forward as a HIP graph: never / always / auto = only for small batches "
+                         "(< 16 samples) whose timed eager step is launch-bound")
     ap.add_argument('--async-observe', type=int, default=0, help='observer kernels on a side HIP stream')
     ap.add_argument('--fuse-params', type=int, default=1, help='all weights of a forward fake-quantised by one multi-tensor launch')
     ap.add_argument('--batch-observations', type=int, default=1, help='all statistics kernels of a forward in one multi-tensor launch')
@@ -162,6 +291,8 @@ def main():
     ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
     args = ap.parse_args()
 
+    maybe_spawn(args)
+    if args.host_selftest: return host_selftest(args)
     rank, world, local = setup_dist(args.gpus, args.backend, bool(args.single_device))
     torch.backends.cudnn.benchmark = bool(args.miopen_find)
     dev = f'cuda:{local}'
@@ -170,6 +301,9 @@ def main():
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     batches = [torch.rand(args.batch, 3, 224, 224, device=dev, generator=g) for _ in range(args.steps)]
+    # HIP-graph replay only pays for launch-bound steps (small batches); at batch >= 16 the step is GPU-bound
+    # and 'auto' used to flip on a noisy host-enqueue measurement (round 1's driver run: 15.0 vs 11.0 ms/step)
+    hip_graph = {'0': False, '1': True, 'auto': 'auto' if args.batch < 16 else False}[args.hip_graph]
 
     # warm-up: W batches through a complete two-phase pass (MIOpen find, library load, allocator)
     if args.warmup > 0:
@@ -177,41 +311,48 @@ def main():
         run_pass(graph, ex, batches[: max(1, min(args.warmup, args.steps))], max(1, min(args.warmup, args.steps)), args.method,
                  bool(args.async_observe), False, bool(args.batch_observations))
         # keep the device under the workload's own load profile for a moment: a GPU that sat idle (fresh
-        # box) otherwise spends the first timed steps in clock / power transitions (sporadic 10-20 ms
-        # device-side stalls were traced to the first steps after idle; tools/find_stall.py)
+        # box) otherwise spends the first timed steps in clock / power transitions
         t_settle = time.perf_counter()
         while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
             for b in batches[:2]: ex.forward(b)
             torch.cuda.synchronize()
         del graph, ex
 
-    # timed region
+    # timed region(s): `repeats` independent passes of exactly K steps each
     global TRACE_STEPS
-    if args.trace_steps:
-        TRACE_STEPS = []
-        ev0 = torch.cuda.Event(enable_timing=True)
-    graph, ex = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params, bool(args.channels_last))
-    barrier(world)
-    t0 = time.perf_counter()
-    if args.trace_steps: ev0.record()
-    p = run_pass(graph, ex, batches, args.steps, args.method, bool(args.async_observe), {'0': False, '1': True, 'auto': 'auto'}[args.hip_graph],
-                 bool(args.batch_observations), bool(args.reuse_activations), (args.queue_mib << 20) or None)
-    barrier(world)
-    elapsed = time.perf_counter() - t0
-    trace = None
-    if args.trace_steps:
-        trace = [{'host_ms': round((t - t0) * 1e3, 2), 'dev_ms': round(ev0.elapsed_time(e), 2)} if not isinstance(e, float)
-                 else {'render_start_ms': round((t - t0) * 1e3, 2), 'render_ms': round((e - t) * 1e3, 2)} for t, e in TRACE_STEPS]
-        TRACE_STEPS = None
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    times, trace, p, graph = [], None, None, None
+    repeats = 1 if (args.trace_steps or args.pmc_child) else max(1, args.repeats)
+    for rep in range(repeats):
+        if args.trace_steps:
+            TRACE_STEPS = []
+            ev0 = torch.cuda.Event(enable_timing=True)
+        del p, graph
+        graph, ex = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params, bool(args.channels_last))
+        barrier(world)
+        t0 = time.perf_counter()
+        if args.trace_steps: ev0.record()
+        p = run_pass(graph, ex, batches, args.steps, args.method, bool(args.async_observe), hip_graph,
+                     bool(args.batch_observations), bool(args.reuse_activations), (args.queue_mib << 20) or None)
+        barrier(world)
+        elapsed = time.perf_counter() - t0
+        if args.trace_steps:
+            trace = [{'host_ms': round((t - t0) * 1e3, 2), 'dev_ms': round(ev0.elapsed_time(e), 2)} if not isinstance(e, float)
+                     else {'render_start_ms': round((t - t0) * 1e3, 2), 'render_ms': round((e - t) * 1e3, 2)} for t, e in TRACE_STEPS]
+            TRACE_STEPS = None
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        times.append(elapsed)
+        del ex
+    elapsed = sorted(times)[len(times) // 2]
+    if args.pmc_child: return                      # the rocprofv3 --pmc child: counters only, no JSON line
     n_obs = sum(len(o.observers()) for o in p._observers.values())
     scale_checksum = float(sum(float(c.scale.sum()) for op in graph.operations.values() if hasattr(op, 'config')
                                for c, v in op.config_with_variable if not v.is_parameter and c.scale is not None
                                and int(getattr(c.state, 'value', c.state)) == 4))
+    merge_stats = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in m.items()} for m in p.merge_stats]
 
     # roofline leg: the identical pass once more with hipEvent pairs around every library launch
     roof = None
@@ -231,11 +372,12 @@ def main():
         torch.cuda.synchronize()
         _lib.lib.ppqhip_prof_enable(0)
         prof_rows = collect_prof()
+        del graph2, ex2
         if prof_rows:
             # An event pair reports kernel duration + the command processor's timestamp / dispatch
             # overhead; the library measures that overhead with EMPTY pairs on the same stream and it is
             # subtracted, so avg_launch_us is comparable with rocprofv3's begin->end kernel duration
-            # (profiles/r01_bench_kernel_stats.csv).  The raw pair time is reported next to it.
+            # (profiles/r02_bench_kernel_stats.csv).  The raw pair time is reported next to it.
             _lib.lib.ppqhip_prof_event_overhead_us(torch.cuda.current_stream().cuda_stream, 16)      # warm
             overhead_us = max(0.0, float(_lib.lib.ppqhip_prof_event_overhead_us(torch.cuda.current_stream().cuda_stream, 256)))
             dom = max(prof_rows, key=lambda r: r['total_ms'])
@@ -243,19 +385,29 @@ def main():
             avg_s = max(raw_s - overhead_us * 1e-6, 0.25 * raw_s)
             avg_b = dom['total_bytes'] / dom['launches']
             ach = avg_b / avg_s / 1e9
-            traffic, traffic_src = pmc_traffic(dom['name'])
             roof = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS,
-                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': traffic,
-                    'traffic_source': traffic_src,
+                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': None, 'traffic_source': None,
                     'launches': dom['launches'], 'avg_launch_us': round(avg_s * 1e6, 2),
                     'avg_event_pair_us': round(raw_s * 1e6, 2), 'event_overhead_us': round(overhead_us, 2),
-                    'algorithmic_bytes_per_launch': round(avg_b)}
+                    'algorithmic_bytes_per_launch': round(avg_b),
+                    'frac_of_measured_copy_ceiling': round(ach / 6290.0, 4)}      # MI355X_MICROARCH.md: 6.29 TB/s float4 copy
     if world > 1:
         barrier(world)
+    torch.cuda.empty_cache()
+    if roof is not None and world == 1 and args.pmc:
+        child = ['--pmc-child', '--no-cpu-baseline', '--no-cpu-ops', '--pmc', '0', '--steps', str(min(args.steps, 2)),
+                 '--warmup', '0', '--repeats', '1', '--batch', str(args.batch), '--bins', str(args.bins),
+                 '--method', args.method, '--hip-graph', '0', '--miopen-find', '0', '--fuse-params', str(args.fuse_params),
+                 '--batch-observations', str(args.batch_observations), '--channels-last', str(args.channels_last)]
+        roof['traffic'], roof['traffic_source'] = pmc_traffic(roof['kernel'], child)
 
-    cpu = None
+    cpu = cpu_ops = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args.bins)
+    if rank == 0 and world == 1 and not args.no_cpu_ops:
+        from oracle import torch_cpu_path as T
+        cpu_ops = {'kind': 'reference-path', 'cores': torch.get_num_threads(), 'unit': 'ms (median) / GB/s of algorithmic bytes',
+                   'rows': T.op_table(args.bins)}
 
     if rank == 0:
         samples = world * args.steps * args.batch
@@ -265,18 +417,21 @@ def main():
             'value': round(samples / elapsed, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'repeats': len(times), 'values': [round(samples / t, 2) for t in times],
+            'spread_pct': round(100.0 * (max(times) - min(times)) / elapsed, 2),
             'config': {'workload': f'ResNet-50 topology (53 Conv + 1 Gemm, BN folded, seeded He init), '
                                    f'RuntimeCalibrationPass {args.method} {args.bins} bins, per-tensor INT8 activations, '
                                    f'per-channel INT8 weights, {args.steps} batches x {args.batch} x 3x224x224 per GPU',
                        'samples': samples, 'batch': args.batch, 'observed_tensors': n_obs,
                        'parallelism': f'dp{world} (batches sharded, 1 all-reduce per phase)',
+                       'rccl_ranks': world, 'backend': args.backend if world > 1 else None, 'merge': merge_stats,
                        'async_observe': bool(args.async_observe), 'cache_params': bool(args.cache_params),
                        'channels_last': bool(args.channels_last), 'fuse_params': bool(args.fuse_params), 'batch_observations': bool(args.batch_observations),
                        'reuse_activations': bool(args.reuse_activations), 'replayed_batches': p.replayed_batches,
                        'hip_graph': args.hip_graph, 'graph_replays': p.graph_replays,
                        'graph_decisions': [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()}
                                            for d in p.graph_decisions]},
-            'roofline': roof, 'cpu_baseline': cpu,
+            'roofline': roof, 'cpu_baseline': cpu, 'cpu_ops': cpu_ops,
             'kernels': [{'name': r['name'], 'launches': r['launches'], 'total_ms': round(r['total_ms'], 3),
                          'GBps': round(r['total_bytes'] / max(r['total_ms'], 1e-9) / 1e6, 1)} for r in prof_rows],
             'scale_checksum': scale_checksum,

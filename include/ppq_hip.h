@@ -266,21 +266,6 @@ int ppqhip_rounding_loss_bwd(const float* x, const float* dy, const float* scale
                              int64_t elem_per_channel, int clip_min, int clip_max, int rounding,
                              void* stream);
 
-/* fused calibration step (MI355X-native addition; one HBM read serves two consumers) ---------- */
-/* out = fake-quant(x) exactly as ppqhip_fq_linear_t, and hist += symmetric histogram of the
- * ORIGINAL x exactly as ppqhip_hist_sym_t. */
-int ppqhip_fq_linear_t_hist_sym(const float* x, const float* scale, const float* offset,
-                                float* out, int64_t n, int clip_min, int clip_max, int rounding,
-                                float hist_scale, int clip_outliers, int32_t* hist,
-                                int64_t num_bins, void* workspace, void* stream);
-/* the same step for an observer that keeps persistent rows (see ppqhip_hist_sym_t_rows): what the
- * executor-side delegate of a config that is ACTIVATED upstream and still observed downstream calls
- * (ppq/executor/torch.py:296-323, 516-550: quantize, then the hook observes the same fp32 value). */
-int ppqhip_fq_linear_t_hist_sym_rows(const float* x, const float* scale, const float* offset,
-                                     float* out, int64_t n, int clip_min, int clip_max, int rounding,
-                                     float hist_scale, int clip_outliers, int32_t* rows,
-                                     int64_t num_bins, void* stream);
-
 /* profiling aid used by bench.py: when enabled, every kernel launch made through this library
  * on this thread is bracketed by hipEvents on its own stream; ppqhip_prof_collect() synchronises
  * those events and returns, per kernel id, launches / total ms / total algorithmic bytes. */

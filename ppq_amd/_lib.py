@@ -76,10 +76,6 @@ PROTOTYPES = {
     'ppqhip_rounding_loss': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp]),
     'ppqhip_rounding_loss_bwd': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_int, c_int,
                                          c_int, c_vp]),
-    'ppqhip_fq_linear_t_hist_sym': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int, c_flt, c_int,
-                                            c_i32p, c_i64, c_vp, c_vp]),
-    'ppqhip_fq_linear_t_hist_sym_rows': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int, c_flt, c_int,
-                                                 c_i32p, c_i64, c_vp]),
     'ppqhip_prof_enable': (c_int, [c_int]),
     'ppqhip_prof_collect': (c_int, [ctypes.POINTER(ProfEntry), c_int]),
     'ppqhip_prof_event_overhead_us': (ctypes.c_double, [c_vp, c_int]),

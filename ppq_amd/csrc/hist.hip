@@ -297,13 +297,6 @@ struct HistJobs {
     uint32_t total_tiles;
     int bins, copies, mode;
 };
-struct FqArgs {                               // fused fake-quant of the (single) job: out = fq_linear_t(x)
-    const float* scale;
-    const float* offset;
-    float* out;
-    int qmin, qmax, rounding;
-};
-
 __host__ __device__ inline uint32_t job_tiles(uint32_t n, bool vec_ok) {
     if (!vec_ok) return (n + kTileElems - 1) / kTileElems;          // every tile through the scalar path
     const uint32_t full = (n >> 2) / kTileVec;
@@ -326,9 +319,9 @@ __device__ __forceinline__ void lds_hist_flush(int* lds, int bins, int copies, i
     __syncthreads();
 }
 
-template <bool ASYM, bool CLIP, bool HOT, bool NT, bool FQ, int R>
+template <bool ASYM, bool CLIP, bool HOT, bool NT>
 __global__ __launch_bounds__(kHistBlock, (kHistBlock * kHistWgPerCu + 255) / 256)
-void hist_persistent_kernel(const HistJobs jobs, const FqArgs fq) {
+void hist_persistent_kernel(const HistJobs jobs) {
     extern __shared__ int lds[];
     const uint32_t G = gridDim.x, g = blockIdx.x;
     uint32_t t = (uint32_t)(((uint64_t)g * jobs.total_tiles) / G);
@@ -347,8 +340,6 @@ void hist_persistent_kernel(const HistJobs jobs, const FqArgs fq) {
     }
     Binner<ASYM, CLIP, HOT> acc;
     acc.init(lds + ((threadIdx.x >> 6) % copies) * bins, bins);
-    float fs = 0.f; int fo = 0;
-    if (FQ) { fs = fq.scale[0]; fo = round_offset(fq.offset[0]); }
 
     for (uint32_t j = lo; t < t_end; j++) {
         const HistJob& job = jobs.job[j];
@@ -359,12 +350,11 @@ void hist_persistent_kernel(const HistJobs jobs, const FqArgs fq) {
         acc.set_rule(job.a, job.hs);
         const float* __restrict__ x = job.x;
         const uint32_t n = job.n;
-        const bool vec_ok = (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (!FQ || (reinterpret_cast<uintptr_t>(fq.out) & 15u) == 0);
+        const bool vec_ok = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
         const uint32_t full = vec_ok ? (n >> 2) / kTileVec : 0u;
         const uint32_t kf = min(k1, full);                                 // full tiles [k, kf)
         if (k < kf) {
             const float4* xv = reinterpret_cast<const float4*>(x) + threadIdx.x;
-            float4* ov = FQ ? reinterpret_cast<float4*>(fq.out) + threadIdx.x : nullptr;
             float4 bufa[kHistU], bufb[kHistU];
             auto fetch = [&](float4 (&buf)[kHistU], uint32_t tile) {
                 const float4* p = xv + (size_t)tile * kTileVec;
@@ -374,14 +364,6 @@ void hist_persistent_kernel(const HistJobs jobs, const FqArgs fq) {
             auto consume = [&](const float4 (&buf)[kHistU], uint32_t tile) {
 #pragma unroll
                 for (int u = 0; u < kHistU; u++) {
-                    if (FQ) {
-                        float4 r;
-                        r.x = fq_linear_scalar<R>(buf[u].x, fs, fo, fq.qmin, fq.qmax, fq.rounding);
-                        r.y = fq_linear_scalar<R>(buf[u].y, fs, fo, fq.qmin, fq.qmax, fq.rounding);
-                        r.z = fq_linear_scalar<R>(buf[u].z, fs, fo, fq.qmin, fq.qmax, fq.rounding);
-                        r.w = fq_linear_scalar<R>(buf[u].w, fs, fo, fq.qmin, fq.qmax, fq.rounding);
-                        ov[(size_t)tile * kTileVec + u * kHistBlock] = r;
-                    }
                     int b[4];
                     acc.bins4(buf[u], b);
                     if (u == 0) acc.elect(b[0], true);
@@ -411,7 +393,6 @@ void hist_persistent_kernel(const HistJobs jobs, const FqArgs fq) {
                 const uint32_t i = e0 + r * kHistBlock;
                 const bool in = i < n;
                 const float a = in ? x[i] : 0.f;
-                if (FQ && in) fq.out[i] = fq_linear_scalar<R>(a, fs, fo, fq.qmin, fq.qmax, fq.rounding);
                 const int b = acc.bin1(a);
                 if ((r & 3) == 0) acc.elect(b, in);
                 acc.template commit<false>(b, in);
@@ -518,15 +499,14 @@ static void launch_reduce(const int* partial, int grid, int bins, int32_t* hist,
                        partial, grid, bins, hist);
 }
 
-template <bool FQ, int R>
-static void launch_persistent(const HistJobs& args, const FqArgs& fq, int grid, int asym, int clip, bool nt, hipStream_t s) {
+static void launch_persistent(const HistJobs& args, int grid, int asym, int clip, bool nt, hipStream_t s) {
     const size_t lds = lds_bytes(args.bins, args.copies);
 #define PPQ_LAUNCH_HIST(A, C)                                                                                         \
     do {                                                                                                              \
-        if (nt) hipLaunchKernelGGL((hist_persistent_kernel<A, C, true, true, FQ, R>), dim3(grid), dim3(kHistBlock),  \
-                                   lds, s, args, fq);                                                                 \
-        else hipLaunchKernelGGL((hist_persistent_kernel<A, C, true, false, FQ, R>), dim3(grid), dim3(kHistBlock),    \
-                                lds, s, args, fq);                                                                    \
+        if (nt) hipLaunchKernelGGL((hist_persistent_kernel<A, C, true, true>), dim3(grid), dim3(kHistBlock), lds, s, \
+                                   args);                                                                             \
+        else hipLaunchKernelGGL((hist_persistent_kernel<A, C, true, false>), dim3(grid), dim3(kHistBlock), lds, s,   \
+                                args);                                                                                \
     } while (0)
     switch ((asym ? 2 : 0) | (clip ? 1 : 0)) {
         case 0: PPQ_LAUNCH_HIST(false, false); break;
@@ -547,15 +527,13 @@ static int persistent_grid(uint32_t tiles) {
 
 // one-shot histogram of one tensor, accumulated into hist[bins] (rows == nullptr) or into the caller's
 // persistent rows[kHistRows][bins]
-template <bool FQ, int R>
 static int launch_hist_one(const float* x, int64_t n, BinRule rule, int32_t* hist, void* workspace, hipStream_t s,
-                           int32_t* rows, const FqArgs& fq) {
+                           int32_t* rows) {
     HistJobs args;
     args.count = 1; args.bins = rule.bins; args.copies = pick_copies(rule.bins, kHistBlock);
     HistJob& d = args.job[0];
     d.x = x; d.n = (uint32_t)n; d.a = rule.a; d.hs = rule.hs; d.first_tile = 0;
-    const bool vec_ok = aligned16(x) && (!FQ || aligned16(fq.out));
-    args.total_tiles = job_tiles((uint32_t)n, vec_ok);
+    args.total_tiles = job_tiles((uint32_t)n, aligned16(x));
     const int grid = persistent_grid(args.total_tiles);
     int* partial = nullptr;
     if (rows) { args.mode = FLUSH_ROWS_ADD; d.rows = rows; }
@@ -565,7 +543,7 @@ static int launch_hist_one(const float* x, int64_t n, BinRule rule, int32_t* his
         if (partial == nullptr) return PPQHIP_ERR_HIP;
         args.mode = FLUSH_ROWS_STORE; d.rows = partial;
     }
-    launch_persistent<FQ, R>(args, fq, grid, rule.asym, rule.clip, n >= PPQHIP_HIST_NT_ELEMS, s);
+    launch_persistent(args, grid, rule.asym, rule.clip, n >= PPQHIP_HIST_NT_ELEMS, s);
     if (partial) launch_reduce(partial, grid, rule.bins, hist, s);
     return PPQHIP_OK;
 }
@@ -577,7 +555,7 @@ static int launch_hist_t(const float* x, int64_t n, BinRule rule, int32_t* hist,
                            rule, hist);
         return PPQHIP_OK;
     }
-    return launch_hist_one<false, 0>(x, n, rule, hist, workspace, s, rows, FqArgs{});
+    return launch_hist_one(x, n, rule, hist, workspace, s, rows);
 }
 
 static int launch_hist_multi(const ppqhip_hist_job* jobs, int count, int bins, int clip, int asym, hipStream_t s) {
@@ -599,7 +577,7 @@ static int launch_hist_multi(const ppqhip_hist_job* jobs, int count, int bins, i
             elems += src.n;
         }
         args.total_tiles = tiles;
-        launch_persistent<false, 0>(args, FqArgs{}, persistent_grid(tiles), asym, clip, elems >= PPQHIP_HIST_NT_ELEMS, s);
+        launch_persistent(args, persistent_grid(tiles), asym, clip, elems >= PPQHIP_HIST_NT_ELEMS, s);
     }
     return PPQHIP_OK;
 }
@@ -733,45 +711,6 @@ int ppqhip_hist_sym_c_scales(const float* x, int64_t n, int64_t num_channel, int
                              void* stream) {
     if (hist_scales == nullptr) { set_error("hist_sym_c_scales: hist_scales is null"); return PPQHIP_ERR_INVALID_VALUE; }
     return hist_sym_c_impl(x, n, num_channel, elem_per_channel, 1.0f, hist_scales, clip_outliers, hist, num_bins, stream);
-}
-
-int ppqhip_fq_linear_t_hist_sym(const float* x, const float* scale, const float* offset, float* out, int64_t n,
-                                int clip_min, int clip_max, int rounding, float hist_scale, int clip_outliers,
-                                int32_t* hist, int64_t num_bins, void* workspace, void* stream) {
-    if (int st = validate(n, num_bins, "fq_linear_t_hist_sym")) return st;
-    if (num_bins > kMaxLdsBins) {
-        set_error("fq_linear_t_hist_sym: at most %d bins", kMaxLdsBins); return PPQHIP_ERR_UNSUPPORTED;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    LaunchScope scope(K_FQ_HIST_FUSED, 8.0 * (double)n, s);
-    BinRule rule = make_rule(0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, 0);
-    FqArgs fq;
-    fq.scale = scale; fq.offset = offset; fq.out = out; fq.qmin = clip_min; fq.qmax = clip_max; fq.rounding = rounding;
-    int st;
-    if (rounding == ROUND_HALF_EVEN) st = launch_hist_one<true, ROUND_HALF_EVEN>(x, n, rule, hist, workspace, s, nullptr, fq);
-    else st = launch_hist_one<true, -1>(x, n, rule, hist, workspace, s, nullptr, fq);
-    if (st) return st;
-    return finish_launch("fq_linear_t_hist_sym");
-}
-
-/* the same, accumulating into the caller's persistent rows[ppqhip_hist_rows()][num_bins] (no per-launch reduce) */
-int ppqhip_fq_linear_t_hist_sym_rows(const float* x, const float* scale, const float* offset, float* out, int64_t n,
-                                     int clip_min, int clip_max, int rounding, float hist_scale, int clip_outliers,
-                                     int32_t* rows, int64_t num_bins, void* stream) {
-    if (int st = validate(n, num_bins, "fq_linear_t_hist_sym_rows")) return st;
-    if (num_bins > kMaxLdsBins) {
-        set_error("fq_linear_t_hist_sym_rows: at most %d bins", kMaxLdsBins); return PPQHIP_ERR_UNSUPPORTED;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    LaunchScope scope(K_FQ_HIST_FUSED, 8.0 * (double)n, s);
-    BinRule rule = make_rule(0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, 0);
-    FqArgs fq;
-    fq.scale = scale; fq.offset = offset; fq.out = out; fq.qmin = clip_min; fq.qmax = clip_max; fq.rounding = rounding;
-    int st;
-    if (rounding == ROUND_HALF_EVEN) st = launch_hist_one<true, ROUND_HALF_EVEN>(x, n, rule, nullptr, nullptr, s, rows, fq);
-    else st = launch_hist_one<true, -1>(x, n, rule, nullptr, nullptr, s, rows, fq);
-    if (st) return st;
-    return finish_launch("fq_linear_t_hist_sym_rows");
 }
 
 }  // extern "C"

@@ -10,7 +10,7 @@ and every ``ppq.core.ffi.CUDA.*`` wrapper of an unmodified PPQ then lands in our
 ``CUDA`` mirrors the reference's static-method class of the same name (ffi.py:56-350): same method
 names, argument names, defaults and order, for code that wants the operator surface without PPQ.
 It adds the MI355X-native entries that have no twin in the reference (``MinMax_T/C``, ``KLLosses``,
-``MseSearch``, ``LinearQuantize_T_Histogram``).
+``MseSearch``, the persistent-row / multi-tensor statistics launches).
 
 All tensor arguments must live on the GPU.  There is no CPU path: a CPU tensor raises.
 Errors follow the reference's convention as seen from Python: the C++ ``ValueTypeException`` /
@@ -618,21 +618,6 @@ class _HipExtension:
                                          int(bool(symmetrical)), best.data_ptr(), ws.data_ptr(), _stream()))
         return best
 
-    @ staticmethod
-    def QuantizeTensor_LT_Histogram(value, scale, offset, clip_min: int, clip_max: int, rounding: int,
-                                    hist_scale: float, clip_outliers: bool, hist) -> torch.Tensor:
-        """Fused: returns QuantizeTensor_LT(value ...) and accumulates Histogram_T(value ...) into hist."""
-        _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset'); _HipExtension._check_hist(hist)
-        v = value.contiguous()
-        out = torch.empty_like(v)
-        with _DeviceOf(v):
-            ws = _workspace(v.device, lib.ppqhip_hist_workspace_bytes(v.numel(), hist.numel()))
-            _raise(lib.ppqhip_fq_linear_t_hist_sym(v.data_ptr(), scale.data_ptr(), offset.data_ptr(), out.data_ptr(),
-                                                   v.numel(), int(clip_min), int(clip_max), int(rounding),
-                                                   float(hist_scale), int(bool(clip_outliers)), hist.data_ptr(),
-                                                   hist.numel(), ws.data_ptr(), _stream()))
-        return out
-
 
 HIP_EXTENSION = _HipExtension()
 
@@ -849,12 +834,6 @@ class CUDA:
     @ staticmethod
     def MseSearch(histogram, hist_scale, min_value, quant_min: int, quant_max: int, symmetrical: bool):
         return HIP_EXTENSION.MSE_Search(histogram, hist_scale, min_value, quant_min, quant_max, symmetrical)
-
-    @ staticmethod
-    def LinearQuantize_T_Histogram(tensor, scales, offsets, histogram, hist_scale: float, minimum: int = -128,
-                                   maximum: int = 127, rounding: int = 0, clip_outliers: bool = True):
-        return HIP_EXTENSION.QuantizeTensor_LT_Histogram(tensor, scales, offsets, minimum, maximum, rounding,
-                                                         hist_scale, clip_outliers, histogram)
 
     @ staticmethod
     def Sync():

@@ -252,8 +252,82 @@ def gen_observers():
     print('observers.npz', {n: int(out[n]) for n in ('minmax_n', 'pct_n', 'kl_n', 'mse_n')})
 
 
+def gen_observers_cuda_rule():
+    """KL / MSE scales the reference renders when ITS CUDA kernels collect the histogram.
+
+    The reference's CPU path bins with torch.histc (x == max lands in the last bin), its CUDA kernels drop
+    that element (sort.cu:84-86) and score MSE candidates with the float loss of csrc/cpu/hist_mse.cc
+    instead of the Python double loop (range.py:423-425).  On small tensors one count can flip the arg-min,
+    so round 1 could only assert "most" scales against the CPU goldens.  Here the reference's OWN
+    `hist_to_scale_offset` / `render_quantization_config` run on a histogram produced by the CUDA bin rule
+    (restated from sort.cu:75-139 in oracle/ppq_oracle.c and pinned to the reference's own tolerance) and,
+    for MSE, with `USING_CUDA_KERNEL = True` and the reference's own hist_mse.cc compiled where it lies
+    (oracle/_ref) installed as `compute_mse_loss` -- exactly the code a CUDA run of the reference executes
+    on the host.  tests/test_gpu_calibration.py asserts 100 % agreement with these."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import ppq_oracle as O
+    from ppq.core.ffi import CUDA_COMPLIER
+    out = {}
+    g = torch.Generator().manual_seed(42)
+    batches = [torch.randn(2, 16, 14, 14, generator=g) * (1 + 0.1 * i) + 0.2 for i in range(4)]
+    relu_batches = [torch.relu(b) for b in batches]
+
+    class HostExtension:                     # only the host helper is reachable with CPU tensors
+        @ staticmethod
+        def compute_mse_loss(hist, start, step, end): return O.ref_mse_loss(hist, start, step, end)
+    CUDA_COMPLIER.__CUDA_EXTENTION__ = HostExtension()
+
+    def cuda_hist(ob, data, sym, bins):
+        h = np.zeros(bins, np.int32)
+        for b in data:
+            if sym: O.hist_sym_t(b.numpy(), np.float32(ob._hist_scale), h)
+            else: O.hist_asym_t(b.numpy(), np.float32(ob._min), np.float32(ob._max), h)
+        return torch.from_numpy(h)
+
+    k = 0
+    for data_name, data in (('randn', batches), ('relu', relu_batches)):
+        for bins in (2048, 4096, 512):
+            for bits in (8, 4):
+                for pow2 in (False, True):
+                    qmin, qmax = (-128, 127) if bits == 8 else (-8, 7)
+                    cfg = tqc(False, True, qmin, qmax, bits, algo='kl', pow2=pow2,
+                              detail={'OBSERVER_KL_HIST_BINS_MANUL_OVERRIDE': bins})
+                    ob = TorchHistObserver(Variable('x'), cfg)
+                    for b in data: ob.observe(b)
+                    ob.render_quantization_config()
+                    ob._hist = cuda_hist(ob, data, True, bins)
+                    ob.render_quantization_config()
+                    out[f'kl_{k}_meta'] = np.array([data_name == 'relu', bins, bits, pow2])
+                    out[f'kl_{k}_scale'] = cfg.scale.numpy()
+                    k += 1
+    out['kl_n'] = np.array(k)
+    k = 0
+    PPQ_CONFIG.USING_CUDA_KERNEL = True
+    try:
+        for data_name, data in (('randn', batches), ('relu', relu_batches)):
+            for sym in (True, False):
+                for bins in (2048, 512):
+                    qmin, qmax = (-128, 127) if sym else (0, 255)
+                    cfg = tqc(False, sym, qmin, qmax, 8, algo='mse')
+                    ob = TorchMSEObserver(Variable('x'), cfg, bins=bins)
+                    for b in data: ob.observe(b)
+                    ob.render_quantization_config()
+                    ob._hist = cuda_hist(ob, data, sym, bins)
+                    ob.render_quantization_config()
+                    out[f'mse_{k}_meta'] = np.array([data_name == 'relu', sym, bins, qmin, qmax])
+                    out[f'mse_{k}_scale'] = cfg.scale.numpy(); out[f'mse_{k}_offset'] = cfg.offset.numpy()
+                    k += 1
+    finally:
+        PPQ_CONFIG.USING_CUDA_KERNEL = False
+    out['mse_n'] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, 'observers_cuda_rule.npz'), **out)
+    print('observers_cuda_rule.npz', {n: int(out[n]) for n in ('kl_n', 'mse_n')})
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
-    gen_linear()
-    gen_rounding()
-    gen_observers()
+    if '--cuda-rule-only' not in sys.argv:
+        gen_linear()
+        gen_rounding()
+        gen_observers()
+    gen_observers_cuda_rule()

@@ -4,6 +4,7 @@ pass plumbing is wired like the reference's, and the data-parallel merge is corr
 world_size 2.  No kernel is launched here (there is no GPU in the build container)."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -343,3 +344,60 @@ def test_harness_topologies():
     acts = sum(1 for op in full.operations.values() for c, p in op.config_with_variable if not p.is_parameter and c.state.value == 1)
     weights = sum(1 for op in full.operations.values() for c, p in op.config_with_variable if p.is_parameter and c.state.value == 1)
     assert (acts, weights) == (98, 50)
+
+
+def test_bench_spawns_its_own_ranks_from_a_plain_shell():
+    """`python bench.py --gpus 2 ...` with no launcher around it: bench.py re-executes itself under
+    torch.distributed.run on 127.0.0.1 and rank 0 prints ONE JSON line with n_gpus == 2.  The CPU-only
+    `--host-selftest` variant exercises spawn + rendezvous + the flat per-phase merge over gloo (the data
+    path itself needs a GPU: tests/test_gpu_calibration.py::test_bench_two_ranks_on_one_gpu)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--host-selftest'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['rccl_ranks'] == 2 and out['merged_counts_ok'] is True
+    assert [m['collectives'] for m in out['merge']] == [1, 1]            # ONE all-reduce per phase
+    assert out['merge'][1]['sum_int32_bytes'] == 72 * 2048 * 4
+    # a world size that contradicts --gpus is refused, not silently run as 1 rank
+    env2 = dict(env, WORLD_SIZE='1', RANK='0')
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--host-selftest'],
+                        capture_output=True, text=True, timeout=120, env=env2)
+    assert r2.returncode != 0 and 'WORLD_SIZE=1' in (r2.stderr + r2.stdout)
+
+
+def test_merge_refuses_mismatched_layouts():
+    """An observer that saw no batch on one rank declares nothing: the merge must fail loudly on every
+    rank instead of all-reducing buffers of different length."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_mismatch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)])
+    for p in procs: p.join(timeout=60)
+    assert all('different statistics layouts' in msg for _, msg in res), res
+
+
+def _mismatch_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ppq_amd.distributed import merge_observers
+
+    class FakeObserver:
+        def __init__(self, bufs): self.bufs = bufs
+        def reducible(self): return self.bufs
+    obs = [FakeObserver([(torch.zeros(64, dtype=torch.int32), 'sum')])]
+    if rank == 0: obs.append(FakeObserver([(torch.zeros(64, dtype=torch.int32), 'sum')]))    # rank 1 saw no batch for it
+    try:
+        merge_observers(obs); msg = 'no error'
+    except RuntimeError as e:
+        msg = str(e)
+    q.put((rank, msg))
+    dist.destroy_process_group()

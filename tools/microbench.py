@@ -72,7 +72,6 @@ def main():
             'minmax_t': (4, lambda: CUDA.MinMax_T(X(), mm)),
             'minmax_c': (4, lambda: CUDA.MinMax_C(X(), 1, mins, maxs)),
             'quantile_t': (4, lambda: CUDA.Quantile(X(), 0.9999)),
-            'fq_t+hist fused': (8, lambda: CUDA.LinearQuantize_T_Histogram(X(), s1, o1, hist, hs)),
             'lsq_bwd_t': (12, lambda: CUDA.LinearQuantize_T_B(X(), s1, o1, dyv, -128, 127, 0)),
             'lsq_bwd_c': (12, lambda: CUDA.LinearQuantize_C_B(X(), sc, oc, dyv, 0, 255, 1, 0)),
             'torch copy (ref)': (8, lambda: X().clone()),
