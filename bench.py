@@ -270,6 +270,7 @@ def main():
     ap.add_argument('--repeats', type=int, default=3, help='timed passes (each exactly K steps); value = median')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cpu-ops', action='store_true')
+    ap.add_argument('--variants', type=int, default=1, help="also time SURVEY 8(d)'s own protocol (batch 1 x 256 steps) once and report it in config.variants")
     ap.add_argument('--pmc', type=int, default=1, help='measure roofline.traffic with two rocprofv3 --pmc child passes of this command')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--host-selftest', action='store_true', help='CPU-only check of spawn + rendezvous + merge (gloo); no GPU work')
@@ -354,6 +355,22 @@ def main():
                                and int(getattr(c.state, 'value', c.state)) == 4))
     merge_stats = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in m.items()} for m in p.merge_stats]
 
+    # BASELINE config 2 exactly as SURVEY 8(d) words it: batch 1, calib_steps 256 (launch-bound: HIP-graph replay pays)
+    variants = []
+    if args.variants and world == 1 and not (args.batch == 1 and args.steps == 256):
+        vb = [torch.rand(1, 3, 224, 224, device=dev, generator=g) for _ in range(256)]
+        vtimes = []
+        for _ in range(2):                 # first pass warms MIOpen's batch-1 kernels, second is reported
+            graph_v, ex_v = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params, bool(args.channels_last))
+            barrier(world); tv = time.perf_counter()
+            pv = run_pass(graph_v, ex_v, vb, 256, args.method, False, 'auto', bool(args.batch_observations))
+            barrier(world); vtimes.append(time.perf_counter() - tv)
+            del graph_v, ex_v
+        variants.append({'workload': 'batch 1 x 256 steps (SURVEY 8(d) protocol), HIP-graph replay auto', 'samples': 256,
+                         'value': round(256 / vtimes[-1], 2), 'unit': 'samples/s', 'ms_per_step': round(vtimes[-1] / 256 * 1e3, 3),
+                         'graph_replays': pv.graph_replays})
+        del vb, pv
+
     # roofline leg: the identical pass once more with hipEvent pairs around every library launch
     roof = None
     prof_rows = []
@@ -395,7 +412,7 @@ def main():
         barrier(world)
     torch.cuda.empty_cache()
     if roof is not None and world == 1 and args.pmc:
-        child = ['--pmc-child', '--no-cpu-baseline', '--no-cpu-ops', '--pmc', '0', '--steps', str(min(args.steps, 2)),
+        child = ['--pmc-child', '--no-cpu-baseline', '--no-cpu-ops', '--pmc', '0', '--variants', '0', '--steps', str(min(args.steps, 2)),
                  '--warmup', '0', '--repeats', '1', '--batch', str(args.batch), '--bins', str(args.bins),
                  '--method', args.method, '--hip-graph', '0', '--miopen-find', '0', '--fuse-params', str(args.fuse_params),
                  '--batch-observations', str(args.batch_observations), '--channels-last', str(args.channels_last)]
@@ -425,6 +442,7 @@ def main():
                        'samples': samples, 'batch': args.batch, 'observed_tensors': n_obs,
                        'parallelism': f'dp{world} (batches sharded, 1 all-reduce per phase)',
                        'rccl_ranks': world, 'backend': args.backend if world > 1 else None, 'merge': merge_stats,
+                       'variants': variants,
                        'async_observe': bool(args.async_observe), 'cache_params': bool(args.cache_params),
                        'channels_last': bool(args.channels_last), 'fuse_params': bool(args.fuse_params), 'batch_observations': bool(args.batch_observations),
                        'reuse_activations': bool(args.reuse_activations), 'replayed_batches': p.replayed_batches,

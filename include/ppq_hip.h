@@ -139,6 +139,12 @@ int ppqhip_hist_sym_c(const float* x, int64_t n, int64_t num_channel, int64_t el
 int ppqhip_hist_sym_c_scales(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
                              const float* hist_scales, int clip_outliers, int32_t* hist,
                              int64_t num_bins, void* stream);
+/* ... and the asymmetric rule per channel: channel c is binned exactly as ppqhip_hist_asym_t would bin the slice
+ * of channel c with (mins[c], maxs[c]) (device float[num_channel] each).  Feeds the per-channel MSE search
+ * (TorchMSEObserver raises on PER_CHANNEL, observer/range.py:496-497). */
+int ppqhip_hist_asym_c_ranges(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
+                              const float* mins, const float* maxs, int clip_outliers, int32_t* hist,
+                              int64_t num_bins, void* stream);
 
 /* order statistics ---------------------------------------------------------------------------- */
 /* replaces Quantile_T, sort.cu:42-59 (CUDA.Quantile ffi.py:171-176): dest[0] = sorted[rn(n*q)],

@@ -46,6 +46,7 @@ PROTOTYPES = {
     'ppqhip_hist_asym_t': (c_int, [c_f32p, c_i64, c_flt, c_flt, c_int, c_i32p, c_i64, c_vp, c_vp]),
     'ppqhip_hist_sym_c': (c_int, [c_f32p, c_i64, c_i64, c_i64, c_flt, c_int, c_i32p, c_i64, c_vp]),
     'ppqhip_hist_sym_c_scales': (c_int, [c_f32p, c_i64, c_i64, c_i64, c_f32p, c_int, c_i32p, c_i64, c_vp]),
+    'ppqhip_hist_asym_c_ranges': (c_int, [c_f32p, c_i64, c_i64, c_i64, c_f32p, c_f32p, c_int, c_i32p, c_i64, c_vp]),
     'ppqhip_quantile_workspace_bytes': (c_i64, [c_i64]),
     'ppqhip_quantile_t': (c_int, [c_f32p, c_i64, c_flt, c_f32p, c_vp, c_vp]),
     'ppqhip_isotone_t': (c_int, [c_f32p, c_i64, c_f32p, c_vp, c_vp]),

@@ -9,24 +9,19 @@ What runs where:
     ``ppqhip_channel_sum`` (double accumulation, fixed summation order);
   * the block forwards go through the executor (``partial_graph_forward``), i.e. through the HIP
     fake-quant kernels for every activated config;
-  * blocks are the reference's ``block_size = 1`` case: every Conv / ConvTranspose / Gemm that owns a
-    bias parameter is its own block (the BlockBuilder graph search of training.py:191-222 for larger
-    blocks is graph plumbing outside this package's scope).
+  * blocks come from ppq_amd/blocks.py (the reference's TrainableBlock definition); ``block_size`` is the
+    depth limit (default 1: every computing op is its own block, as in the reference's default).
 """
 from collections import defaultdict
 from typing import Callable, Dict, Iterable, List, Tuple
 
 import torch
 
+from .blocks import collect, compute_block_loss, split_graph_into_blocks, torch_mean_square_error
 from .calibration import QuantizationOptimizationPass
 from .ffi import CUDA
 
 BIAS_CORRECTION_INTERST_TYPE = {'Conv', 'ConvTranspose', 'Gemm'}      # ppq/core/common.py
-
-
-def torch_mean_square_error(y_pred: torch.Tensor, y_real: torch.Tensor) -> torch.Tensor:
-    """ppq/quantization/measure/norm.py: mean over the batch of the per-sample mean squared error."""
-    return torch.mean(torch.mean(torch.square(y_pred.flatten(1) - y_real.flatten(1)), dim=-1))
 
 
 def collect_bias(output: torch.Tensor, op_type: str) -> torch.Tensor:
@@ -42,8 +37,6 @@ class BiasCorrectionPass(QuantizationOptimizationPass):
     def __init__(self, interested_layers: List[str] = [], collecting_device: str = 'cuda',
                  steps: int = 32, block_size: int = 1) -> None:
         super().__init__(name='PPQ Bias Correction Pass')
-        if block_size != 1:
-            raise NotImplementedError('BiasCorrectionPass: only block_size = 1 (one computing op per block)')
         self.interested_layers = interested_layers
         self.steps = steps
         self.block_size = block_size
@@ -51,54 +44,39 @@ class BiasCorrectionPass(QuantizationOptimizationPass):
         self.loss_fn = torch_mean_square_error
         self.report: List[Tuple[str, float, float]] = []
 
-    # ---------------------------------------------------------------- data collection (training.py:224-298)
-    def collect(self, graph, op, executor, batches) -> Tuple[List[Dict[str, torch.Tensor]], List[Dict[str, torch.Tensor]]]:
-        feeds = [v for v in op.inputs if not v.is_parameter]
-        quantable = [o for o in graph.operations.values() if hasattr(o, 'config')]
-        for o in quantable: o.dequantize()
-        fp_outputs = [{op.outputs[0].name: executor.forward(b, [op.outputs[0].name])[0]} for b in batches]
-        for o in quantable: o.restore_quantize_state()
-        qt_inputs = []
-        for b in batches:
-            if all(v.name in graph.inputs for v in feeds):
-                vals = [b if isinstance(b, torch.Tensor) else b[v.name] for v in feeds]
-            else:
-                vals = executor.forward(b, [v.name for v in feeds])
-            qt_inputs.append({v.name: x for v, x in zip(feeds, vals)})
-        return qt_inputs, fp_outputs
-
-    def compute_block_loss(self, op, qt_inputs, fp_outputs, executor) -> float:
-        """training.py:300-335."""
-        name, loss = op.outputs[0].name, 0.0
-        for qt_input, fp_output in zip(qt_inputs, fp_outputs):
-            out = executor.partial_graph_forward([op], qt_input, [name])[0]
-            loss += float(self.loss_fn(out, fp_output[name]))
-        return loss / len(qt_inputs)
-
     # ---------------------------------------------------------------- one block (training.py:433-527)
     @ torch.no_grad()
-    def correct_bias(self, qt_inputs, fp_outputs, op, executor) -> Tuple[float, float]:
-        pre_loss = self.compute_block_loss(op, qt_inputs, fp_outputs, executor)
-        bias = op.inputs[-1]
-        bias_cloned = bias.value.clone()
-        name = op.outputs[0].name
+    def correct_bias(self, qt_inputs, fp_outputs, block, executor, graph) -> Tuple[float, float]:
+        pre_loss = compute_block_loss(block, qt_inputs, fp_outputs, executor, self.loss_fn)
+        bias_cloned, interested_outputs = {}, []
+        for op in block.rps:
+            if (op.type in BIAS_CORRECTION_INTERST_TYPE and len(op.inputs) == 3 and op.inputs[-1].is_parameter
+                    and isinstance(op.inputs[-1].value, torch.Tensor)):
+                bias_cloned[op.name] = op.inputs[-1].value.clone()
+                interested_outputs.append(op.outputs[0].name)
+        if not interested_outputs: return pre_loss, pre_loss
         fp_cache, qt_cache = defaultdict(list), defaultdict(list)
-        op.dequantize()                                                   # phase 1: FP32 block output
+        quantable = [op for op in block.rps if hasattr(op, 'config')]
+        for op in quantable: op.dequantize()                              # phase 1: FP32 block outputs
         for qt_input in qt_inputs:
-            out = executor.partial_graph_forward([op], qt_input, [name])[0]
-            fp_cache[name].append(collect_bias(out, op.type))
-        op.restore_quantize_state()                                       # phase 2: quantised block output
+            outs = executor.partial_graph_forward(block.rps, qt_input, interested_outputs)
+            for name, value in zip(interested_outputs, outs):
+                fp_cache[name].append(collect_bias(value, graph.variables[name].source_op.type))
+        for op in quantable: op.restore_quantize_state()                  # phase 2: quantised block outputs
         for qt_input in qt_inputs:
-            out = executor.partial_graph_forward([op], qt_input, [name])[0]
-            qt_cache[name].append(collect_bias(out, op.type))
-        if len(fp_cache[name]) == 0 or len(qt_cache[name]) == 0:
-            raise ValueError('Bias correction failed, No data was collected.')
-        DC_term_fp = torch.mean(torch.cat(fp_cache[name], dim=0), dim=0)
-        DC_term_qt = torch.mean(torch.cat(qt_cache[name], dim=0), dim=0)
-        bias.value += (DC_term_fp - DC_term_qt).to(bias.value.dtype)
-        post_loss = self.compute_block_loss(op, qt_inputs, fp_outputs, executor)
+            outs = executor.partial_graph_forward(block.rps, qt_input, interested_outputs)
+            for name, value in zip(interested_outputs, outs):
+                qt_cache[name].append(collect_bias(value, graph.variables[name].source_op.type))
+        for name in interested_outputs:
+            if len(fp_cache[name]) == 0 or len(qt_cache[name]) == 0:
+                raise ValueError('Bias correction failed, No data was collected.')
+            DC_term_fp = torch.mean(torch.cat(fp_cache[name], dim=0), dim=0)
+            DC_term_qt = torch.mean(torch.cat(qt_cache[name], dim=0), dim=0)
+            bias = graph.variables[name].source_op.inputs[-1]
+            bias.value += (DC_term_fp - DC_term_qt).to(bias.value.dtype)
+        post_loss = compute_block_loss(block, qt_inputs, fp_outputs, executor, self.loss_fn)
         if post_loss > pre_loss:                                          # loss check: drop a worse result
-            bias.value.copy_(bias_cloned)
+            for op_name, value in bias_cloned.items(): graph.operations[op_name].inputs[-1].value.copy_(value)
             post_loss = pre_loss
         return pre_loss, post_loss
 
@@ -108,11 +86,9 @@ class BiasCorrectionPass(QuantizationOptimizationPass):
             batches.append(collate_fn(data) if collate_fn is not None else data)
             if len(batches) >= self.steps: break
         self.report = []
-        for op in graph.topological_sort():
-            if op.type not in BIAS_CORRECTION_INTERST_TYPE or not hasattr(op, 'config'): continue
-            if self.interested_layers and op.name not in self.interested_layers: continue
-            if not (len(op.inputs) == 3 and op.inputs[-1].is_parameter
-                    and isinstance(op.inputs[-1].value, torch.Tensor)): continue   # no bias: skipped
-            qt_inputs, fp_outputs = self.collect(graph, op, executor, batches)
-            pre_loss, post_loss = self.correct_bias(qt_inputs, fp_outputs, op, executor)
-            self.report.append((op.name, pre_loss, post_loss))
+        blocks = split_graph_into_blocks(graph, graph.topological_sort(), self.block_size,
+                                         interested_layers=self.interested_layers)
+        for block in blocks:
+            qt_inputs, fp_outputs = collect(graph, block, executor, batches)
+            pre_loss, post_loss = self.correct_bias(qt_inputs, fp_outputs, block, executor, graph)
+            self.report.append((block.sp.name, pre_loss, post_loss))

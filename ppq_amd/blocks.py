@@ -1,0 +1,150 @@
+"""Trainable blocks -- what the finetuning passes (LearnedStepSizePass, BiasCorrectionPass) iterate over.
+
+Counterpart of ``TrainableBlock`` / ``BlockBuilder`` (ppq/quantization/algorithm/training.py:171-315) and of
+``TrainingBasedPass.split_graph_into_blocks / collect / compute_block_loss``
+(ppq/quantization/optim/training.py:177-335).  The block DEFINITION is the reference's (training.py:229-242):
+
+    a block is a triple (S, E, M): S the input operation, E the output operation, M every operation on a
+    path from S to E;  E lies on every path from S to a graph output, S on every path from a graph input to
+    E;  the minimal block of an operation p is (p, p, {p});  depth(E) - depth(S) <= limit.
+
+The SEARCH is this package's own: instead of the reference's recursive coherent-successor / blocking-node
+walk over its SearchableGraph, one forward sweep in execution order grows the region reached from S and
+records, after every operation it absorbs, whether the region is closed -- no value enters it except
+through S, no value leaves it except through the operation just absorbed.  Each closed prefix is a block by
+the definition above, and the last one within the depth limit is returned (the reference's walk stops at
+the same operations: its coherent successor and blocking multi-input node are exactly the closure points).
+"""
+from typing import Dict, Iterable, List, Optional, Tuple
+
+import torch
+
+OPTIM_ADVOPT_GRAPH_MAXDEPTH = 4                                  # ppq/core/common.py
+COMPUTING_OP = {'Conv', 'Gemm', 'ConvTranspose', 'MatMul'}      # ppq/core/common.py:56
+
+
+class TrainableBlock:
+    """training.py:171-188."""
+    def __init__(self, sp, ep, rps: list) -> None:
+        self.sp, self.ep, self.rps = sp, ep, rps
+
+    def __str__(self) -> str:
+        return f'[Graph Block from {self.sp.name} to {self.ep.name}]'
+
+
+def upstream_operations(op) -> list:
+    return [v.source_op for v in op.inputs if not v.is_parameter and v.source_op is not None]
+
+
+def downstream_operations(op) -> list:
+    out = []
+    for v in op.outputs:
+        for d in v.dest_ops:
+            if d not in out: out.append(d)
+    return out
+
+
+class BlockBuilder:
+    def __init__(self, graph, topo_order: Optional[list] = None) -> None:
+        self.graph = graph
+        self.op_orders = list(topo_order) if topo_order is not None else graph.topological_sort()
+        self.index = {op.name: i for i, op in enumerate(self.op_orders)}
+        self.depth: Dict[str, int] = {}
+        for op in self.op_orders:                                  # training.py:300-315
+            ups = upstream_operations(op)
+            self.depth[op.name] = 0 if not ups else max(self.depth[u.name] for u in ups) + 1
+
+    def build(self, op, limit: int) -> TrainableBlock:
+        start = self.index[op.name]
+        region = {op.name}
+        members = [op]
+        open_edges = {}                       # member name -> consumers not yet absorbed (graph outputs never close)
+        graph_outputs = set(self.graph.outputs)
+
+        def consumers(o):
+            return {d.name for d in downstream_operations(o)}
+        open_edges[op.name] = consumers(op)
+        best = 1                              # members[:best] is the last closed prefix == the block
+        for nxt in self.op_orders[start + 1:]:
+            ups = [u.name for u in upstream_operations(nxt)]
+            if not any(u in region for u in ups): continue        # a parallel branch that does not descend from S
+            feeds_from_outside = any(u not in region for u in ups) or \
+                any((not v.is_parameter) and v.source_op is None for v in nxt.inputs)
+            if feeds_from_outside: break                          # S no longer dominates: nothing beyond is a block
+            if self.depth[nxt.name] - self.depth[op.name] > limit: break
+            region.add(nxt.name); members.append(nxt)
+            open_edges[nxt.name] = consumers(nxt)
+            closed = True
+            for m in members[:-1]:
+                if any(c not in region for c in open_edges[m.name]) or any(v.name in graph_outputs for v in m.outputs):
+                    closed = False; break
+            if closed: best = len(members)
+        rps = members[:best]
+        return TrainableBlock(sp=op, ep=rps[-1], rps=rps)
+
+
+def split_graph_into_blocks(graph, executing_order: Optional[list] = None, blocksize: Optional[int] = None,
+                            overlap: bool = False, interested_layers: Optional[List[str]] = None) -> List[TrainableBlock]:
+    """optim/training.py:177-222: one block per (not yet visited) quantable computing op, in graph order."""
+    if blocksize is None: blocksize = OPTIM_ADVOPT_GRAPH_MAXDEPTH
+    builder = BlockBuilder(graph, executing_order)
+    visited, blocks = set(), []
+    for op in graph.operations.values():
+        if op.name in visited and not overlap: continue
+        if hasattr(op, 'config') and op.type in COMPUTING_OP:
+            block = builder.build(op, blocksize)
+            for o in block.rps: visited.add(o.name)
+            blocks.append(block)
+    if not interested_layers: return blocks
+    return [b for b in blocks if any(o.name in interested_layers for o in b.rps)]
+
+
+def torch_mean_square_error(y_pred: torch.Tensor, y_real: torch.Tensor) -> torch.Tensor:
+    """ppq/quantization/measure/norm.py: mean over the batch of the per-sample mean squared error."""
+    return torch.mean(torch.mean(torch.square(y_pred.flatten(1) - y_real.flatten(1)), dim=-1))
+
+
+@ torch.no_grad()
+def collect_fp_outputs(graph, blocks: List[TrainableBlock], executor, batches: Iterable) -> List[List[dict]]:
+    """FP32 end-point outputs of EVERY block from one dequantised forward per batch (the weights as they are
+    now): result[k][i] = {name: tensor} for block k, batch i."""
+    quantable = [o for o in graph.operations.values() if hasattr(o, 'config')]
+    names = [[v.name for v in b.ep.outputs] for b in blocks]
+    flat = [n for ns in names for n in ns]
+    for o in quantable: o.dequantize()
+    out = [[] for _ in blocks]
+    for b in batches:
+        vals = dict(zip(flat, executor.forward(b, flat)))
+        for k, ns in enumerate(names): out[k].append({n: vals[n].detach() for n in ns})
+    for o in quantable: o.restore_quantize_state()
+    return out
+
+
+@ torch.no_grad()
+def collect(graph, block: TrainableBlock, executor, batches: Iterable, fp_outputs: List[dict] = None) -> Tuple[List[dict], List[dict]]:
+    """optim/training.py:224-298: FP32 outputs of the block's end point with the WHOLE graph dequantised,
+    then the quantised inputs of its start point with the quantisation state restored (two forwards per
+    batch; everything stays on the executor's device -- 288 GB of HBM hold the cache).  `fp_outputs`: use
+    these targets instead of collecting them now."""
+    quantable = [o for o in graph.operations.values() if hasattr(o, 'config')]
+    if fp_outputs is None: fp_outputs = collect_fp_outputs(graph, [block], executor, batches)[0]
+    feeds = [v for v in block.sp.inputs if not v.is_parameter]
+    qt_inputs = []
+    for b in batches:
+        if all(v.name in graph.inputs for v in feeds):
+            vals = [b if isinstance(b, torch.Tensor) else b[v.name] for v in feeds]
+        else:
+            vals = executor.forward(b, [v.name for v in feeds])
+        qt_inputs.append({v.name: x.detach() for v, x in zip(feeds, vals)})
+    return qt_inputs, fp_outputs
+
+
+@ torch.no_grad()
+def compute_block_loss(block: TrainableBlock, qt_inputs, fp_outputs, executor, loss_fn=torch_mean_square_error) -> float:
+    """optim/training.py:300-335."""
+    names = [v.name for v in block.ep.outputs]
+    losses = {n: 0.0 for n in names}
+    for qt_input, fp_output in zip(qt_inputs, fp_outputs):
+        outs = executor.partial_graph_forward(block.rps, qt_input, names)
+        for n, y in zip(names, outs): losses[n] += float(loss_fn(y, fp_output[n]))
+    return sum(v / len(qt_inputs) for v in losses.values())

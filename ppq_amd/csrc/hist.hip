@@ -426,20 +426,25 @@ __global__ __launch_bounds__(kBlock) void hist_t_global_kernel(const float* __re
 }
 
 // per channel, long rows: workgroup = (row, chunk); one channel per workgroup -> LDS histogram
-template <bool CLIP>
+// (scales: one hist_scale per channel; mins / maxs: one asymmetric range per channel, hist_scale =
+//  (max - min) / bins as in sort.cu:123)
+template <bool ASYM, bool CLIP>
 __global__ __launch_bounds__(kBlock) void hist_c_row_kernel(const float* __restrict__ x, uint32_t epc, FastDiv chunks,
                                                             FastDiv num_channel, uint32_t chunk_elems, BinRule rule,
                                                             int copies, int* __restrict__ hist,
-                                                            const float* __restrict__ scales) {
+                                                            const float* __restrict__ scales,
+                                                            const float* __restrict__ mins,
+                                                            const float* __restrict__ maxs) {
     extern __shared__ int lds[];
     for (int i = threadIdx.x; i < copies * rule.bins; i += kBlock) lds[i] = 0;
     __syncthreads();
     const uint32_t row = fdiv(blockIdx.x, chunks);
     const uint32_t chunk = blockIdx.x - row * chunks.d;
     const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
-    Binner<false, CLIP, true> acc;
+    Binner<ASYM, CLIP, true> acc;
     acc.init(lds + ((threadIdx.x >> 6) % copies) * rule.bins, rule.bins);
-    acc.set_rule(0.f, scales != nullptr ? scales[c] : rule.hs);          // per-channel hist_scale
+    if (ASYM) acc.set_rule(mins[c], (maxs[c] - mins[c]) / (float)rule.bins);      // per-channel range
+    else acc.set_rule(0.f, scales != nullptr ? scales[c] : rule.hs);              // per-channel hist_scale
     const uint32_t lo = chunk * chunk_elems;
     const uint32_t hi = min(lo + chunk_elems, epc);
     const float* xr = x + (size_t)row * epc;
@@ -464,13 +469,16 @@ __global__ __launch_bounds__(kBlock) void hist_c_row_kernel(const float* __restr
 __global__ __launch_bounds__(kBlock) void hist_c_global_kernel(const float* __restrict__ x, uint32_t n,
                                                                FastDiv elem_per_channel, FastDiv num_channel,
                                                                BinRule rule, int* __restrict__ hist,
-                                                               const float* __restrict__ scales) {
+                                                               const float* __restrict__ scales,
+                                                               const float* __restrict__ mins,
+                                                               const float* __restrict__ maxs) {
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const uint32_t row = fdiv(i, elem_per_channel);
         const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
         BinRule r = rule;
         if (scales != nullptr) r.hs = scales[c];
+        if (rule.asym) { r.a = mins[c]; r.hs = (maxs[c] - mins[c]) / (float)rule.bins; }
         int b;
         if (bin_of(x[i], r, &b)) atomicAdd(&hist[(size_t)c * rule.bins + b], 1);
     }
@@ -670,47 +678,61 @@ int ppqhip_hist_rows_finish(const int32_t* rows, int64_t num_bins, int32_t* hist
     return finish_launch("hist_rows_finish");
 }
 
-static int hist_sym_c_impl(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
-                           float hist_scale, const float* scales, int clip_outliers, int32_t* hist, int64_t num_bins,
-                           void* stream) {
-    if (int st = validate(n, num_bins, "hist_sym_c")) return st;
+static int hist_c_impl(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
+                       float hist_scale, const float* scales, const float* mins, const float* maxs, int clip_outliers,
+                       int32_t* hist, int64_t num_bins, void* stream, const char* what) {
+    if (int st = validate(n, num_bins, what)) return st;
     if (num_channel <= 0 || elem_per_channel <= 0 || n % (num_channel * elem_per_channel) != 0) {
-        set_error("hist_sym_c: Kernel Failure, Histogram shape is invalid."); return PPQHIP_ERR_INVALID_VALUE;
+        set_error("%s: Kernel Failure, Histogram shape is invalid.", what); return PPQHIP_ERR_INVALID_VALUE;
     }
     hipStream_t s = (hipStream_t)stream;
+    const int asym = mins != nullptr;
     LaunchScope scope(K_HIST_SYM_C, 4.0 * (double)n, s);
-    BinRule rule = make_rule(0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, 0);
+    BinRule rule = make_rule(0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, asym);
     const FastDiv nc = make_fastdiv((uint32_t)num_channel);
     if (elem_per_channel >= 1024 && num_bins <= kMaxLdsBins) {
         const int copies = pick_copies(rule.bins, kBlock);
         const uint32_t chunk_elems = 16384;
         const uint32_t chunks = (uint32_t)((elem_per_channel + chunk_elems - 1) / chunk_elems);
         const int64_t rows = n / elem_per_channel;
-        if (rule.clip)
-            hipLaunchKernelGGL((hist_c_row_kernel<true>), dim3((uint32_t)(rows * chunks)), dim3(kBlock),
-                               lds_bytes(rule.bins, copies), s, x, (uint32_t)elem_per_channel, make_fastdiv(chunks), nc,
-                               chunk_elems, rule, copies, hist, scales);
-        else
-            hipLaunchKernelGGL((hist_c_row_kernel<false>), dim3((uint32_t)(rows * chunks)), dim3(kBlock),
-                               lds_bytes(rule.bins, copies), s, x, (uint32_t)elem_per_channel, make_fastdiv(chunks), nc,
-                               chunk_elems, rule, copies, hist, scales);
+#define PPQ_LAUNCH_HIST_C(A, C)                                                                                      \
+        hipLaunchKernelGGL((hist_c_row_kernel<A, C>), dim3((uint32_t)(rows * chunks)), dim3(kBlock),                 \
+                           lds_bytes(rule.bins, copies), s, x, (uint32_t)elem_per_channel, make_fastdiv(chunks), nc, \
+                           chunk_elems, rule, copies, hist, scales, mins, maxs)
+        switch ((asym ? 2 : 0) | (rule.clip ? 1 : 0)) {
+            case 0: PPQ_LAUNCH_HIST_C(false, false); break;
+            case 1: PPQ_LAUNCH_HIST_C(false, true); break;
+            case 2: PPQ_LAUNCH_HIST_C(true, false); break;
+            default: PPQ_LAUNCH_HIST_C(true, true); break;
+        }
+#undef PPQ_LAUNCH_HIST_C
     } else {
         hipLaunchKernelGGL(hist_c_global_kernel, dim3(stream_grid(n, kBlock * 4)), dim3(kBlock), 0, s, x, (uint32_t)n,
-                           make_fastdiv((uint32_t)elem_per_channel), nc, rule, hist, scales);
+                           make_fastdiv((uint32_t)elem_per_channel), nc, rule, hist, scales, mins, maxs);
     }
-    return finish_launch("hist_sym_c");
+    return finish_launch(what);
 }
 
 int ppqhip_hist_sym_c(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
                       float hist_scale, int clip_outliers, int32_t* hist, int64_t num_bins, void* stream) {
-    return hist_sym_c_impl(x, n, num_channel, elem_per_channel, hist_scale, nullptr, clip_outliers, hist, num_bins, stream);
+    return hist_c_impl(x, n, num_channel, elem_per_channel, hist_scale, nullptr, nullptr, nullptr, clip_outliers, hist,
+                       num_bins, stream, "hist_sym_c");
 }
 
 int ppqhip_hist_sym_c_scales(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
                              const float* hist_scales, int clip_outliers, int32_t* hist, int64_t num_bins,
                              void* stream) {
     if (hist_scales == nullptr) { set_error("hist_sym_c_scales: hist_scales is null"); return PPQHIP_ERR_INVALID_VALUE; }
-    return hist_sym_c_impl(x, n, num_channel, elem_per_channel, 1.0f, hist_scales, clip_outliers, hist, num_bins, stream);
+    return hist_c_impl(x, n, num_channel, elem_per_channel, 1.0f, hist_scales, nullptr, nullptr, clip_outliers, hist,
+                       num_bins, stream, "hist_sym_c_scales");
+}
+
+int ppqhip_hist_asym_c_ranges(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
+                              const float* mins, const float* maxs, int clip_outliers, int32_t* hist,
+                              int64_t num_bins, void* stream) {
+    if (mins == nullptr || maxs == nullptr) { set_error("hist_asym_c_ranges: mins / maxs is null"); return PPQHIP_ERR_INVALID_VALUE; }
+    return hist_c_impl(x, n, num_channel, elem_per_channel, 1.0f, nullptr, mins, maxs, clip_outliers, hist, num_bins,
+                       stream, "hist_asym_c_ranges");
 }
 
 }  // extern "C"

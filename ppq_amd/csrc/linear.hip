@@ -115,15 +115,20 @@ __global__ __launch_bounds__(kBlock) void fq_linear_c_scalar_kernel(
 // --------------------------------------------------------------------------- LSQ backward
 // One element of QuantizeTensor_LT_B / _LC_B (linear.cu:255-274 / :352-372).  `o` is the rounded
 // offset kept as float, as in the reference; returns the partial d(loss)/d(scale) term.
-template <bool CHANNEL>
-__device__ __forceinline__ float lsq_bwd_elem(float v, float dy, float s, float o, int qmin, int qmax,
-                                              int rounding, float* gx) {
-    const int qt = f2i_sat((float)round2int(v / s, rounding) + o);
-    if (qt > qmax) { *gx = 0.f; return ((float)qmax - o) * dy; }
-    if (qt < qmin) { *gx = 0.f; return ((float)qmin - o) * dy; }
-    const float q = (float)(qt - f2i_sat(o)) * s;
-    *gx = dy;
-    return CHANNEL ? ((q - v) / s * dy) : ((q - v) * dy / s);
+// R >= 0: the rounding policy is a compile-time constant (ROUND_HALF_EVEN: one v_rndne); R < 0: runtime.
+// The quotient v / s that decides the clipping mask is the IEEE division (grad_x must be exact); the
+// residual term (q - v) / s * dy only feeds a float32 sum over the whole tensor, so it uses RN(1/s):
+// 2 ulp on a term whose sum is order dependent to 1e-6 anyway (tests: 1e-4 relative vs the oracle).
+template <bool CHANNEL, int R>
+__device__ __forceinline__ float lsq_bwd_elem(float v, float dy, float s, float rcp_s, float o, int oi, int qmin,
+                                              int qmax, int rounding, float* gx) {
+    const int r = (R >= 0) ? round2int_t<(R >= 0 ? R : 0)>(v / s) : round2int(v / s, rounding);
+    const int qt = f2i_sat((float)r + o);
+    const float q = (float)(qt - oi) * s;
+    const bool hi = qt > qmax, lo = qt < qmin;
+    const float inside = CHANNEL ? ((q - v) * rcp_s * dy) : ((q - v) * dy * rcp_s);
+    *gx = (hi || lo) ? 0.f : dy;
+    return hi ? ((float)qmax - o) * dy : (lo ? ((float)qmin - o) * dy : inside);
 }
 
 __device__ __forceinline__ float block_sum(float v, float* lds) {
@@ -142,39 +147,59 @@ __device__ __forceinline__ float block_sum(float v, float* lds) {
 // per tensor: one contiguous chunk per workgroup, 16-B loads of x and dy, 16-B stores of grad_x;
 // the workgroup's partial d(loss)/d(scale) goes to partial[blockIdx.x] (no same-address atomics),
 // lsq_finish_kernel sums the partials in double and applies grad_factor.
+#ifndef PPQHIP_LSQ_U
+#define PPQHIP_LSQ_U 4                  // (x, dy) 16-B load pairs in flight per lane (MI355X sweep, Bx32: U=1 152 us, 2 127, 4 116)
+#endif
+#ifndef PPQHIP_LSQ_MAX_WG
+#define PPQHIP_LSQ_MAX_WG 65536         // workgroups per launch (one partial sum each)
+#endif
+template <int R, bool NT>
 __global__ __launch_bounds__(kBlock) void fq_linear_t_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
     const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ partial, uint32_t n, int vec_ok,
     int qmin, int qmax, int rounding) {
     __shared__ float lds[kBlock / kWave];
     const float s = scale[0];
+    const float rcp_s = 1.0f / s;
     const float o = __builtin_roundf(offset[0]);
+    const int oi = f2i_sat(o);
     float acc = 0.f;
     uint32_t done = 0;
     if (vec_ok) {
+        constexpr int U = PPQHIP_LSQ_U;
         const uint32_t nvec = n >> 2;
         const float4* xv = reinterpret_cast<const float4*>(x);
         const float4* dv = reinterpret_cast<const float4*>(dy);
         float4* gv = reinterpret_cast<float4*>(gx);
-        const uint32_t tiles = (nvec + kBlock - 1) / kBlock;
+        const uint32_t tile = kBlock * U;
+        const uint32_t tiles = (nvec + tile - 1) / tile;
         const uint32_t per = (tiles + gridDim.x - 1) / gridDim.x;
-        const uint32_t lo = blockIdx.x * per * kBlock;
-        const uint32_t hi = min(lo + per * kBlock, nvec);
-        for (uint32_t v = lo + threadIdx.x; v < hi; v += kBlock) {
-            const float4 a = xv[v], d = dv[v];
-            float4 g;
-            acc += lsq_bwd_elem<false>(a.x, d.x, s, o, qmin, qmax, rounding, &g.x);
-            acc += lsq_bwd_elem<false>(a.y, d.y, s, o, qmin, qmax, rounding, &g.y);
-            acc += lsq_bwd_elem<false>(a.z, d.z, s, o, qmin, qmax, rounding, &g.z);
-            acc += lsq_bwd_elem<false>(a.w, d.w, s, o, qmin, qmax, rounding, &g.w);
-            gv[v] = g;
+        const uint32_t lo = blockIdx.x * per * tile;
+        const uint32_t hi = min(lo + per * tile, nvec);
+        for (uint32_t v = lo + threadIdx.x; v < hi; v += tile) {
+            float4 a[U], d[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t at = min(v + u * kBlock, hi - 1);          // clamped: loads stay unconditional
+                a[u] = load4<NT>(&xv[at]); d[u] = load4<NT>(&dv[at]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (v + u * kBlock >= hi) break;
+                float4 g;
+                acc += lsq_bwd_elem<false, R>(a[u].x, d[u].x, s, rcp_s, o, oi, qmin, qmax, rounding, &g.x);
+                acc += lsq_bwd_elem<false, R>(a[u].y, d[u].y, s, rcp_s, o, oi, qmin, qmax, rounding, &g.y);
+                acc += lsq_bwd_elem<false, R>(a[u].z, d[u].z, s, rcp_s, o, oi, qmin, qmax, rounding, &g.z);
+                acc += lsq_bwd_elem<false, R>(a[u].w, d[u].w, s, rcp_s, o, oi, qmin, qmax, rounding, &g.w);
+                gv[v + u * kBlock] = g;
+            }
         }
         done = nvec << 2;
     }
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t i = done + blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         float g;
-        acc += lsq_bwd_elem<false>(x[i], dy[i], s, o, qmin, qmax, rounding, &g);
+        acc += lsq_bwd_elem<false, R>(x[i], dy[i], s, rcp_s, o, oi, qmin, qmax, rounding, &g);
         gx[i] = g;
     }
     const float tot = block_sum(acc, lds);
@@ -199,6 +224,7 @@ __global__ __launch_bounds__(kBlock) void lsq_finish_kernel(const float* __restr
 
 // rows = outer * C rows of `epc` contiguous elements; block b handles chunk (b % chunks) of row
 // (b / chunks) -> one channel per block, one atomic per block (spread over C addresses).
+template <int R>
 __global__ __launch_bounds__(kBlock) void fq_linear_c_bwd_row_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
     const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ gs, uint32_t epc, int vec_ok,
@@ -209,7 +235,9 @@ __global__ __launch_bounds__(kBlock) void fq_linear_c_bwd_row_kernel(
     const uint32_t chunk = blockIdx.x - row * chunks.d;
     const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
     const float s = scale[c];
+    const float rcp_s = 1.0f / s;
     const float o = __builtin_roundf(offset[c]);
+    const int oi = f2i_sat(o);
     const uint32_t lo = chunk * chunk_elems;
     const uint32_t hi = min(lo + chunk_elems, epc);
     const size_t base = (size_t)row * epc;
@@ -221,16 +249,16 @@ __global__ __launch_bounds__(kBlock) void fq_linear_c_bwd_row_kernel(
         for (uint32_t v = (lo >> 2) + threadIdx.x; v < (hi >> 2); v += kBlock) {
             const float4 a = xv[v], d = dv[v];
             float4 g;
-            acc += lsq_bwd_elem<true>(a.x, d.x, s, o, qmin, qmax, rounding, &g.x);
-            acc += lsq_bwd_elem<true>(a.y, d.y, s, o, qmin, qmax, rounding, &g.y);
-            acc += lsq_bwd_elem<true>(a.z, d.z, s, o, qmin, qmax, rounding, &g.z);
-            acc += lsq_bwd_elem<true>(a.w, d.w, s, o, qmin, qmax, rounding, &g.w);
+            acc += lsq_bwd_elem<true, R>(a.x, d.x, s, rcp_s, o, oi, qmin, qmax, rounding, &g.x);
+            acc += lsq_bwd_elem<true, R>(a.y, d.y, s, rcp_s, o, oi, qmin, qmax, rounding, &g.y);
+            acc += lsq_bwd_elem<true, R>(a.z, d.z, s, rcp_s, o, oi, qmin, qmax, rounding, &g.z);
+            acc += lsq_bwd_elem<true, R>(a.w, d.w, s, rcp_s, o, oi, qmin, qmax, rounding, &g.w);
             gv[v] = g;
         }
     } else {
         for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
             float g;
-            acc += lsq_bwd_elem<true>(x[base + j], dy[base + j], s, o, qmin, qmax, rounding, &g);
+            acc += lsq_bwd_elem<true, R>(x[base + j], dy[base + j], s, rcp_s, o, oi, qmin, qmax, rounding, &g);
             gx[base + j] = g;
         }
     }
@@ -256,8 +284,8 @@ __global__ __launch_bounds__(kBlock) void fq_linear_c_bwd_generic_kernel(
         const uint32_t row = fdiv(i, elem_per_channel);
         const uint32_t c = row - fdiv(row, num_channel) * C;
         float g;
-        const float p = lsq_bwd_elem<true>(x[i], dy[i], scale[c], __builtin_roundf(offset[c]), qmin, qmax,
-                                            rounding, &g);
+        const float sc = scale[c], oc = __builtin_roundf(offset[c]);
+        const float p = lsq_bwd_elem<true, -1>(x[i], dy[i], sc, 1.0f / sc, oc, f2i_sat(oc), qmin, qmax, rounding, &g);
         gx[i] = g;
         if (use_lds) atomicAdd(&acc_lds[c], p);
         else atomicAdd(&gs[c], p * grad_factor);
@@ -515,12 +543,20 @@ int ppqhip_fq_linear_t_bwd(const float* x, const float* scale, const float* offs
     LaunchScope scope(K_FQ_LINEAR_T_BWD, 12.0 * (double)n, s);
     // rsqrtf(((double)n * (clip_max - clip_min))): linear.cu:299
     const float grad_factor = (float)(1.0 / sqrt((double)n * (double)(clip_max - clip_min)));
-    const int grid = stream_grid(n, kBlock * 4 * 4, kNumCU * 8);
+    // one tile per workgroup while that keeps the grid below PPQHIP_LSQ_MAX_WG: tens of thousands of short
+    // workgroups stream better than a chip-sized persistent grid here (same finding as the forward tile kernels;
+    // lsq_bwd_c, which has always been tiled by rows, ran 10 % faster than the persistent form of this kernel)
+    const int grid = stream_grid(n, kBlock * 4 * PPQHIP_LSQ_U, PPQHIP_LSQ_MAX_WG);
     float* partial = (float*)scratch(s, sizeof(float) * (size_t)grid);
     if (partial == nullptr) return PPQHIP_ERR_HIP;
     const int vec_ok = (aligned16(x) && aligned16(grad_y) && aligned16(grad_x)) ? 1 : 0;
-    hipLaunchKernelGGL(fq_linear_t_bwd_kernel, dim3(grid), dim3(kBlock), 0, s, x, scale, offset, grad_y, grad_x,
-                       partial, (uint32_t)n, vec_ok, clip_min, clip_max, rounding);
+    const bool nt = n >= kStreamElems / 2;       // x and dy together exceed cache residency: streaming loads
+#define PPQ_LAUNCH_LSQ_T(R, NT)                                                                                     \
+    hipLaunchKernelGGL((fq_linear_t_bwd_kernel<R, NT>), dim3(grid), dim3(kBlock), 0, s, x, scale, offset, grad_y,   \
+                       grad_x, partial, (uint32_t)n, vec_ok, clip_min, clip_max, rounding)
+    if (rounding == ROUND_HALF_EVEN) { if (nt) PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, true); else PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, false); }
+    else { if (nt) PPQ_LAUNCH_LSQ_T(-1, true); else PPQ_LAUNCH_LSQ_T(-1, false); }
+#undef PPQ_LAUNCH_LSQ_T
     hipLaunchKernelGGL(lsq_finish_kernel, dim3(1), dim3(kBlock), 0, s, (const float*)partial, (uint32_t)grid,
                        grad_factor, grad_s);
     return finish_launch("fq_linear_t_bwd");
@@ -544,9 +580,14 @@ int ppqhip_fq_linear_c_bwd(const float* x, const float* scale, const float* offs
         const uint32_t chunks = (uint32_t)((elem_per_channel + chunk_elems - 1) / chunk_elems);
         const int64_t rows = n / elem_per_channel;
         const int vec_ok = (elem_per_channel % 4 == 0 && aligned16(x) && aligned16(grad_y) && aligned16(grad_x)) ? 1 : 0;
-        hipLaunchKernelGGL(fq_linear_c_bwd_row_kernel, dim3((uint32_t)(rows * chunks)), dim3(kBlock), 0, s, x,
-                           scale, offset, grad_y, grad_x, grad_s, (uint32_t)elem_per_channel, vec_ok,
-                           make_fastdiv(chunks), nc, chunk_elems, clip_min, clip_max, grad_factor, rounding);
+        if (rounding == ROUND_HALF_EVEN)
+            hipLaunchKernelGGL((fq_linear_c_bwd_row_kernel<ROUND_HALF_EVEN>), dim3((uint32_t)(rows * chunks)),
+                               dim3(kBlock), 0, s, x, scale, offset, grad_y, grad_x, grad_s, (uint32_t)elem_per_channel,
+                               vec_ok, make_fastdiv(chunks), nc, chunk_elems, clip_min, clip_max, grad_factor, rounding);
+        else
+            hipLaunchKernelGGL((fq_linear_c_bwd_row_kernel<-1>), dim3((uint32_t)(rows * chunks)), dim3(kBlock), 0, s, x,
+                               scale, offset, grad_y, grad_x, grad_s, (uint32_t)elem_per_channel, vec_ok,
+                               make_fastdiv(chunks), nc, chunk_elems, clip_min, clip_max, grad_factor, rounding);
     } else {
         const int use_lds = num_channel <= 8192;
         const size_t lds = use_lds ? sizeof(float) * (size_t)num_channel : 0;

@@ -109,6 +109,7 @@ class _DeviceOf:
 
 
 _workspaces = {}
+_MAX_WORKSPACES = 16
 
 
 def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
@@ -117,10 +118,12 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
     captured into a HIP graph (it then comes from the graph's private pool and lives as long as this
     cache holds it).  Launches that use it are ordered on the current stream."""
     key = (device.index, _stream())
-    ws = _workspaces.get(key)
+    ws = _workspaces.pop(key, None)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=device)
-        _workspaces[key] = ws
+    _workspaces[key] = ws                       # most recently used last
+    while len(_workspaces) > _MAX_WORKSPACES:   # streams come and go (side streams, graph capture): drop the oldest;
+        _workspaces.pop(next(iter(_workspaces)))    # the caching allocator frees it once queued work on its stream is done
     return ws
 
 
@@ -347,6 +350,19 @@ class _HipExtension:
         with _DeviceOf(v):
             _raise(lib.ppqhip_hist_sym_c_scales(v.data_ptr(), v.numel(), C, epc, hist_scales.contiguous().data_ptr(),
                                                 int(bool(clip_outliers)), hist.data_ptr(), hist.numel() // C, _stream()))
+
+    @ staticmethod
+    def Histogram_Asymmetric_C_Ranges(value, channel_axis: int, mins, maxs, clip_outliers: bool, hist) -> None:
+        """Per-channel asymmetric histogram, one (min, max) per channel (device float32 [C]); hist int32 [C, bins]."""
+        _f32(value, 'Value'); _f32(mins, 'Mins'); _f32(maxs, 'Maxs'); _HipExtension._check_hist(hist)
+        v = value.contiguous()
+        C, epc = _geometry(v.shape, channel_axis)
+        if hist.numel() % C != 0 or mins.numel() != C or maxs.numel() != C:
+            raise RuntimeError(_KERNEL_FAILURE + 'Histogram shape is invalid.')
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_hist_asym_c_ranges(v.data_ptr(), v.numel(), C, epc, mins.contiguous().data_ptr(),
+                                                 maxs.contiguous().data_ptr(), int(bool(clip_outliers)), hist.data_ptr(),
+                                                 hist.numel() // C, _stream()))
 
     @ staticmethod
     def Quantile_T(source, q: float) -> torch.Tensor:
@@ -686,6 +702,11 @@ class CUDA:
     @ staticmethod
     def Histogram_C_Scales(tensor, channel_axis: int, histogram, scales, clip_outliers: bool = True):
         HIP_EXTENSION.Histogram_C_Scales(tensor, channel_axis, scales, clip_outliers, histogram)
+        return histogram
+
+    @ staticmethod
+    def Histogram_Asymmetric_C_Ranges(tensor, channel_axis: int, histogram, mins, maxs, clip_outliers: bool = True):
+        HIP_EXTENSION.Histogram_Asymmetric_C_Ranges(tensor, channel_axis, mins, maxs, clip_outliers, histogram)
         return histogram
 
     @ staticmethod

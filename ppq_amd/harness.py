@@ -30,7 +30,7 @@ from .core import QuantizationProperty as P
 from .observer import OperationObserver, TensorObserverFactroy
 from .qfunction import PPQuantFunction
 
-PASSIVE_OPERATIONS = {'MaxPool', 'GlobalMaxPool', 'Reshape', 'Flatten', 'Identity', 'Dropout', 'Slice', 'Pad',
+PASSIVE_OPERATIONS = {'MaxPool', 'GlobalMaxPool', 'Reshape', 'Flatten', 'Identity', 'Dropout', 'Slice', 'Pad', 'Resize',
                       'Split', 'Transpose', 'Interp', 'Squeeze', 'Unsqueeze'}        # ppq/core/common.py:50-53
 COMPUTING_OP = {'Conv', 'Gemm', 'ConvTranspose', 'MatMul'}
 
@@ -152,6 +152,7 @@ def _forward(op: Operation, x: List[torch.Tensor]):
     if t == 'Concat': return torch.cat([v.expand(x[-1].shape[0], *v.shape[1:]) if v.shape[0] == 1 else v for v in x],
                                        dim=a.get('axis', 1))
     if t == 'Slice': return x[0].narrow(a['axis'], a['start'], a['length'])
+    if t == 'Resize': return F.interpolate(x[0], scale_factor=a.get('scale', 2), mode=a.get('mode', 'nearest'))
     raise NotImplementedError(f'Graph op: {op.name}({op.type}) has no backend implementation')
 
 
@@ -205,7 +206,6 @@ class TorchExecutor:
         """torch.py:412-455: the same loop with autograd enabled (finetuning passes)."""
         return TorchExecutor.forward.__wrapped__(self, inputs, output_names, hooks)
 
-    @ torch.no_grad()
     def partial_graph_forward(self, operations: List[Operation], feed_dict: Dict[str, torch.Tensor],
                               output_names: List[str]) -> List[torch.Tensor]:
         """ppq/executor/torch.py:654-730: run only `operations` (already in execution order) on the
@@ -452,6 +452,93 @@ def resnet50_graph(seed: int = 0, num_classes: int = 1000) -> BaseGraph:
     y = g.create_operation('Gemm', 'fc', [y, w, b])
     g.outputs[y.name] = y
     return g
+
+
+def yolov6s_graph(seed: int = 0, num_classes: int = 80) -> BaseGraph:
+    """A YOLOv6-s-like detector (BASELINE config 5), deploy form: EfficientRep backbone (RepVGG blocks
+    re-parameterised to 3x3 Conv + Relu, widths 32-64-128-256-512, repeats 1-2-4-6-2, SPPF-style pooling
+    tail), Rep-PAN neck (1x1 reduce, nearest x2 Resize, Concat, Rep blocks; 3x3 stride-2 down path) and a
+    decoupled head per scale (1x1 stem, 3x3 + 1x1 class branch, 3x3 + 1x1 box branch): 6 outputs at strides
+    8 / 16 / 32.  Seeded He-initialised weights, BatchNorm folded.  Stands in for the ONNX model that cannot be
+    loaded here (no `onnx`); what matters to this package is the operator mix the finetuning passes walk:
+    plain conv chains, fan-outs that close at a Concat, Resize / MaxPool passive ops, multiple outputs."""
+    gen = torch.Generator().manual_seed(seed)
+    g = BaseGraph('yolov6s')
+    x = g.create_variable('input')
+    g.inputs['input'] = x
+    n = [0]
+
+    def conv(inp, cin, cout, k=3, stride=1, relu=True, tag='conv'):
+        n[0] += 1
+        # He-UNIFORM weights: every output channel spreads over its whole per-channel range, so INT4 (16 levels)
+        # keeps information in nearly every weight -- like a trained, quantisation-aware detector, and unlike a
+        # raw re-parameterised RepVGG kernel whose identity tap would own the range and round the rest to zero
+        a = (6.0 / (cin * k * k)) ** 0.5
+        w = g.create_variable(f'{tag}{n[0]}_w', (torch.rand([cout, cin, k, k], generator=gen) * 2 - 1) * a, True)
+        b = g.create_variable(f'{tag}{n[0]}_b', torch.randn(cout, generator=gen) * 0.05, True)
+        y = g.create_operation('Conv', f'{tag}{n[0]}', [inp, w, b], {'strides': stride, 'pads': k // 2})
+        if relu: y = g.create_operation('Relu', f'relu{n[0]}', [y])
+        return y
+
+    def rep(inp, c, repeats):
+        for _ in range(repeats): inp = conv(inp, c, c, 3, tag='rep')
+        return inp
+
+    def cat(name, vs): return g.create_operation('Concat', name, vs, {'axis': 1})
+
+    y = conv(x, 3, 32, 3, 2, tag='stem')                         # stride 2
+    feats, cin = [], 32
+    for stage, (c, r) in enumerate(zip([64, 128, 256, 512], [2, 4, 6, 2])):
+        y = conv(y, cin, c, 3, 2, tag=f's{stage}_down')
+        y = rep(y, c, r)
+        cin = c
+        feats.append(y)                                          # strides 4, 8, 16, 32
+    # SPPF-style tail on the stride-32 feature
+    p = conv(feats[3], 512, 256, 1, tag='sppf_in')
+    m1 = g.create_operation('MaxPool', 'sppf_pool1', [p], {'kernel_shape': 5, 'strides': 1, 'pads': 2})
+    m2 = g.create_operation('MaxPool', 'sppf_pool2', [m1], {'kernel_shape': 5, 'strides': 1, 'pads': 2})
+    m3 = g.create_operation('MaxPool', 'sppf_pool3', [m2], {'kernel_shape': 5, 'strides': 1, 'pads': 2})
+    c5 = conv(cat('sppf_cat', [p, m1, m2, m3]), 1024, 512, 1, tag='sppf_out')
+    c3, c4 = feats[1], feats[2]                                  # 128 @ s8, 256 @ s16
+    # Rep-PAN: top-down
+    r5 = conv(c5, 512, 128, 1, tag='reduce5')
+    u5 = g.create_operation('Resize', 'up5', [r5], {'scale': 2})
+    p4 = rep(conv(cat('cat_p4', [u5, c4]), 128 + 256, 128, 3, tag='p4_in'), 128, 3)
+    r4 = conv(p4, 128, 64, 1, tag='reduce4')
+    u4 = g.create_operation('Resize', 'up4', [r4], {'scale': 2})
+    p3 = rep(conv(cat('cat_p3', [u4, c3]), 64 + 128, 64, 3, tag='p3_in'), 64, 3)          # out @ s8
+    # bottom-up
+    d3 = conv(p3, 64, 64, 3, 2, tag='down3')
+    n4 = rep(conv(cat('cat_n4', [d3, r4]), 64 + 64, 128, 3, tag='n4_in'), 128, 3)         # out @ s16
+    d4 = conv(n4, 128, 128, 3, 2, tag='down4')
+    n5 = rep(conv(cat('cat_n5', [d4, r5]), 128 + 128, 256, 3, tag='n5_in'), 256, 3)       # out @ s32
+    for name, f, c in (('s8', p3, 64), ('s16', n4, 128), ('s32', n5, 256)):
+        stem = conv(f, c, c, 1, tag=f'head_{name}_stem')
+        cls = conv(conv(stem, c, c, 3, tag=f'head_{name}_cls'), c, num_classes, 1, relu=False, tag=f'head_{name}_cls_out')
+        box = conv(conv(stem, c, c, 3, tag=f'head_{name}_box'), c, 4, 1, relu=False, tag=f'head_{name}_box_out')
+        g.outputs[cls.name] = cls
+        g.outputs[box.name] = box
+    _unit_variance_init(g, torch.rand(2, 3, 96, 96, generator=gen))
+    return g
+
+
+@ torch.no_grad()
+def _unit_variance_init(g: BaseGraph, sample: torch.Tensor) -> None:
+    """Layer-sequential unit-variance rescaling of the seeded weights (a trained, BatchNorm-folded detector has
+    O(1) activations everywhere; 56 unnormalised He-initialised convolutions in a row do not: the positive mean
+    of ReLU outputs compounds to 1e10).  One CPU forward on a seeded sample; every Conv's weight and bias are
+    divided by the standard deviation of its output.  Deterministic in `seed`."""
+    values = {next(iter(g.inputs)): sample}
+    for op in g.operations.values():
+        xs = [v.value if v.is_parameter else values[v.name] for v in op.inputs]
+        y = _forward(op, xs)
+        if op.type == 'Conv':
+            std = float(y.std())
+            if std > 0:
+                op.inputs[1].value = op.inputs[1].value / std
+                if len(op.inputs) > 2: op.inputs[2].value = op.inputs[2].value / std
+                y = y / std
+        values[op.outputs[0].name] = y
 
 
 def small_cnn_graph(seed: int = 0, width: int = 16) -> BaseGraph:

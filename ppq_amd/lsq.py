@@ -113,18 +113,36 @@ class LSQDelegator:
 
 
 class LearnedStepSizePass:
-    """The finetune loop of ppq/quantization/optim/training.py:728-826 (LearnedStepSizePass.finetune)
-    for a graph treated as ONE trainable block: LSQDelegators on every activated config, Adam over
-    {weights, scales, offsets}, MSE between the quantised and the FP32 block output (+ gamma * weight
-    quantisation error), withdraw when the loss did not improve.  The reference's block splitting
-    (BlockBuilder, training.py:191-315) is graph plumbing outside this package's scope."""
-    def __init__(self, steps: int = 100, lr: float = 5e-5, gamma: float = 0.0, optimizer=None, process_group=None):
+    """ppq/quantization/optim/training.py:569-863: block-wise LSQ finetuning.
+
+    The graph is cut into TrainableBlocks (ppq_amd/blocks.py; ``block_size`` = the reference's depth limit,
+    default 5, training.py:711); per block: collect the FP32 block outputs (graph dequantised) and the
+    quantised block inputs, put an LSQDelegator on every activated config of the block, run Adam over
+    {weights, scales, offsets} through ``partial_graph_forward`` (forward fake-quant kernels, backward LSQ
+    kernels), loss = MSE against the FP32 block output (+ gamma * weight quantisation error), withdraw when
+    the block loss did not improve (training.py:728-826).  ``block_size=None`` treats the whole graph as ONE
+    block (round 1's form, kept for graphs with one input and one output).
+
+    Data-parallel finetuning (one process per GPU, each with its shard of the batches): the gradients of ALL
+    trainable tensors of a block travel in ONE flat all-reduce per step (a few MB at most -- latency bound on
+    xGMI, so never one collective per tensor); block losses are averaged so every rank takes the same keep /
+    withdraw decision.  ``report`` = [(block, pre_loss, post_loss)]."""
+    def __init__(self, steps: int = 500, lr: float = 5e-5, gamma: float = 0.0, optimizer=None, process_group=None,
+                 block_size: int = None, interested_layers: List[str] = None, is_scale_trainable: bool = True,
+                 fp_reference: str = 'current'):
         self.steps, self.lr, self.gamma, self.optimizer = steps, lr, gamma, optimizer
-        # data-parallel finetuning (one process per GPU, each with its shard of the batches): gradients of
-        # ALL trainable tensors travel in ONE flat all-reduce per step (a few MB at most for a block --
-        # latency bound on xGMI, so never one collective per tensor), block losses are averaged so every
-        # rank takes the same keep / withdraw decision
         self.process_group = process_group
+        self.block_size = block_size
+        self.interested_layers = interested_layers or []
+        self.is_scale_trainable = is_scale_trainable
+        # 'current' (the reference, training.py:224-298): a block's FP32 target is collected right before it is
+        # trained, from the dequantised graph WITH the weights the earlier blocks have already moved -- Adam's
+        # sign-like steps on the latent FP32 weights are coherent over a whole fan-in, so on hard cases (INT4) the
+        # FP32 function itself drifts and later blocks chase a moving target.  'initial' (opt-in, not in the
+        # reference): every block's target comes from the ORIGINAL weights, collected once before any training.
+        if fp_reference not in ('current', 'initial'): raise ValueError("fp_reference: 'current' or 'initial'")
+        self.fp_reference = fp_reference
+        self.report = []
 
     def _world(self) -> int:
         import torch.distributed as dist
@@ -146,36 +164,28 @@ class LearnedStepSizePass:
     def _loss(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
         return torch.mean(torch.square(a.flatten(1) - b.flatten(1)))          # torch_mean_square_error
 
-    def optimize(self, graph, dataloader, executor, **kwargs):
-        ops = [op for op in graph.operations.values() if hasattr(op, 'config')]
-        saved = {}
-        # FP32 reference outputs: every config switched off (QuantableOperation.dequantize)
-        for op in ops:
-            for cfg, _ in op.config_with_variable:
-                saved[cfg] = cfg.state
-                if QuantizationStates.is_activated(cfg.state): cfg.state = QuantizationStates.FP32
-        batches = list(dataloader)
-        fp_outputs = [executor.forward(b)[0].detach() for b in batches]
-        for cfg, st in saved.items(): cfg.state = st
+    def _block_loss(self, block, qt_inputs, fp_outputs, executor) -> float:
+        from .blocks import compute_block_loss
+        loss = torch.tensor([compute_block_loss(block, qt_inputs, fp_outputs, executor, self._loss)],
+                            dtype=torch.float32, device=next(iter(qt_inputs[0].values())).device)
+        self._average([loss])
+        return float(loss)
 
-        def block_loss():
-            with torch.no_grad():
-                loss = sum(self._loss(executor.forward(b)[0], f) for b, f in zip(batches, fp_outputs)) / len(batches)
-                loss = loss.reshape(1).clone()
-                self._average([loss])
-                return float(loss)
-        pre_loss = block_loss()
+    def finetune(self, block, executor, qt_inputs, fp_outputs):
+        """training.py:728-826 for one block."""
+        pre_loss = self._block_loss(block, qt_inputs, fp_outputs, executor)
         delegators, tensors = {}, []
-        for op in ops:
+        for op in block.rps:
+            if not hasattr(op, 'config'): continue
             if op.type in {'Conv', 'Gemm', 'ConvTranspose', 'MatMul', 'Add', 'Mul'}:
                 for var in op.inputs:
-                    if var.is_parameter:
+                    if var.is_parameter and isinstance(var.value, torch.Tensor) and var.value.dtype == torch.float32:
                         var.value.requires_grad_(True); tensors.append(var.value)
             for cfg, var in op.config_with_variable:
                 if state_value(cfg.state) in (QuantizationStates.ACTIVATED.value, QuantizationStates.PASSIVE.value):
                     for t in (cfg.scale, cfg.offset):
                         if isinstance(t, torch.Tensor) and t.is_floating_point(): t.requires_grad_(True)
-                    d = LSQDelegator(config=cfg, var=var)
+                    d = LSQDelegator(config=cfg, var=var, is_scale_trainable=self.is_scale_trainable)
                     tensors.extend(d.trainable_tensors())
                     executor.register_quantize_delegate(cfg, d)
                     delegators[cfg] = d
@@ -185,25 +195,57 @@ class LearnedStepSizePass:
         if not uniq:
             for cfg in delegators: executor.remove_quantize_delegate(cfg)
             return 0.0, 0.0
+        # parameters whose config carries no delegator (FP32 bias: this harness has no PassiveParameterQuantizePass,
+        # where the reference would hold a PASSIVE config + delegator backup) are trained too -- keep their own backup
+        covered = {id(d.var.value) for d in delegators.values() if d.is_parameter}
+        loose = [(t, t.detach().clone()) for t in uniq if id(t) not in covered
+                 and not any(t is c.scale or t is c.offset for c in delegators)]
         opt = torch.optim.Adam(uniq, lr=self.lr) if self.optimizer is None else self.optimizer(uniq, lr=self.lr)
+        names = [v.name for v in block.ep.outputs]
         for step in range(self.steps):
-            b, f = batches[step % len(batches)], fp_outputs[step % len(batches)]
+            qt_input, fp_output = qt_inputs[step % len(qt_inputs)], fp_outputs[step % len(qt_inputs)]
             opt.zero_grad()
-            out = executor.forward_with_gradient(b)[0]
-            loss = self._loss(out, f)
-            if self.gamma:
-                for op in ops:
-                    if op.type in {'Conv', 'Gemm'}:
-                        w, wc = op.inputs[1].value, op.config.input_quantization_config[1]
-                        loss = loss + self._loss(w, PPQuantFunction(w, wc).detach()) * self.gamma
+            with torch.enable_grad():
+                outs = executor.partial_graph_forward(block.rps, qt_input, names)
+                loss = sum(self._loss(y, fp_output[n]) for n, y in zip(names, outs))
+                if self.gamma:
+                    for op in block.rps:
+                        if hasattr(op, 'config') and op.type in {'Conv', 'Gemm', 'ConvTranspose', 'MatMul'}:
+                            w, wc = op.inputs[1].value, op.config.input_quantization_config[1]
+                            loss = loss + self._loss(w, PPQuantFunction(w, wc).detach()) * self.gamma
             loss.backward()
             with torch.no_grad():
                 self._average([t.grad for t in uniq if t.grad is not None])
             opt.step()
-        post_loss = block_loss()
+        post_loss = self._block_loss(block, qt_inputs, fp_outputs, executor)
         for cfg, d in delegators.items():
             if post_loss > pre_loss: d.withdraw()
             d.finalize()
             executor.remove_quantize_delegate(cfg)
-        for t in uniq: t.requires_grad_(False)
+        if post_loss > pre_loss:
+            with torch.no_grad():
+                for t, backup in loose: t.copy_(backup)
+        for t in uniq:
+            t.requires_grad_(False); t.grad = None
         return pre_loss, post_loss
+
+    def optimize(self, graph, dataloader, executor, collate_fn=None, **kwargs):
+        from .blocks import TrainableBlock, collect, split_graph_into_blocks
+        batches = [collate_fn(b) if collate_fn is not None else b for b in dataloader]
+        if self.block_size is None:
+            ops = graph.topological_sort()
+            blocks = [TrainableBlock(sp=ops[0], ep=ops[-1], rps=ops)]
+        else:
+            blocks = split_graph_into_blocks(graph, graph.topological_sort(), self.block_size,
+                                             interested_layers=self.interested_layers)
+        self.report = []
+        initial = None
+        if self.fp_reference == 'initial':
+            from .blocks import collect_fp_outputs
+            initial = collect_fp_outputs(graph, blocks, executor, batches)
+        for k, block in enumerate(blocks):
+            qt_inputs, fp_outputs = collect(graph, block, executor, batches, fp_outputs=None if initial is None else initial[k])
+            pre_loss, post_loss = self.finetune(block, executor, qt_inputs, fp_outputs)
+            self.report.append((str(block), pre_loss, post_loss))
+        if not self.report: return 0.0, 0.0
+        return sum(r[1] for r in self.report), sum(min(r[1], r[2]) for r in self.report)

@@ -574,6 +574,77 @@ class TorchMSEObserver(TorchHistObserver):
         return minmax_to_scale_offset(range_min, range_max, config, scale_threshold)
 
 
+class ChannelwiseMSEObserver(TorchMSEObserver):
+    """SURVEY section 8f-4 -- a capability the reference lacks (TorchMSEObserver raises on PER_CHANNEL configs,
+    range.py:496-497): the two-phase histogram MSE calibration PER CHANNEL, symmetrical or asymmetrical.
+    Phase 1 = per-channel min/max (MinMax_C); phase 2 = one histogram per channel binned with that channel's
+    own range (Histogram_C_Scales / Histogram_Asymmetric_C_Ranges); render = ONE batched MseSearch launch over
+    the [C, bins] histograms, then the reference's minmax_to_scale_offset channel by channel.  By
+    construction channel c gets exactly the (scale, offset) the per-tensor 'mse' observer renders for the slice
+    of channel c.  Registered as 'mse_channel'."""
+    def __init__(self, watch_on, quant_cfg, bins: int = OBSERVER_MSE_HIST_BINS):
+        super().__init__(watch_on, quant_cfg, bins)
+        if not quant_cfg.policy.has_property(P.PER_CHANNEL):
+            raise TypeError('ChannelwiseMSEObserver needs a per-channel config.')
+        self._mins_dev = self._maxs_dev = self._scales_dev = None
+
+    def observe(self, value: torch.Tensor):
+        if not is_initial(self._quant_cfg): return
+        assert value.numel() > 0, (f'You are observing an empty tensor({getattr(self._watch_on, "name", "")}).')
+        if self._phase == 'Detecting Minmax':
+            return TorchMinMaxObserver.observe(self, value)
+        cfg = self._quant_cfg
+        C = value.shape[cfg.channel_axis]
+        if self._hist is None:
+            self._hist = torch.zeros(size=(C, self._hist_bins), dtype=torch.int32, device=value.device)
+        if cfg.policy.has_property(P.ASYMMETRICAL):
+            CUDA.Histogram_Asymmetric_C_Ranges(value, cfg.channel_axis, self._hist, self._mins_dev, self._maxs_dev)
+        else:
+            CUDA.Histogram_C_Scales(value, cfg.channel_axis, self._hist, self._scales_dev)
+
+    def histogram(self): return self._hist
+
+    def reducible(self):
+        if self._phase == 'Detecting Minmax': return TorchMinMaxObserver.reducible(self)
+        return [(self._hist, 'sum')] if self._hist is not None else []
+
+    def render_quantization_config(self):
+        cfg = self._quant_cfg
+        if not is_initial(cfg): return
+        sym = cfg.policy.has_property(P.SYMMETRICAL)
+        if self._phase == 'Detecting Minmax':
+            r = self._range_on_host()                                      # [2, C]
+            self._min = [float(v) for v in r[0]]
+            self._max = [float(v) for v in r[1]]
+            # range.py:294-301, channel by channel
+            self._hist_scale = [(float(max(abs(hi), abs(lo))) if sym else (hi - lo)) / self._hist_bins
+                                for lo, hi in zip(self._min, self._max)]
+            dev = self._range.device
+            self._mins_dev = torch.tensor(self._min, dtype=torch.float32, device=dev)
+            self._maxs_dev = torch.tensor(self._max, dtype=torch.float32, device=dev)
+            self._scales_dev = torch.tensor(self._hist_scale, dtype=torch.float32, device=dev)
+            self._phase = 'Collating Hist'
+            return
+        if self._hist is None:
+            raise ValueError('Can not render quantization config yet, histogram is empty. '
+                             'Invoke observe() function before render config.')
+        dev = self._hist.device
+        best = CUDA.MseSearch(self._hist, torch.tensor(self._hist_scale, dtype=torch.float64, device=dev),
+                              torch.tensor(self._min, dtype=torch.float64, device=dev), cfg.quant_min, cfg.quant_max,
+                              sym).cpu().numpy()                          # [C, 4]: one launch, one D2H
+        scale_threshold = cfg.detail.get(OBSERVER_MIN_SCALE_MANUL_OVERRIDE, OBSERVER_MIN_SCALE)
+        scales, offsets = [], []
+        for c in range(self._hist.shape[0]):
+            start, end, hs = int(best[c][0]), int(best[c][1]), self._hist_scale[c]
+            if sym: range_min, range_max = -(end * hs), (end * hs)                          # range.py:512-516
+            else: range_min, range_max = (start * hs) + self._min[c], (end * hs) + self._min[c]
+            s_, o_ = minmax_to_scale_offset(range_min, range_max, cfg, scale_threshold)
+            scales.append(s_); offsets.append(o_)
+        cfg.scale = torch.tensor(scales, dtype=torch.float32, device=dev)
+        cfg.offset = torch.tensor(offsets, dtype=torch.float32, device=dev)
+        set_activated(cfg)
+
+
 class ConstantObserver(BaseTensorObserver):
     """observer/floating.py:11-48: scale 1, offset 0."""
     def __init__(self, watch_on, quant_cfg):
@@ -687,6 +758,7 @@ OBSERVER_TABLE = {
     'kl_channel': ChannelwiseKLObserver,       # extension, not in the reference's table
     'percentile': TorchPercentileObserver,
     'mse': TorchMSEObserver,
+    'mse_channel': ChannelwiseMSEObserver,     # extension, not in the reference's table
     'constant': ConstantObserver,
     'floating': DirectMSEObserver,
 }

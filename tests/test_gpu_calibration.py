@@ -577,8 +577,12 @@ def test_bias_correction_pass():
         assert torch.equal(got_err, torch.zeros_like(got_err))
     # every config is back in its quantised state
     assert all(not getattr(op, '_dequantized', False) for op in graph.operations.values())
-    with pytest.raises(NotImplementedError):
-        BiasCorrectionPass(block_size=4)
+    # larger blocks (training.py:191-315): conv + relu chains become one block, the pass still never makes a block worse
+    graph, ex = build()
+    RuntimeCalibrationPass().optimize(graph, dataloader=batches, executor=ex, calib_steps=8)
+    p4 = BiasCorrectionPass(steps=8, block_size=4)
+    p4.optimize(graph, dataloader=batches, executor=ex)
+    assert 1 <= len(p4.report) <= len(bias_before) and all(post <= pre for _, pre, post in p4.report)
 
 
 def test_multi_tensor_launches_equal_single(CUDA):
@@ -1053,7 +1057,7 @@ def test_bench_two_ranks_on_one_gpu():
     the checksum equals a 1-rank run over the same 2 x K batches... which needs the same seeds, so here
     only the contract is checked: n_gpus, merge records, value = all ranks' samples / max time."""
     small = ['--steps', '2', '--warmup', '1', '--batch', '4', '--repeats', '1', '--no-cpu-baseline', '--no-cpu-ops',
-             '--pmc', '0', '--settle-ms', '0']
+             '--pmc', '0', '--settle-ms', '0', '--variants', '0']
     out = _run_bench('--gpus', '2', '--backend', 'gloo', '--single-device', '1', *small)
     assert out['n_gpus'] == 2 and out['config']['rccl_ranks'] == 2 and out['config']['samples'] == 2 * 2 * 4
     merge = out['config']['merge']
@@ -1065,3 +1069,109 @@ def test_bench_two_ranks_on_one_gpu():
     for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
                 'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert key in one
+
+
+@pytest.mark.parametrize('sym', [True, False])
+def test_channelwise_mse_observer_equals_per_tensor_mse_on_each_channel(CUDA, sym):
+    """SURVEY 8f-4 extension: 'mse_channel' (per-channel two-phase histogram MSE; the reference's 'mse' raises on
+    PER_CHANNEL, range.py:496-497) gives every channel exactly the (scale, offset) the per-tensor 'mse' observer
+    renders on that channel's slice; Histogram_Asymmetric_C_Ranges == Histogram_Asymmetric_T per slice."""
+    from ppq_amd.observer import TensorObserverFactroy, OBSERVER_TABLE, ChannelwiseMSEObserver
+    assert OBSERVER_TABLE['mse_channel'] is ChannelwiseMSEObserver
+    g = torch.Generator().manual_seed(61)
+    C = 5
+    data = [(torch.randn(3, C, 40, 30, generator=g) * torch.arange(1, C + 1).view(1, C, 1, 1) * (1 + 0.1 * i) + 0.3 * i) for i in range(4)]
+    data = [torch.relu(d) if i % 2 else d for i, d in enumerate(data)]
+    # kernel level: long rows (LDS path), short rows / axis 0 / axis last (global path), clipped and clamped
+    for shape, axis in (((3, C, 40, 30), 1), ((5, 7, 9), 1), ((4, 3), 0), ((2, 3, 2000), 1), ((6, 50, 4), 2)):
+        x = torch.randn(*shape, generator=g) * 2
+        Cx = shape[axis]
+        lo = torch.tensor([float(x.select(axis, c).min()) * 0.9 for c in range(Cx)])
+        hi = torch.tensor([float(x.select(axis, c).max()) * 0.9 for c in range(Cx)])
+        for clip in (True, False):
+            h = torch.zeros(Cx, 256, dtype=torch.int32, device=DEV)
+            CUDA.Histogram_Asymmetric_C_Ranges(x.to(DEV), axis, h, lo.to(DEV), hi.to(DEV), clip_outliers=clip)
+            for c in range(Cx):
+                sl = x.select(axis, c).contiguous().numpy()
+                want = O.hist_asym_t(sl, float(lo[c]), float(hi[c]), np.zeros(256, np.int32), clip)
+                assert np.array_equal(h[c].cpu().numpy(), want), (shape, axis, c, clip)
+    # observer level
+    cfg = _cfg('mse_channel', sym=sym, per_channel_axis=1)
+    ob = TensorObserverFactroy.build_observer('x', cfg)
+    for _ in range(2):
+        for d in data: ob.observe(d.to(DEV))
+        ob.render_quantization_config()
+    assert cfg.state.value == 4 and cfg.scale.shape == (C,) and cfg.offset.shape == (C,)
+    for c in range(C):
+        ref_cfg = _cfg('mse', sym=sym)
+        ref = TensorObserverFactroy.build_observer('x', ref_cfg)
+        for _ in range(2):
+            for d in data: ref.observe(d[:, c].contiguous().to(DEV))
+            ref.render_quantization_config()
+        assert float(ref_cfg.scale) == float(cfg.scale[c]) and float(ref_cfg.offset) == float(cfg.offset[c]), c
+    with pytest.raises((ValueError, PermissionError)):                       # the reference's 'mse' still refuses per-channel (range.py:288-289, 496-497)
+        bad = _cfg('mse', sym=sym, per_channel_axis=1)
+        ob = TensorObserverFactroy.build_observer('x', bad)
+        for _ in range(2):
+            for d in data[:1]: ob.observe(d.to(DEV))
+            ob.render_quantization_config()
+
+
+def test_yolov6s_int4_blockwise_lsq_and_bias_correction():
+    """BASELINE config 5 on the YOLOv6-s-like detector (56 convolutions, 17 M parameters, 6 outputs): INT4
+    per-channel weights + INT8 activations, calibrated, then BiasCorrectionPass (block_size 1) and the
+    block-wise LearnedStepSizePass (block_size 5: 27 TrainableBlocks incl. the SPPF fan-out that closes at its
+    Concat) through the HIP forward / LSQ-backward kernels.  No block may end worse than it started, the
+    finetune must cut the summed block loss, and the error at the graph outputs must drop."""
+    from ppq_amd import harness
+    from ppq_amd.bias_correction import BiasCorrectionPass
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    from ppq_amd.lsq import LearnedStepSizePass
+    graph = harness.yolov6s_graph(seed=3)
+    harness.quantize_graph(graph, 'minmax')
+    for op in graph.operations.values():                        # weights -> int4 [-8, 7]
+        for cfg, var in op.config_with_variable:
+            if var.is_parameter and cfg.state.value == 1:
+                cfg.num_of_bits, cfg.quant_min, cfg.quant_max = 4, -8, 7
+    ex = harness.TorchExecutor(graph, DEV)
+    harness.ParameterQuantizePass().optimize(graph)
+    g = torch.Generator().manual_seed(9)
+    batches = [torch.rand(2, 3, 160, 160, generator=g).to(DEV) for _ in range(8)]
+    RuntimeCalibrationPass().optimize(graph, dataloader=batches, executor=ex, calib_steps=8)
+    outs = list(graph.outputs)
+
+    def output_error():
+        quantable = [o for o in graph.operations.values() if hasattr(o, 'config')]
+        for o in quantable: o.dequantize()
+        fp = [ex.forward(b, outs) for b in batches[:4]]
+        for o in quantable: o.restore_quantize_state()
+        qt = [ex.forward(b, outs) for b in batches[:4]]
+        num = sum(float(torch.sum((q - f) ** 2)) for fs, qs in zip(fp, qt) for f, q in zip(fs, qs))
+        den = sum(float(torch.sum(f ** 2)) for fs in fp for f in fs)
+        return num / den
+    err0 = output_error()
+    bc = BiasCorrectionPass(steps=8, block_size=1)
+    bc.optimize(graph, dataloader=batches, executor=ex)
+    assert len(bc.report) == 56 and all(post <= pre for _, pre, post in bc.report)
+    err1 = output_error()
+    # FP32 targets collected once from the original weights (fp_reference='initial'): end-to-end error must drop
+    quantable = [o for o in graph.operations.values() if hasattr(o, 'config')]
+    for o in quantable: o.dequantize()
+    fp_ref = [ex.forward(b, outs) for b in batches[:4]]                    # the ORIGINAL network's outputs
+    for o in quantable: o.restore_quantize_state()
+
+    def error_vs_original():
+        qt = [ex.forward(b, outs) for b in batches[:4]]
+        num = sum(float(torch.sum((q - f) ** 2)) for fs, qs in zip(fp_ref, qt) for f, q in zip(fs, qs))
+        return num / sum(float(torch.sum(f ** 2)) for fs in fp_ref for f in fs)
+    e_before = error_vs_original()
+    lsq = LearnedStepSizePass(steps=40, lr=1e-4, block_size=5, fp_reference='initial')
+    pre, post = lsq.optimize(graph, batches, ex)
+    assert len(lsq.report) == 27
+    assert post < 0.8 * pre, (pre, post)
+    improved = sum(1 for _, a, b in lsq.report if b < 0.9 * a)
+    assert improved >= 20, [(n, round(a, 4), round(b, 4)) for n, a, b in lsq.report]
+    e_after = error_vs_original()
+    assert e_after < 0.8 * e_before, (err0, err1, e_before, e_after)
+    assert all(torch.isfinite(v.value).all() for v in graph.variables.values() if v.is_parameter)
+    assert not ex._delegates

@@ -401,3 +401,49 @@ def _mismatch_worker(rank, world, port, q):
         msg = str(e)
     q.put((rank, msg))
     dist.destroy_process_group()
+
+
+def test_block_builder_blocks_satisfy_the_reference_definition():
+    """ppq_amd/blocks.py against the DEFINITION of a TrainableBlock (training.py:229-242), checked by brute
+    force on the YOLOv6-s-like and ResNet-50 topologies: M holds exactly the operations on paths S -> E, no
+    value enters M except through S, none leaves except through E, depth(E) - depth(S) <= limit; computing
+    ops are covered exactly once; known shapes: a Conv-Relu chain, the SPPF fan-out closing at its Concat,
+    a residual branch that cannot extend past the Add."""
+    from ppq_amd import harness
+    from ppq_amd.blocks import BlockBuilder, downstream_operations, split_graph_into_blocks, upstream_operations
+    for build, limit in ((harness.yolov6s_graph, 5), (harness.yolov6s_graph, 1), (harness.resnet50_graph, 4), (harness.small_cnn_graph, 3)):
+        g = build(seed=0)
+        harness.quantize_graph(g, 'minmax')
+        blocks = split_graph_into_blocks(g, None, limit)
+        builder = BlockBuilder(g)
+        covered = [o.name for b in blocks for o in b.rps]
+        assert len(covered) == len(set(covered))
+        computing = [o.name for o in g.operations.values() if o.type in ('Conv', 'Gemm')]
+        assert all(c in covered for c in computing)
+        for b in blocks:
+            names = {o.name for o in b.rps}
+            assert b.rps[0] is b.sp and b.rps[-1] is b.ep
+            assert builder.depth[b.ep.name] - builder.depth[b.sp.name] <= limit
+            # forward reachability from S restricted to ops that reach E == M
+            def reach(start, step):
+                seen, todo = {start.name}, [start]
+                while todo:
+                    for nxt in step(todo.pop()):
+                        if nxt.name not in seen: seen.add(nxt.name); todo.append(nxt)
+                return seen
+            on_paths = reach(b.sp, downstream_operations) & reach(b.ep, upstream_operations)
+            assert on_paths == names, (str(b), sorted(on_paths ^ names))
+            for o in b.rps:
+                if o is not b.sp:
+                    assert all(u.name in names for u in upstream_operations(o))
+                    assert not any((not v.is_parameter) and v.source_op is None for v in o.inputs)
+                if o is not b.ep:
+                    assert all(d.name in names for d in downstream_operations(o))
+                    assert not any(v.name in g.outputs for v in o.outputs)
+    g = harness.yolov6s_graph(seed=0); harness.quantize_graph(g, 'minmax')
+    by_sp = {b.sp.name: b for b in split_graph_into_blocks(g, None, 5)}
+    assert [o.type for o in by_sp['stem1'].rps] == ['Conv', 'Relu'] * 3
+    assert by_sp['sppf_in20'].ep.name == 'sppf_cat' and len(by_sp['sppf_in20'].rps) == 6
+    g = harness.resnet50_graph(seed=0); harness.quantize_graph(g, 'minmax')
+    by_sp = {b.sp.name: b for b in split_graph_into_blocks(g, None, 4)}
+    assert len(by_sp['down5'].rps) == 1 and by_sp['conv2'].ep.name == 'conv4'

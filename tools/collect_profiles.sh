@@ -1,7 +1,6 @@
 #!/bin/bash
 # Runs ON THE GPU BOX (through gpurun): everything the numbers in DESIGN.md / profiles/ come from.
 #   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh'
-# then locally:  python tools/summarize_profile.py gpurun_out/final profiles/r01_bench
 # PMC counters are collected in their own passes with --kernel-trace only (no sys/hip/hsa tracing).
 set -u
 export TMPDIR=/tmp
@@ -9,22 +8,20 @@ R=$PWD
 O=$R/gpurun_out/final
 rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
-B="python $R/bench.py --no-cpu-baseline"
+B="python $R/bench.py --no-cpu-baseline --no-cpu-ops --pmc 0 --variants 0"
 cd /tmp
-rocprofv3 --output-format csv --kernel-trace --stats -d $O/trace -o bench -- $B > $O/bench_trace.log 2>&1
-rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $O/fetch -o bench -- $B > /dev/null 2>&1
-rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $O/write -o bench -- $B > /dev/null 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/trace -o bench -- $B > $O/bench_traced.json 2>/dev/null
 cd $R
-python tools/microbench.py --tensors A,B,Bx8,Bx32 --rotate 4 > $O/microbench_randn_rot4.txt 2>&1
-python tools/microbench.py --tensors B,Bx32 --rotate 4 --relu > $O/microbench_relu_rot4.txt 2>&1
-python tools/microbench.py --tensors A,B --rotate 1 > $O/microbench_randn_cached.txt 2>&1
+python tools/microbench.py --tensors A,B,Bx32 > $O/microbench_randn.txt 2>&1
+python tools/microbench.py --tensors B,Bx32 --relu --only hist,minmax,quantile > $O/microbench_relu.txt 2>&1
 python tools/multi_bench.py > $O/multi_bench.txt 2>&1
-for b in 1 8; do python bench.py --no-cpu-baseline --batch $b --steps $((256 / b)) > $O/bench_batch$b.json 2>/dev/null; done
+for b in 1 8; do python bench.py --no-cpu-baseline --no-cpu-ops --pmc 0 --variants 0 --batch $b --steps $((256 / b)) > $O/bench_batch$b.json 2>/dev/null; done
 cd /tmp
-rocprofv3 --output-format csv --kernel-trace --stats -d $O/micro_trace -o micro -- python $R/tools/microbench.py --tensors B,Bx32 --rotate 4 > /dev/null 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $O/micro_trace -o micro -- python $R/tools/microbench.py --tensors B,Bx32 > /dev/null 2>&1
 cd $R
 # keep the merge-back small: only the CSV summaries
 find $O -name "*.db" -delete 2>/dev/null
 find $O -name "*_agent_info.csv" -delete 2>/dev/null
+find $O -name "*kernel_trace.csv" -delete 2>/dev/null
 du -sh $O
-tail -1 $O/bench.json
+tail -1 $O/bench.json | cut -c1-600
