@@ -89,11 +89,12 @@ def main():
     bins = 2048
     out = {}
     # ---- (1) in situ
-    xs, hs = capture_insitu()
+    if os.environ.get('HV_SKIP_INSITU'): xs, hs = [], []
+    else: xs, hs = capture_insitu()
     total = sum(x.numel() for x in xs) * 4
     print(f'in-situ set: {len(xs)} tensors, {total/1e9:.3f} GB', flush=True)
     ref_hists = None
-    for lib in libs:
+    for lib in (libs if xs else []):
         rows = [torch.zeros(lib.R, bins, dtype=torch.int32, device='cuda') for _ in xs]
         jobs = np.empty(len(xs), dtype=HIST_JOB)
         jobs['x'] = [x.data_ptr() for x in xs]; jobs['rows'] = [r.data_ptr() for r in rows]
@@ -115,7 +116,8 @@ def main():
     torch.cuda.empty_cache()
     # ---- (2) single tensors
     torch.manual_seed(0)
-    shapes = {'A': (1, 3, 224, 224), 'B': (1, 512, 56, 56), 'Bx32': (32, 512, 56, 56)}
+    shapes = {'A': (1, 3, 224, 224), 'B': (1, 512, 56, 56), 'Bx4': (4, 512, 56, 56), 'Bx32': (32, 512, 56, 56)}
+    if os.environ.get('HV_TENSORS'): shapes = {k: v for k, v in shapes.items() if k in os.environ['HV_TENSORS'].split(',')}
     for tname, shp in shapes.items():
         for dist in ('randn', 'relu'):
             rot = 4 if tname == 'Bx32' else 1
