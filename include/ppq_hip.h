@@ -148,21 +148,23 @@ int ppqhip_hist_asym_c_ranges(const float* x, int64_t n, int64_t num_channel, in
 
 /* order statistics ---------------------------------------------------------------------------- */
 /* replaces Quantile_T, sort.cu:42-59 (CUDA.Quantile ffi.py:171-176): dest[0] = sorted[rn(n*q)],
- * dest[1] = sorted[rn(n*(1-q))], indices clamped to [0, n-1].  Implemented as a radix select, not
- * a sort.  `workspace` is device scratch of ppqhip_quantile_workspace_bytes(n) bytes. */
+ * dest[1] = sorted[rn(n*(1-q))], indices clamped to [0, n-1].  Implemented as a sample-guided radix
+ * select that reads the tensor once in the usual case (never a sort, never a copy of the data).
+ * `workspace` is device scratch of ppqhip_quantile_workspace_bytes(n) bytes. */
 int64_t ppqhip_quantile_workspace_bytes(int64_t n);
 int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, void* workspace,
                       void* stream);
 
 /* many tensors, one launch per pass: dest_k[0..1] = (q, 1-q) order statistics of job k exactly as
  * ppqhip_quantile_t.  `jobs` is a HOST array (copied into the kernel arguments); workspace holds
- * ppqhip_quantile_multi_workspace_bytes(num_jobs) bytes. */
+ * ppqhip_quantile_multi_workspace_bytes(num_jobs, total_elems) bytes, total_elems = the sum of the
+ * jobs' n (the speculative key lists are sized n / 128 per job and side, 4096 keys at least). */
 typedef struct ppqhip_quantile_job {
     const float* x;   /* device, n floats */
     float* dest;      /* device, 2 floats */
     int64_t n;
 } ppqhip_quantile_job;
-int64_t ppqhip_quantile_multi_workspace_bytes(int num_jobs);
+int64_t ppqhip_quantile_multi_workspace_bytes(int num_jobs, int64_t total_elems);
 int ppqhip_quantile_t_multi(const ppqhip_quantile_job* jobs, int num_jobs, float q, void* workspace,
                             void* stream);
 

@@ -52,9 +52,6 @@ constexpr int kMaxLdsBins = 16384;     // 64 KiB of int32 per copy at most
 #define PPQHIP_HIST_ATOMIC_MAX_WG 128  // one-shot entry points: flush with device atomics up to this grid (B = [1,512,56,56]:
                                        // ONE launch of 7.4 us instead of 8.3 us + a 4.0 us reduce launch; rocprofv3 durations)
 #endif
-#ifndef PPQHIP_HIST_ASM
-#define PPQHIP_HIST_ASM 1              // EXEC-mask commits in inline assembly (Binner::commit4_exec); 0 = compiler-generated
-#endif
 #ifndef PPQHIP_HIST_NT_ELEMS
 #define PPQHIP_HIST_NT_ELEMS (48ll << 20)   // streaming (nontemporal) loads beyond cache residency
 #endif
@@ -65,7 +62,6 @@ constexpr int kHistU = PPQHIP_HIST_U;                  // float4 loads in flight
 constexpr int kHistRows = kNumCU * kHistWgPerCu;       // grid limit == rows of a persistent accumulator
 constexpr uint32_t kTileVec = (uint32_t)kHistBlock * kHistU;   // float4 per tile
 constexpr uint32_t kTileElems = kTileVec * 4;
-constexpr int kHotMin = 12;            // lanes that must share the candidate bin to make it hot
 static_assert(kHistBlock % 64 == 0 && kHistBlock >= 64 && kHistBlock <= 1024, "histogram workgroup: whole waves");
 
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -112,14 +108,11 @@ __device__ __forceinline__ int f2i_floor(float t) {
 // Per-wavefront accumulator over one LDS histogram copy.  ASYM / CLIP specialise the bin rule, HOT
 // enables the hot-bin register.
 template <bool ASYM, bool CLIP, bool HOT>
-struct Binner {
-    int* h;
+struct Binner : WaveBinCounter<ASYM, CLIP, HOT> {
+    using Base = WaveBinCounter<ASYM, CLIP, HOT>;
+    using Base::h; using Base::last; using Base::hot_bin; using Base::hot_cnt;
     float a0, hs, rcp;
-    int last;        // bins - 1
-    int hot_bin;     // wave-uniform, -1 = none
-    int hot_cnt;     // wave-uniform: hits are counted with ballot + s_bcnt1 (no VALU)
 
-    __device__ __forceinline__ void init(int* copy, int bins) { h = copy; last = bins - 1; hot_bin = -1; hot_cnt = 0; }
     __device__ __forceinline__ void set_rule(float a, float scale) { a0 = a; hs = scale; rcp = 1.0f / scale; }
 
     // slots of four values.  Returns bins with the reference's conversion semantics; `exact` lanes
@@ -157,103 +150,6 @@ struct Binner {
         return exact_bin(a);
     }
 
-    // population count of a lane mask as a 32-bit SCALAR (two s_bcnt1_i32_b32: a 64-bit count would be
-    // compared / selected on the vector unit, which drags hot_bin / hot_cnt into VGPRs)
-    static __device__ __forceinline__ int popc_mask(unsigned long long m) {
-        return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32));
-    }
-
-    // count one value in bin b (as produced by bins4 / bin1); `in` = the value exists.
-    template <bool IN_ALWAYS>
-    __device__ __forceinline__ void commit(int b, bool in) {
-        bool ok = IN_ALWAYS ? true : in;
-        if (CLIP) ok = ok && (unsigned)b <= (unsigned)last;            // b < 0 wraps above `last`
-        else b = ASYM ? (b < 0 ? 0 : (b > last ? last : b)) : (b > last ? last : b);
-        if (HOT) {
-            const bool hit = b == hot_bin;
-            // wave-uniform count on the scalar unit: s_and + s_bcnt1 + s_add, no VALU
-            hot_cnt += popc_mask(__builtin_amdgcn_ballot_w64(ok) & __builtin_amdgcn_ballot_w64(hit));
-            if (ok && !hit) atomicAdd(&h[b], 1);
-        } else {
-            if (ok) atomicAdd(&h[b], 1);
-        }
-    }
-
-    // Four full-wave commits (CLIP && HOT, every lane holds a value) with the EXEC mask doing the
-    // predication: per element v_cmpx (b <= last narrows EXEC), v_cmp (hot hits -> VCC, counted with
-    // s_bcnt1 on the scalar unit and removed from EXEC), v_lshl_add (LDS address), ds_add_u32 --
-    // 3 VALU + 4 SALU instead of the ~6 + ~8 the compiler needs for the same logic through lane masks.
-    // Only SGPR / VCC / EXEC hand-offs that the hardware interlocks are used (VALU-written VCC is read by
-    // SALU only; EXEC is restored from an SGPR pair before control returns to compiled code).
-    __device__ __forceinline__ void commit4_exec(const int (&b)[4]) {
-#if PPQHIP_HIST_ASM
-        unsigned long long save;
-        int t0, a0r;
-        int cnt = __builtin_amdgcn_readfirstlane(hot_cnt);
-        const int hot = __builtin_amdgcn_readfirstlane(hot_bin), lastu = __builtin_amdgcn_readfirstlane(last);
-        const unsigned base = (unsigned)(uintptr_t)h;
-        asm volatile(
-            "s_mov_b64 %[sv], exec\n\t"
-            "v_cmpx_ge_u32_e32 vcc, %[last], %[b0]\n\t"
-            "v_cmp_eq_u32_e32 vcc, %[hot], %[b0]\n\t"
-            "s_bcnt1_i32_b64 %[t], vcc\n\t"
-            "s_andn2_b64 exec, exec, vcc\n\t"
-            "s_add_i32 %[cnt], %[cnt], %[t]\n\t"
-            "v_lshl_add_u32 %[a], %[b0], 2, %[base]\n\t"
-            "ds_add_u32 %[a], %[one]\n\t"
-            "s_mov_b64 exec, %[sv]\n\t"
-            "v_cmpx_ge_u32_e32 vcc, %[last], %[b1]\n\t"
-            "v_cmp_eq_u32_e32 vcc, %[hot], %[b1]\n\t"
-            "s_bcnt1_i32_b64 %[t], vcc\n\t"
-            "s_andn2_b64 exec, exec, vcc\n\t"
-            "s_add_i32 %[cnt], %[cnt], %[t]\n\t"
-            "v_lshl_add_u32 %[a], %[b1], 2, %[base]\n\t"
-            "ds_add_u32 %[a], %[one]\n\t"
-            "s_mov_b64 exec, %[sv]\n\t"
-            "v_cmpx_ge_u32_e32 vcc, %[last], %[b2]\n\t"
-            "v_cmp_eq_u32_e32 vcc, %[hot], %[b2]\n\t"
-            "s_bcnt1_i32_b64 %[t], vcc\n\t"
-            "s_andn2_b64 exec, exec, vcc\n\t"
-            "s_add_i32 %[cnt], %[cnt], %[t]\n\t"
-            "v_lshl_add_u32 %[a], %[b2], 2, %[base]\n\t"
-            "ds_add_u32 %[a], %[one]\n\t"
-            "s_mov_b64 exec, %[sv]\n\t"
-            "v_cmpx_ge_u32_e32 vcc, %[last], %[b3]\n\t"
-            "v_cmp_eq_u32_e32 vcc, %[hot], %[b3]\n\t"
-            "s_bcnt1_i32_b64 %[t], vcc\n\t"
-            "s_andn2_b64 exec, exec, vcc\n\t"
-            "s_add_i32 %[cnt], %[cnt], %[t]\n\t"
-            "v_lshl_add_u32 %[a], %[b3], 2, %[base]\n\t"
-            "ds_add_u32 %[a], %[one]\n\t"
-            "s_mov_b64 exec, %[sv]"
-            : [cnt] "+s"(cnt), [sv] "=&s"(save), [t] "=&s"(t0), [a] "=&v"(a0r)
-            : [last] "s"(lastu), [hot] "s"(hot), [b0] "v"(b[0]), [b1] "v"(b[1]), [b2] "v"(b[2]), [b3] "v"(b[3]),
-              [base] "v"(base), [one] "v"(1)
-            : "vcc", "scc", "memory");
-        hot_cnt = cnt;
-#else
-        commit<true>(b[0], true); commit<true>(b[1], true); commit<true>(b[2], true); commit<true>(b[3], true);
-#endif
-    }
-
-    __device__ __forceinline__ void flush_hot() {
-        if (!HOT) return;
-        if ((threadIdx.x & 63) == 0 && hot_cnt != 0 && hot_bin >= 0) atomicAdd(&h[hot_bin], hot_cnt);
-        hot_cnt = 0;
-    }
-
-    // Re-elect the hot bin from one bin per lane; all lanes of the wave call this together.  The bin of
-    // the first valid lane becomes hot when at least kHotMin lanes share it.
-    __device__ __forceinline__ void elect(int b, bool in) {
-        if (!HOT) return;
-        const bool valid = in && (unsigned)b <= (unsigned)last;
-        const unsigned long long act = __builtin_amdgcn_ballot_w64(valid);
-        if (act == 0ull) return;
-        const int cand = __builtin_amdgcn_readlane(b, __builtin_ctzll(act));
-        if (cand == hot_bin) return;
-        const int share = popc_mask(act & __builtin_amdgcn_ballot_w64(b == cand));
-        if (share >= kHotMin) { flush_hot(); hot_bin = cand; }
-    }
 };
 
 // column sums of partial[count][bins] into hist.  grid = (ceil(bins / 256), slices): each thread

@@ -318,6 +318,11 @@ __device__ __forceinline__ uint32_t f2key(float f) {
 __device__ __forceinline__ float key2f(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
+    return v;
+}
 
 // workspace layout PER JOB (uint32 words)
 constexpr int kQ1 = 4096, kQ2 = 4096, kQ3 = 256;
@@ -336,7 +341,31 @@ enum { kSTop = 0,     // 12-bit prefix of the bucket that holds the rank
        kSR24 = 7 };
 enum { kModeHist = 0, kModeCompact = 1, kModeDone = 2 };
 constexpr int kOffCand = kOffSel + 16;      // cand[2][kQCap]: full keys of the bucket's elements
-constexpr int kQWords = kOffCand + 2 * (int)kQCap;
+constexpr int kOffH0 = kOffCand + 2 * (int)kQCap;   // hist0[4096]: key >> 20 of the SAMPLE (speculation, see below)
+constexpr int kOffR0 = kOffH0 + kQ1;        // round0[4096]: those of them that ARE their bucket's round key (0, 6.0, -1.0 ..)
+constexpr int kOffSpec = kOffR0 + kQ1;      // spec[16]: thresholds + counters of the speculative lists
+enum { kPEnabled = 0,  // 1 once select0 has chosen thresholds
+       kPTHi = 1,      // keys > T_hi are appended to the hi list (0xFFFFFFFF: none)
+       kPTLo = 2,      // keys < T_lo are appended to the lo list (0: none);  T_lo <= T_hi
+       kPCntHi = 3, kPCntLo = 4,          // keys appended (may exceed the capacity: then the list is unusable)
+       kPTieHi = 5, kPTieLo = 6,          // LOWER BOUNDS of the number of keys == T_hi / == T_lo (one element in eight is looked at)
+       kPOvfHi = 9, kPOvfLo = 10 };       // some workgroup met more matching keys than it can stage: list incomplete
+constexpr int kQWords = kOffSpec + 16;
+// the key of the smallest-magnitude value of bucket b (3 mantissa bits): the values activations TIE on -- 0 after a ReLU, 6.0
+// after a ReLU6 / clip, +-1 after a saturating function -- are of this form
+__host__ __device__ inline uint32_t round_key_of_bucket(uint32_t b) { return b >= 0x800u ? (b << 20) : ((b << 20) | 0xFFFFFu); }
+// capacity (keys per side) of a job's speculative lists; they live behind the fixed parts of all jobs
+__host__ __device__ inline uint32_t quantile_spec_cap(uint64_t n) {
+    uint64_t c = n / 128;
+    if (c < 4096) c = 4096;
+    if (c > (1u << 20)) c = 1u << 20;
+    return (uint32_t)((c + 3) & ~3ull);             // lists stay 16-B aligned
+}
+constexpr uint32_t kQSampleVec = 256;       // float4 sampled at the head of every workgroup's chunk (one per lane)
+#ifndef PPQHIP_Q_SPEC_MIN_ELEMS
+#define PPQHIP_Q_SPEC_MIN_ELEMS (1ll << 18)
+#endif
+constexpr int64_t kQSpeculateMinElems = PPQHIP_Q_SPEC_MIN_ELEMS;   // smaller launches skip the speculation (two launches saved)
 
 // find the bin of `hist[0..nbins)` that holds rank k (0-based) and the rank inside it.
 // All threads of the workgroup call this (blockDim.x == 256, nbins in {256, 4096}); thread t owns
@@ -384,51 +413,310 @@ constexpr int kQTrash = 64;
 
 // Radix select of two order statistics without sorting or moving data (replaces the clone + full
 // thrust::sort of Quantile_T, sort.cu:42-59), for MANY tensors per launch:
-//   pass 1   (all data)   histogram of the top 12 key bits
-//   select A (1 wg/job)   bucket + rank of both targets; a bucket of <= kQCap elements is COMPACTED
-//   pass 2   (all data)   COMPACT: append the bucket's keys to a candidate list (a few thousand global
-//                         atomics); else histogram of the middle 12 bits + min / max key of the bucket
-//   select B (1 wg/job)   COMPACT: finish on the candidate list in LDS -> done.  Else: all keys equal
-//                         (ReLU zeros, saturated values) -> done; otherwise 24-bit prefix for pass 3
-//   pass 3   (all data)   only for sides still open (workgroups of finished jobs return at once)
-//   pick     (1 wg/job)   last 8 bits
-// Typical activations (0.9999 quantile: a few thousand elements in the selected bucket; the low side of
-// a ReLU output: all zeros) finish after TWO passes over the data instead of three.
+//   pass 1   (all data)      histogram of the top 12 key bits (persistent kernel, below)
+//   select A (1 wg/job/side) bucket + rank of the target; a bucket of <= kQCap elements is COMPACTED
+//   pass 2   (all data)      COMPACT: append the bucket's keys to a candidate list (a few thousand global
+//                            atomics); else histogram of the middle 12 bits + min / max key of the bucket
+//   select B (1 wg/job)      COMPACT: finish on the candidate list in LDS -> done.  Else: all keys equal
+//                            (saturated values) -> done; otherwise 24-bit prefix for pass 3
+//   pass 3   (all data)      only for sides still open (workgroups of finished jobs return at once)
+//   pick     (1 wg/job)      last 8 bits
+// (Folding the single-workgroup steps into the tail of the pass before them -- "last block done" -- was tried: the
+// agent-scope release / acquire it needs is an L2 write-back + invalidate per workgroup on this 8-XCD part, and the
+// sample launch went from 10 to 77 us.  Launch boundaries are the cheaper fence.)
+//
+// Speculation (round 2): for the extreme order statistics calibration asks for (q = 0.9999) the answer lies among a
+// few thousand elements, and reading the whole tensor again just to look at them is what kept this kernel at
+// ~0.5 passes^-1 of the roofline.  A SAMPLE launch (1 KB-element heads of the workgroup chunks, ~1 % of the data)
+// histograms the top 12 key bits, and how many of each bucket's keys are the bucket's round key; select0
+// picks KEY thresholds T_hi / T_lo such that ~1.3-2x the wanted number of elements lies beyond them; pass 1
+// then, while building the exact histogram, STAGES every key beyond a threshold for a list (one compare per float4 in
+// the streaming loop, ~0.03 % of the elements take the branch) and counts a lower bound of the keys EQUAL to a
+// threshold (ties: ReLU zeros, ReLU6 sixes).  Select A finds the wanted rank in the list or proves it is the tied
+// threshold value; only if neither holds (unlucky sample, overflow, ties on an odd value) passes 2 / 3 run as before.
+// The result is exact either way; in the usual case the tensor is read ONCE (+1 % for the sample).
 struct QuantileCtx {
     const float* x;
     uint32_t* ws;
+    uint32_t* spec;       // [2][cap] speculative key lists (hi, lo)
     float* dest;
-    uint32_t n, k_hi, k_lo;
+    uint32_t n, k_hi, k_lo, cap;
 };
 
-__device__ __forceinline__ void quantile_pass1_body(const QuantileCtx& c, uint32_t bidx, uint32_t nblk) {
-    __shared__ uint32_t h[kQ1 + kQTrash];
-    for (int i = threadIdx.x; i < kQ1; i += kBlock) h[i] = 0;
+// thresholds from the sample histogram: one workgroup per job.
+// hi side: bucket b = the LARGEST with (sample count of top >= b) >= need; the threshold lies INSIDE it -- at its round key
+// when at least half of the bucket's sample is that one value (ties), else interpolated so that about 1.6x the still missing
+// count lies above it (the density falls towards the extreme, a linear share would come up short).  lo side mirrored.
+__device__ __forceinline__ void quantile_select0_body(const QuantileCtx& c) {
+    __shared__ uint32_t scratch[kBlock];
+    __shared__ uint32_t stop[2], thr[2];
+    const int t = threadIdx.x;
+    constexpr int per = kQ1 / kBlock;                  // 16 bins per thread
+    uint32_t mine[per];
+    uint32_t local = 0;
+#pragma unroll
+    for (int j = 0; j < per; j++) { mine[j] = c.ws[kOffH0 + t * per + j]; local += mine[j]; }
+    if (t == 0) { stop[0] = 0u; stop[1] = kQ1; thr[0] = 0xFFFFFFFFu; thr[1] = 0u; }
+    scratch[t] = local;
     __syncthreads();
-    HotCounter hc;
-    hc.init(h, kQ1);
-    const bool vec_ok = (reinterpret_cast<uintptr_t>(c.x) & 15u) == 0;
-    stream_tiles<4>(c.x, c.n, vec_ok,
-                    [&](float v, bool in) { hc.elect((int)(f2key(v) >> 20), in); },
-                    [&](float v, bool in) { hc.add(in ? (int)(f2key(v) >> 20) : hc.trash()); }, bidx, nblk);
-    hc.flush();
+    uint32_t incl = local;
+    for (int d = 1; d < kBlock; d <<= 1) {
+        const uint32_t add = t >= d ? scratch[t - d] : 0u;
+        __syncthreads();
+        incl += add;
+        scratch[t] = incl;
+        __syncthreads();
+    }
+    const uint32_t m = scratch[kBlock - 1];            // sample size
+    if (m == 0) return;                                // spec[kPEnabled] stays 0
+    const double frac = (double)m / (double)c.n;
+    // 1.3x the expected sample count + 16: a too small list is caught by the exact histogram (fallback), never wrong
+    const double need_hi = 1.3 * frac * (double)(c.n - 1 - c.k_hi) + 16.0;
+    const double need_lo = 1.3 * frac * (double)c.k_lo + 16.0;
+    const double budget = frac * (double)(c.cap / 2);
+    uint32_t F = incl - local;                         // F(b) = sample count with top < b, here b = t * per
+    uint32_t best_hi = 0, best_lo = kQ1;
+    bool any_hi = false;
+#pragma unroll
+    for (int j = 0; j < per; j++) {
+        const uint32_t b = (uint32_t)(t * per + j);
+        const uint32_t Fb = F, Fb1 = F + mine[j];
+        if ((double)Fb1 >= need_lo && b < best_lo) best_lo = b;
+        if ((double)(m - Fb) >= need_hi) { best_hi = b; any_hi = true; }
+        F = Fb1;
+    }
+    if (best_lo < kQ1) atomicMin(&stop[1], best_lo);
+    if (any_hi) atomicMax(&stop[0], best_hi);
     __syncthreads();
-    for (int i = threadIdx.x; i < kQ1; i += kBlock)
-        if (h[i]) atomicAdd(&c.ws[kOffH1 + i], h[i]);
+    const uint32_t bh = stop[0], bl = stop[1];
+    const bool have_hi = (double)m >= need_hi, have_lo = bl < kQ1;
+    F = incl - local;
+#pragma unroll
+    for (int j = 0; j < per; j++) {
+        const uint32_t b = (uint32_t)(t * per + j);
+        const uint32_t Fb = F, Fb1 = F + mine[j];
+        const uint32_t L = b << 20, H = L | 0xFFFFFu, R = round_key_of_bucket(b);
+        const double cnt = (double)mine[j];
+        if (have_hi && b == bh) {
+            const double above = (double)(m - Fb1), missing = need_hi - above;          // missing in (0, cnt]
+            const double round = (double)c.ws[kOffR0 + b];
+            uint32_t T = 0xFFFFFFFFu;
+            if (2.0 * round >= cnt) {
+                if (above + (R == L ? cnt - round : 0.0) <= budget) T = R;
+            } else {
+                const double take = fmin(cnt, 1.6 * missing);
+                if (above + take <= budget) {
+                    const uint32_t w = (uint32_t)(take / cnt * 1048576.0);
+                    T = w >= 0x100000u ? (L ? L - 1u : 0u) : H - w;
+                }
+            }
+            thr[0] = T;
+        }
+        if (have_lo && b == bl) {
+            const double below = (double)Fb, missing = need_lo - below;
+            const double round = (double)c.ws[kOffR0 + b];
+            uint32_t T = 0u;
+            if (2.0 * round >= cnt) {
+                if (below + (R == H ? cnt - round : 0.0) <= budget) T = R;
+            } else {
+                const double take = fmin(cnt, 1.6 * missing);
+                if (below + take <= budget) {
+                    const uint32_t w = (uint32_t)(take / cnt * 1048576.0);
+                    T = w >= 0x100000u ? (H == 0xFFFFFFFFu ? H : H + 1u) : L + w;
+                }
+            }
+            thr[1] = T;
+        }
+        F = Fb1;
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t* P = c.ws + kOffSpec;
+        if (thr[1] > thr[0]) return;                   // thresholds cross (tiny / degenerate sample): no speculation
+        P[kPTHi] = thr[0]; P[kPTLo] = thr[1];
+        P[kPCntHi] = 0; P[kPCntLo] = 0; P[kPTieHi] = 0; P[kPTieLo] = 0; P[kPOvfHi] = 0; P[kPOvfLo] = 0;
+        P[kPEnabled] = 1u;
+    }
 }
 
-__device__ __forceinline__ void quantile_select_a_body(const QuantileCtx& c) {
+#ifndef PPQHIP_QS_STRIDE
+#define PPQHIP_QS_STRIDE 4
+#endif
+// every 4th workgroup samples the heads of 4 chunks: the launch is bound by the LDS atomics of ONE workgroup
+// (measured on [32,512,56,56], randn / relu: stride 1: 24 / 22 us, 2: 14 / 15, 4: 11 / 14, 8: 12 / 22, 16: 19 / 38)
+constexpr uint32_t kQSampleStride = PPQHIP_QS_STRIDE;
+__device__ __forceinline__ void quantile_sample_body(const QuantileCtx& c, uint32_t bidx, uint32_t nblk) {
+    __shared__ uint32_t h[kQ1], hr[kQ1];
+    const bool vec_ok = (reinterpret_cast<uintptr_t>(c.x) & 15u) == 0;
+    if (!vec_ok || bidx % kQSampleStride != 0) return;     // unaligned tensors: no sample -> no speculation
+    for (int i = threadIdx.x; i < kQ1; i += kBlock) { h[i] = 0; hr[i] = 0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    // every lane of the wave calls this; when >= 16 lanes share the first lane's bucket they count with ONE ds_add (after a
+    // ReLU half of the sample is the same key, and 256 same-address LDS atomics per value made this launch 3x longer)
+    auto count = [&](float f, bool valid) {
+        const uint32_t key = f2key(f), top = key >> 20;
+        const bool round = key == round_key_of_bucket(top);
+        const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)top);
+        const bool same = valid && top == lead;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(same);
+        if (__builtin_popcountll(m) < 16) {            // wave-uniform: no tie worth aggregating
+            if (valid) { atomicAdd(&h[top], 1u); if (round) atomicAdd(&hr[top], 1u); }
+            return;
+        }
+        const unsigned long long mr = __builtin_amdgcn_ballot_w64(same && round);
+        if (same) {
+            if (lane == __builtin_ctzll(m)) {
+                atomicAdd(&h[top], (uint32_t)__builtin_popcountll(m));
+                if (mr) atomicAdd(&hr[top], (uint32_t)__builtin_popcountll(mr));
+            }
+        } else if (valid) {
+            atomicAdd(&h[top], 1u);
+            if (round) atomicAdd(&hr[top], 1u);
+        }
+    };
+    // the same chunking as stream_tiles<4>: workgroup b owns float4 [b * per * tile, (b + 1) * per * tile)
+    const uint32_t nvec = c.n >> 2, tile = kBlock * 4;
+    const uint32_t tiles = (nvec + tile - 1) / tile;
+    const uint32_t per = (tiles + nblk - 1) / nblk;
+    float4 a[kQSampleStride];
+    bool ok[kQSampleStride];
+#pragma unroll
+    for (uint32_t j = 0; j < kQSampleStride; j++) {
+        const uint32_t lo = (bidx + j) * per * tile;
+        const uint32_t v = lo + threadIdx.x;
+        ok[j] = bidx + j < nblk && threadIdx.x < kQSampleVec && v < nvec;
+        a[j] = reinterpret_cast<const float4*>(c.x)[ok[j] ? v : 0u];
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kQSampleStride; j++) {
+        count(a[j].x, ok[j]); count(a[j].y, ok[j]); count(a[j].z, ok[j]); count(a[j].w, ok[j]);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kQ1; i += kBlock) {
+        if (h[i]) atomicAdd(&c.ws[kOffH0 + i], h[i]);
+        if (hr[i]) atomicAdd(&c.ws[kOffR0 + i], hr[i]);
+    }
+}
+
+// Selection inside a key list (16-B aligned), restricted to the keys whose top 12 bits equal `top`: two radix rounds
+// (12 + 8 bits) with the histogram in LDS, 16-B loads, 8 of them in flight per lane.  Every thread of the workgroup
+// calls these.  list_round1 builds the first histogram in h[0..kQ2) and returns how many keys matched;
+// list_finish returns (in sel[0]) the rank-th smallest of them (0-based, rank < matched).
+template <typename F>
+__device__ __forceinline__ void list_sweep(const uint32_t* __restrict__ list, uint32_t count, F&& f) {
+    const uint4* lv = reinterpret_cast<const uint4*>(list);
+    const uint32_t nv = (count + 3) >> 2;
+    for (uint32_t i = threadIdx.x; i < nv; i += 8 * kBlock) {
+        uint4 k[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) k[u] = lv[min(i + u * kBlock, nv - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t at = (i + u * kBlock) << 2;
+            if (i + u * kBlock < nv) {
+                if (at + 0 < count) f(k[u].x);
+                if (at + 1 < count) f(k[u].y);
+                if (at + 2 < count) f(k[u].z);
+                if (at + 3 < count) f(k[u].w);
+            }
+        }
+    }
+}
+__device__ uint32_t list_round1(const uint32_t* __restrict__ list, uint32_t count, uint32_t top, uint32_t* h, uint32_t* scratch) {
+    for (int i = threadIdx.x; i < kQ2; i += kBlock) h[i] = 0;
+    if (threadIdx.x == 0) scratch[0] = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    list_sweep(list, count, [&](uint32_t key) { if ((key >> 20) == top) { atomicAdd(&h[(key >> 8) & 0xFFFu], 1u); mine++; } });
+    mine = wave_sum_u32(mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&scratch[0], mine);
+    __syncthreads();
+    const uint32_t matched = scratch[0];
+    __syncthreads();
+    return matched;
+}
+__device__ void list_finish(const uint32_t* __restrict__ list, uint32_t count, uint32_t top, uint32_t rank, uint32_t* h,
+                            uint32_t* scratch, uint32_t* sel) {
+    select_bin(h, kQ2, rank, scratch, sel);
+    const uint32_t mid = sel[0], r2 = sel[1];
+    __syncthreads();
+    for (int i = threadIdx.x; i < kQ3; i += kBlock) h[i] = 0;
+    __syncthreads();
+    const uint32_t p24 = (top << 12) | mid;
+    list_sweep(list, count, [&](uint32_t key) { if ((key >> 8) == p24) atomicAdd(&h[key & 0xFFu], 1u); });
+    __syncthreads();
+    select_bin(h, kQ3, r2, scratch, sel);
+    const uint32_t low = sel[0];
+    __syncthreads();
+    if (threadIdx.x == 0) sel[0] = (p24 << 8) | low;
+    __syncthreads();
+}
+__device__ void select_in_list(const uint32_t* __restrict__ list, uint32_t count, uint32_t top, uint32_t rank, uint32_t* h,
+                               uint32_t* scratch, uint32_t* sel) {
+    list_round1(list, count, top, h, scratch);
+    list_finish(list, count, top, rank, h, scratch, sel);
+}
+
+// one workgroup per (job, side).  With the exact histogram: bucket `top` of the wanted rank and the rank r inside it.
+// The speculative list of the side holds EVERY key beyond the threshold T (unless it overflowed), i.e. the `listed`
+// most extreme keys of bucket `top`; directly inside of them lie the >= tie keys equal to T (T's own bucket only).
+//   hi:  r >= in_bucket - listed -> the (r - (in_bucket - listed))-th smallest listed key;  else within `tie` of it -> T
+//   lo:  r < listed -> the r-th smallest listed key;  else r - listed < tie -> T
+// Anything else (unlucky sample, overflow, a tie on a value that is not a round key) falls back to passes 2 / 3.
+__device__ __forceinline__ void quantile_select_a_body(const QuantileCtx& c, int w) {
     __shared__ uint32_t scratch[kBlock];
     __shared__ uint32_t sel[2];
-    const uint32_t ks[2] = {c.k_hi, c.k_lo};
+    __shared__ uint32_t h[kQ1];
+    const uint32_t* P = c.ws + kOffSpec;
+    select_bin(c.ws + kOffH1, kQ1, w ? c.k_lo : c.k_hi, scratch, sel);
+    const uint32_t top = sel[0], rank = sel[1];
+    __syncthreads();
+    bool done = false;
+    const uint32_t count = P[w ? kPCntLo : kPCntHi];
+    if (P[kPEnabled] != 0u && count <= c.cap && P[w ? kPOvfLo : kPOvfHi] == 0u) {
+        const uint32_t T = P[w ? kPTLo : kPTHi], tie = P[w ? kPTieLo : kPTieHi];
+        const uint32_t* list = c.spec + (w ? c.cap : 0u);
+        const uint32_t in_bucket = c.ws[kOffH1 + top];
+        const uint32_t listed = list_round1(list, count, top, h, scratch);
+        const uint32_t first_listed = w ? 0u : in_bucket - listed;       // ranks [first_listed, first_listed + listed) are listed
+        if (rank >= first_listed && rank - first_listed < listed) {
+            list_finish(list, count, top, rank - first_listed, h, scratch, sel);
+            if (threadIdx.x == 0) c.dest[w] = key2f(sel[0]);
+            done = true;
+        } else if ((T >> 20) == top) {
+            const uint32_t away = w ? rank - listed + 1u : first_listed - rank;      // 1 = the key next to the listed ones
+            if (away >= 1u && away <= tie) {
+                if (threadIdx.x == 0) c.dest[w] = key2f(T);
+                done = true;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        uint32_t* S = c.ws + kOffSel + 8 * w;
+        S[kSTop] = top; S[kSRank] = rank;
+        S[kSMode] = done ? kModeDone : (c.ws[kOffH1 + top] <= kQCap ? kModeCompact : kModeHist);
+        S[kSCount] = 0; S[kSMin] = 0xFFFFFFFFu; S[kSMax] = 0u;
+    }
+}
+
+__device__ __forceinline__ void quantile_select_b_body(const QuantileCtx& c) {
+    __shared__ uint32_t h[kQ2];
+    __shared__ uint32_t scratch[kBlock];
+    __shared__ uint32_t sel[2];
     for (int w = 0; w < 2; w++) {
-        select_bin(c.ws + kOffH1, kQ1, ks[w], scratch, sel);
-        if (threadIdx.x == 0) {
-            uint32_t* S = c.ws + kOffSel + 8 * w;
-            const uint32_t top = sel[0];
-            S[kSTop] = top; S[kSRank] = sel[1];
-            S[kSMode] = c.ws[kOffH1 + top] <= kQCap ? kModeCompact : kModeHist;
-            S[kSCount] = 0; S[kSMin] = 0xFFFFFFFFu; S[kSMax] = 0u;
+        uint32_t* S = c.ws + kOffSel + 8 * w;
+        const uint32_t mode = S[kSMode], top = S[kSTop], rank = S[kSRank];
+        if (mode == kModeDone) {
+        } else if (mode == kModeCompact) {
+            const uint32_t count = min(S[kSCount], kQCap);
+            select_in_list(c.ws + kOffCand + w * kQCap, count, top, rank, h, scratch, sel);
+            if (threadIdx.x == 0) { c.dest[w] = key2f(sel[0]); S[kSMode] = kModeDone; }
+        } else if (S[kSMin] == S[kSMax]) {                         // every element of the bucket is the same value
+            if (threadIdx.x == 0) { c.dest[w] = key2f(S[kSMin]); S[kSMode] = kModeDone; }
+        } else {
+            select_bin(c.ws + kOffH2 + w * kQ2, kQ2, rank, scratch, sel);
+            if (threadIdx.x == 0) { S[kSP24] = (top << 12) | sel[0]; S[kSR24] = sel[1]; }
         }
         __syncthreads();
     }
@@ -446,7 +734,10 @@ __device__ __forceinline__ void quantile_pass2_body(const QuantileCtx& c, uint32
     if (threadIdx.x < 2) staged_n[threadIdx.x] = 0;
     uint32_t* S_hi = c.ws + kOffSel;
     uint32_t* S_lo = c.ws + kOffSel + 8;
-    const uint32_t p_hi = S_hi[kSTop], p_lo = S_lo[kSTop];
+    if (S_hi[kSMode] == kModeDone && S_lo[kSMode] == kModeDone) return;       // the speculation settled both sides
+    // a finished side must match nothing: 0xFFFFFFFF is no 12-bit prefix
+    const uint32_t p_hi = S_hi[kSMode] == kModeDone ? 0xFFFFFFFFu : S_hi[kSTop];
+    const uint32_t p_lo = S_lo[kSMode] == kModeDone ? 0xFFFFFFFFu : S_lo[kSTop];
     const bool compact_hi = S_hi[kSMode] == kModeCompact, compact_lo = S_lo[kSMode] == kModeCompact;
     uint32_t* cand_hi = c.ws + kOffCand;
     uint32_t* cand_lo = c.ws + kOffCand + kQCap;
@@ -517,45 +808,14 @@ __device__ __forceinline__ void quantile_pass2_body(const QuantileCtx& c, uint32
     }
 }
 
-// rank-th smallest (0-based) of cand[0..count): two LDS radix rounds over the low 20 key bits (all
-// candidates share the top 12).  Every thread of the workgroup calls it; result in sel[0].
-__device__ void select_in_candidates(const uint32_t* __restrict__ cand, uint32_t count, uint32_t rank, uint32_t top,
-                                     uint32_t* h, uint32_t* scratch, uint32_t* sel) {
-    for (int i = threadIdx.x; i < kQ2; i += kBlock) h[i] = 0;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < count; i += kBlock) atomicAdd(&h[(cand[i] >> 8) & 0xFFFu], 1u);
-    __syncthreads();
-    select_bin(h, kQ2, rank, scratch, sel);
-    const uint32_t mid = sel[0], r2 = sel[1];
-    __syncthreads();
-    for (int i = threadIdx.x; i < kQ3; i += kBlock) h[i] = 0;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < count; i += kBlock)
-        if (((cand[i] >> 8) & 0xFFFu) == mid) atomicAdd(&h[cand[i] & 0xFFu], 1u);
-    __syncthreads();
-    select_bin(h, kQ3, r2, scratch, sel);
-    const uint32_t low = sel[0];
-    __syncthreads();
-    if (threadIdx.x == 0) sel[0] = (top << 20) | (mid << 8) | low;
-    __syncthreads();
-}
-
-__device__ __forceinline__ void quantile_select_b_body(const QuantileCtx& c) {
-    __shared__ uint32_t h[kQ2];
+__device__ __forceinline__ void quantile_pick_body(const QuantileCtx& c) {
     __shared__ uint32_t scratch[kBlock];
     __shared__ uint32_t sel[2];
     for (int w = 0; w < 2; w++) {
-        uint32_t* S = c.ws + kOffSel + 8 * w;
-        const uint32_t mode = S[kSMode], top = S[kSTop], rank = S[kSRank];
-        if (mode == kModeCompact) {
-            const uint32_t count = min(S[kSCount], kQCap);
-            select_in_candidates(c.ws + kOffCand + w * kQCap, count, rank, top, h, scratch, sel);
-            if (threadIdx.x == 0) { c.dest[w] = key2f(sel[0]); S[kSMode] = kModeDone; }
-        } else if (S[kSMin] == S[kSMax]) {                         // every element of the bucket is the same value
-            if (threadIdx.x == 0) { c.dest[w] = key2f(S[kSMin]); S[kSMode] = kModeDone; }
-        } else {
-            select_bin(c.ws + kOffH2 + w * kQ2, kQ2, rank, scratch, sel);
-            if (threadIdx.x == 0) { S[kSP24] = (top << 12) | sel[0]; S[kSR24] = sel[1]; }
+        const uint32_t* S = c.ws + kOffSel + 8 * w;
+        if (S[kSMode] == kModeHist) {
+            select_bin(c.ws + kOffH3 + w * kQ3, kQ3, S[kSR24], scratch, sel);
+            if (threadIdx.x == 0) c.dest[w] = key2f((S[kSP24] << 8) | sel[0]);
         }
         __syncthreads();
     }
@@ -594,19 +854,6 @@ __device__ __forceinline__ void quantile_pass3_body(const QuantileCtx& c, uint32
     }
 }
 
-__device__ __forceinline__ void quantile_pick_body(const QuantileCtx& c) {
-    __shared__ uint32_t scratch[kBlock];
-    __shared__ uint32_t sel[2];
-    for (int w = 0; w < 2; w++) {
-        const uint32_t* S = c.ws + kOffSel + 8 * w;
-        if (S[kSMode] == kModeHist) {
-            select_bin(c.ws + kOffH3 + w * kQ3, kQ3, S[kSR24], scratch, sel);
-            if (threadIdx.x == 0) c.dest[w] = key2f((S[kSP24] << 8) | sel[0]);
-        }
-        __syncthreads();
-    }
-}
-
 // job j owns workgroups [first_block[j], first_block[j+1]) and its own kQWords-word slice of the workspace
 constexpr int kQuantileMultiMax = 64;                  // jobs per launch (2.6 KB of kernel arguments)
 constexpr uint32_t kQuantileMultiChunk = 32u << 10;    // elements per workgroup (128 KB)
@@ -614,30 +861,191 @@ constexpr uint32_t kQuantileMultiCap = 1024;           // workgroups per job at 
 struct QuantileJob {
     const float* x;
     uint32_t* ws;
+    uint32_t* spec;
     float* dest;
-    uint32_t n, k_hi, k_lo, first_block;
+    uint32_t n, k_hi, k_lo, first_block, cap, first_tile;
 };
 struct QuantileJobs {
     QuantileJob job[kQuantileMultiMax];
-    uint32_t count;
+    uint32_t count, total_tiles;
 };
-enum { kQPass1 = 1, kQSelectA, kQPass2, kQSelectB, kQPass3, kQPick };
+enum { kQSelectA = 2, kQPass2, kQSelectB, kQPass3, kQPick, kQSample, kQSelect0 };
+
+// ---- pass 1 as a persistent kernel (the design of hist_persistent_kernel, hist.hip) ----------------------
+// The work is the concatenated list of tiles (kQ1Block * kQ1U float4) of all jobs, split evenly over a chip-sized
+// grid; a workgroup walks its contiguous range with two ping-pong register tiles, counts key >> 20 in ONE LDS
+// histogram (EXEC-mask commits + hot bin: WaveBinCounter) and, per job it touches, adds the non-zero bins to that
+// job's hist1 with device atomics.  SPEC: keys outside (B_lo, B_hi) are staged for the speculative lists; the test
+// is one subtract + max per element and ONE wave-level branch per float4 (the element-wise branches of the first
+// version cost as much as a second pass: 13 SALU / element).
+constexpr int kQ1Block = 512, kQ1U = 2, kQ1WgPerCu = 2;
+constexpr uint32_t kQ1TileVec = kQ1Block * kQ1U, kQ1TileElems = kQ1TileVec * 4;
+constexpr uint32_t kQ1LocalCap = 1024;            // keys a workgroup can stage per side and job
+#ifndef PPQHIP_Q1_COPIES
+#define PPQHIP_Q1_COPIES 4
+#endif
+constexpr int kQ1Copies = PPQHIP_Q1_COPIES;
+__host__ __device__ inline uint32_t q1_job_tiles(uint32_t n, bool vec_ok) {
+    if (!vec_ok) return (n + kQ1TileElems - 1) / kQ1TileElems;
+    const uint32_t full = (n >> 2) / kQ1TileVec;
+    return full + (n > full * kQ1TileElems ? 1u : 0u);
+}
+
+// A key outside [T_lo, T_hi]: stage it for the speculative list of its side.  Deliberately NOT inlined (eight inlined
+// copies tripled the streaming loop's code size for a branch ~5 % of the wave iterations take).
+__device__ __noinline__ void q1_rare_key(uint32_t key, uint32_t t_hi, uint32_t* staged_hi, uint32_t* staged_lo,
+                                         uint32_t* staged_n) {
+    const int w = key > t_hi ? 0 : 1;
+    const uint32_t at = atomicAdd(&staged_n[w], 1u);
+    if (at < kQ1LocalCap) (w ? staged_lo : staged_hi)[at] = key;
+}
+
+template <bool SPEC>
+__global__ __launch_bounds__(kQ1Block, (kQ1Block * kQ1WgPerCu + 255) / 256)
+void quantile_pass1_persistent_kernel(const QuantileJobs jobs) {
+    // kQ1Copies histogram copies, chosen by lane: activations put most keys into a few dozen exponent buckets, and a
+    // k-way same-address ds_add costs ~k cycles -- spreading the lanes of a wave over 4 copies cuts the conflicts 4x
+    __shared__ int h[kQ1Copies * kQ1];
+    __shared__ uint32_t staged[2][SPEC ? kQ1LocalCap : 1];
+    __shared__ uint32_t staged_n[2], staged_base[2];
+    __shared__ uint32_t ties[2];                  // keys seen == T_hi / == T_lo (this workgroup, this job)
+    const uint32_t G = gridDim.x, g = blockIdx.x;
+    uint32_t t = (uint32_t)(((uint64_t)g * jobs.total_tiles) / G);
+    const uint32_t t_end = (uint32_t)(((uint64_t)(g + 1) * jobs.total_tiles) / G);
+    if (t >= t_end) return;
+    for (int i = threadIdx.x; i < kQ1Copies * kQ1; i += kQ1Block) h[i] = 0;
+    if (threadIdx.x < 2) { staged_n[threadIdx.x] = 0; ties[threadIdx.x] = 0; }
+    __syncthreads();
+    uint32_t lo = 0, hi = jobs.count;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (jobs.job[mid].first_tile <= t) lo = mid; else hi = mid;
+    }
+    WaveBinCounter<false, true, true> acc;
+    acc.init(h + (threadIdx.x % kQ1Copies) * kQ1, kQ1);
+    for (uint32_t j = lo; t < t_end; j++) {
+        const QuantileJob& job = jobs.job[j];
+        const uint32_t j_end = (j + 1 < jobs.count) ? jobs.job[j + 1].first_tile : jobs.total_tiles;
+        uint32_t k = t - job.first_tile;
+        const uint32_t k1 = min(t_end, j_end) - job.first_tile;
+        t = min(t_end, j_end);
+        const float* __restrict__ x = job.x;
+        const uint32_t n = job.n;
+        uint32_t* P = job.ws + kOffSpec;
+        const bool spec = SPEC && P[kPEnabled] != 0u;
+        // not enabled: [0, 0xFFFFFFFF] has no outside
+        const uint32_t t_hi = spec ? P[kPTHi] : 0xFFFFFFFFu, t_lo = spec ? P[kPTLo] : 0u;
+        const uint32_t span = t_hi - t_lo;                             // t_lo <= t_hi always (select0); key - t_lo > span <=> outside
+        int tie_hi = 0, tie_lo = 0;                                    // wave-uniform
+        auto rare = [&](uint32_t key) { q1_rare_key(key, t_hi, staged[0], staged[1], staged_n); };
+        const bool vec_ok = (reinterpret_cast<uintptr_t>(x) & 15u) == 0;
+        const uint32_t full = vec_ok ? (n >> 2) / kQ1TileVec : 0u;
+        const uint32_t kf = min(k1, full);
+        if (k < kf) {
+            const float4* xv = reinterpret_cast<const float4*>(x) + threadIdx.x;
+            float4 bufa[kQ1U], bufb[kQ1U];
+            auto fetch = [&](float4 (&buf)[kQ1U], uint32_t tile) {
+                const float4* p = xv + (size_t)tile * kQ1TileVec;
+#pragma unroll
+                for (int u = 0; u < kQ1U; u++) buf[u] = load4<true>(p + u * kQ1Block);
+            };
+            auto consume = [&](const float4 (&buf)[kQ1U]) {
+#pragma unroll
+                for (int u = 0; u < kQ1U; u++) {
+                    const uint32_t k0 = f2key(buf[u].x), k1_ = f2key(buf[u].y), k2 = f2key(buf[u].z), k3 = f2key(buf[u].w);
+                    int b[4] = {(int)(k0 >> 20), (int)(k1_ >> 20), (int)(k2 >> 20), (int)(k3 >> 20)};
+                    if (u == 0) acc.elect(b[0], true);
+                    acc.commit4_exec(b);
+                    if (SPEC) {
+                        const uint32_t d0 = k0 - t_lo, d1 = k1_ - t_lo, d2 = k2 - t_lo, d3 = k3 - t_lo;
+                        if (u == 0) {      // ties on the thresholds: a lower bound is all select A needs -> one element in eight
+                            tie_hi += acc.popc_mask(__builtin_amdgcn_ballot_w64(k0 == t_hi));
+                            tie_lo += acc.popc_mask(__builtin_amdgcn_ballot_w64(k0 == t_lo));
+                        }
+                        if (max(max(d0, d1), max(d2, d3)) > span) {
+                            if (d0 > span) rare(k0);
+                            if (d1 > span) rare(k1_);
+                            if (d2 > span) rare(k2);
+                            if (d3 > span) rare(k3);
+                        }
+                    }
+                }
+            };
+            fetch(bufa, k);
+            for (;;) {
+                fetch(bufb, min(k + 1, kf - 1));
+                consume(bufa);
+                if (++k >= kf) break;
+                fetch(bufa, min(k + 1, kf - 1));
+                consume(bufb);
+                if (++k >= kf) break;
+            }
+        }
+        for (; k < k1; k++) {             // ragged tail tile / unaligned tensor: masked 4-B loads
+            const uint32_t e0 = k * kQ1TileElems + threadIdx.x;
+#pragma unroll 4
+            for (int r = 0; r < 4 * kQ1U; r++) {
+                const uint32_t i = e0 + r * kQ1Block;
+                const bool in = i < n;
+                const uint32_t key = f2key(in ? x[i] : 0.f);
+                const int b = (int)(key >> 20);
+                if ((r & 3) == 0) acc.elect(b, in);
+                acc.template commit<false>(b, in);
+                if (SPEC && in && key - t_lo > span) rare(key);
+            }
+        }
+        acc.flush_hot();
+        acc.hot_bin = -1;
+        if (SPEC && spec && (threadIdx.x & 63) == 0) {
+            if (tie_hi) atomicAdd(&ties[0], (uint32_t)tie_hi);
+            if (tie_lo) atomicAdd(&ties[1], (uint32_t)tie_lo);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the inline-assembly ds_adds are invisible to the compiler
+        __syncthreads();
+        if (spec) {
+            if (threadIdx.x < 2) {                                 // reserve this workgroup's slice of the job's lists
+                const uint32_t all = staged_n[threadIdx.x];
+                staged_base[threadIdx.x] = all ? atomicAdd(&P[threadIdx.x ? kPCntLo : kPCntHi], min(all, kQ1LocalCap)) : 0u;
+                if (all > kQ1LocalCap) P[threadIdx.x ? kPOvfLo : kPOvfHi] = 1u;
+            }
+            if (threadIdx.x < 2 && ties[threadIdx.x]) atomicAdd(&P[threadIdx.x ? kPTieLo : kPTieHi], ties[threadIdx.x]);
+            __syncthreads();
+            for (int w = 0; w < 2; w++) {
+                const uint32_t cnt = min(staged_n[w], kQ1LocalCap), at = staged_base[w];
+                uint32_t* list = job.spec + (w ? job.cap : 0u);
+                for (uint32_t i = threadIdx.x; i < cnt; i += kQ1Block)
+                    if (at + i < job.cap) list[at + i] = staged[w][i];
+            }
+        }
+        for (int i = threadIdx.x; i < kQ1; i += kQ1Block) {        // flush + zero the LDS histogram copies
+            int v = 0;
+#pragma unroll
+            for (int cpy = 0; cpy < kQ1Copies; cpy++) { v += h[cpy * kQ1 + i]; h[cpy * kQ1 + i] = 0; }
+            if (v) atomicAdd(&job.ws[kOffH1 + i], (uint32_t)v);
+        }
+        __syncthreads();
+        if (threadIdx.x < 2) { staged_n[threadIdx.x] = 0; ties[threadIdx.x] = 0; }
+        __syncthreads();
+    }
+}
 
 template <int STEP>
 __global__ __launch_bounds__(kBlock) void quantile_multi_kernel(const QuantileJobs jobs) {
-    constexpr bool per_job = STEP == kQSelectA || STEP == kQSelectB || STEP == kQPick;     // one workgroup per job
-    uint32_t lo = per_job ? blockIdx.x : 0, hi = jobs.count;
+    // one workgroup per job (select A: per job and side)
+    constexpr bool per_job = STEP == kQSelectA || STEP == kQSelectB || STEP == kQPick || STEP == kQSelect0;
+    uint32_t lo = per_job ? (STEP == kQSelectA ? blockIdx.x >> 1 : blockIdx.x) : 0, hi = jobs.count;
     while (!per_job && hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
         if (jobs.job[mid].first_block <= blockIdx.x) lo = mid; else hi = mid;
     }
     const QuantileJob& j = jobs.job[lo];
     QuantileCtx c;
-    c.x = j.x; c.ws = j.ws; c.dest = j.dest; c.n = j.n; c.k_hi = j.k_hi; c.k_lo = j.k_lo;
+    c.x = j.x; c.ws = j.ws; c.spec = j.spec; c.dest = j.dest; c.n = j.n; c.k_hi = j.k_hi; c.k_lo = j.k_lo; c.cap = j.cap;
     const uint32_t end = lo + 1 < jobs.count ? jobs.job[lo + 1].first_block : gridDim.x;
     const uint32_t bidx = blockIdx.x - j.first_block, nblk = end - j.first_block;
-    if (STEP == kQPass1) quantile_pass1_body(c, bidx, nblk);
-    if (STEP == kQSelectA) quantile_select_a_body(c);
+    if (STEP == kQSample) quantile_sample_body(c, bidx, nblk);
+    if (STEP == kQSelect0) quantile_select0_body(c);
+    if (STEP == kQSelectA) quantile_select_a_body(c, (int)(blockIdx.x & 1u));
     if (STEP == kQPass2) quantile_pass2_body(c, bidx, nblk);
     if (STEP == kQSelectB) quantile_select_b_body(c);
     if (STEP == kQPass3) quantile_pass3_body(c, bidx, nblk);
@@ -858,8 +1266,7 @@ int ppqhip_channel_sum(const float* x, int64_t n, int64_t num_channel, int64_t e
 }
 
 int64_t ppqhip_quantile_workspace_bytes(int64_t n) {
-    (void)n;
-    const int64_t q = (int64_t)kQWords * 4;
+    const int64_t q = ((int64_t)kQWords + 2 * (int64_t)quantile_spec_cap((uint64_t)(n > 0 ? n : 0))) * 4;
     const int64_t iso = (int64_t)kIsotoneBlocks * (int64_t)sizeof(Top2);
     return q > iso ? q : iso;
 }
@@ -869,13 +1276,16 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
     uint32_t* ws = (uint32_t*)workspace;
     if (int st = check_hip(hipMemsetAsync(ws, 0, (size_t)num_jobs * kQWords * 4, s), "memset quantile workspace"))
         return st;
+    uint32_t* spec_at = ws + (size_t)num_jobs * kQWords;     // the speculative lists live behind all fixed parts
     for (int base = 0; base < num_jobs; base += kQuantileMultiMax) {
         QuantileJobs args;
         args.count = (uint32_t)((num_jobs - base) < kQuantileMultiMax ? (num_jobs - base) : kQuantileMultiMax);
-        uint32_t blocks = 0;
+        uint32_t blocks = 0, tiles = 0;
+        int64_t elems = 0;
         for (uint32_t k = 0; k < args.count; k++) {
             const ppqhip_quantile_job& src = jobs[base + k];
             const int64_t n = src.n;
+            elems += n;
             // index rule of _Quantile_T, sort.cu:13-19: __float2int_rn(num_of_elements * q), clipped to [0, n-1]
             auto pos = [n](float f) -> uint32_t {
                 float p = nearbyintf((float)n * f);
@@ -885,15 +1295,28 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
             };
             QuantileJob& d = args.job[k];
             d.x = src.x; d.dest = src.dest; d.n = (uint32_t)n; d.ws = ws + (size_t)(base + k) * kQWords;
+            d.cap = quantile_spec_cap((uint64_t)n); d.spec = spec_at; spec_at += 2 * (size_t)d.cap;
             d.k_hi = pos(q); d.k_lo = pos(1 - q); d.first_block = blocks;
+            d.first_tile = tiles;
+            tiles += q1_job_tiles(d.n, aligned16(src.x));
             uint32_t nb = (uint32_t)((n + kQuantileMultiChunk - 1) / kQuantileMultiChunk);
             if (nb > kQuantileMultiCap) nb = kQuantileMultiCap;
             if (nb < 1) nb = 1;
             blocks += nb;
         }
+        args.total_tiles = tiles;
+        uint32_t g1 = tiles / 2;                  // persistent pass 1: >= 2 tiles per workgroup, <= 2 workgroups per CU
+        if (g1 < 1) g1 = 1;
+        if (g1 > (uint32_t)(kNumCU * kQ1WgPerCu)) g1 = kNumCU * kQ1WgPerCu;
         const dim3 all(blocks), one(args.count), wg(kBlock);
-        hipLaunchKernelGGL(quantile_multi_kernel<kQPass1>, all, wg, 0, s, args);
-        hipLaunchKernelGGL(quantile_multi_kernel<kQSelectA>, one, wg, 0, s, args);
+        if (elems >= kQSpeculateMinElems) {       // sample -> thresholds -> pass 1 with speculative lists
+            hipLaunchKernelGGL(quantile_multi_kernel<kQSample>, all, wg, 0, s, args);
+            hipLaunchKernelGGL(quantile_multi_kernel<kQSelect0>, one, wg, 0, s, args);
+            hipLaunchKernelGGL((quantile_pass1_persistent_kernel<true>), dim3(g1), dim3(kQ1Block), 0, s, args);
+        } else {
+            hipLaunchKernelGGL((quantile_pass1_persistent_kernel<false>), dim3(g1), dim3(kQ1Block), 0, s, args);
+        }
+        hipLaunchKernelGGL(quantile_multi_kernel<kQSelectA>, dim3(2 * args.count), wg, 0, s, args);
         hipLaunchKernelGGL(quantile_multi_kernel<kQPass2>, all, wg, 0, s, args);
         hipLaunchKernelGGL(quantile_multi_kernel<kQSelectB>, one, wg, 0, s, args);
         hipLaunchKernelGGL(quantile_multi_kernel<kQPass3>, all, wg, 0, s, args);
@@ -912,8 +1335,10 @@ int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, void* wor
     return quantile_multi_impl(&job, 1, q, workspace, s, "quantile_t");
 }
 
-int64_t ppqhip_quantile_multi_workspace_bytes(int num_jobs) {
-    return num_jobs > 0 ? (int64_t)num_jobs * kQWords * 4 : 0;
+int64_t ppqhip_quantile_multi_workspace_bytes(int num_jobs, int64_t total_elems) {
+    // fixed part per job + the speculative lists: sum over jobs of 2 * clamp(n / 128, 4096, 2^20) keys
+    if (num_jobs <= 0) return 0;
+    return ((int64_t)num_jobs * (kQWords + 2 * 4096) + 2 * ((total_elems > 0 ? total_elems : 0) / 128)) * 4;
 }
 
 int ppqhip_quantile_t_multi(const ppqhip_quantile_job* jobs, int num_jobs, float q, void* workspace, void* stream) {

@@ -395,7 +395,7 @@ class _HipExtension:
         jobs['dest'] = [d.data_ptr() for d in dests]
         jobs['n'] = [v.numel() for v in vs]
         with _DeviceOf(vs[0]):
-            ws = _workspace(vs[0].device, lib.ppqhip_quantile_multi_workspace_bytes(len(vs)))
+            ws = _workspace(vs[0].device, lib.ppqhip_quantile_multi_workspace_bytes(len(vs), sum(v.numel() for v in vs)))
             _raise(lib.ppqhip_quantile_t_multi(jobs.ctypes.data, len(vs), float(q), ws.data_ptr(), _stream()))
         return dests
 

@@ -40,6 +40,7 @@ def timeit(fn, iters=50, warmup=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--relu', action='store_true')
+    ap.add_argument('--relu6', action='store_true', help='clamp(4 x, 0, 6): ties on both ends')
     ap.add_argument('--bins', type=int, default=2048)
     ap.add_argument('--only', type=str, default='')
     ap.add_argument('--rotate', type=int, default=6, help='distinct buffers per role (inputs, outputs)')
@@ -54,6 +55,7 @@ def main():
         R = args.rotate
         xs = [torch.randn(*shp, device=dev) for _ in range(R)]
         if args.relu: xs = [torch.relu(t) for t in xs]
+        if args.relu6: xs = [torch.clamp(4 * t, 0, 6) for t in xs]
         dys = [torch.rand_like(xs[0]) for _ in range(R)]
         outs = [torch.empty_like(xs[0]) for _ in range(R)]
         n, C = xs[0].numel(), shp[1]
@@ -114,7 +116,7 @@ def main():
         del xs, dys, outs
         torch.cuda.empty_cache()
     os.makedirs('gpurun_out', exist_ok=True)
-    tag = ('relu' if args.relu else 'randn') + f'_{args.bins}'
+    tag = ('relu6' if args.relu6 else 'relu' if args.relu else 'randn') + f'_{args.bins}'
     json.dump(rows, open(f'gpurun_out/microbench_{tag}.json', 'w'), indent=1)
 
 
