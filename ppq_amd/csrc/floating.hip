@@ -15,6 +15,11 @@ struct FloatFmt {
     int exponent_min_p1;   // exponent_min + 1
     float min_subnormal;
     int mantissa;
+    // fast path (quant_float_rne_pow2)
+    uint32_t half_m1;      // (1 << (22 - mantissa)) - 1: added to |u|'s pattern, a carry out of the dropped bits <=> they exceed one half
+    uint32_t keep;         // ~((1 << (23 - mantissa)) - 1)
+    uint32_t sub_limit;    // patterns of |u| below this take the subnormal branch: (exponent_min + 1 + 127) << 23
+    float sub_scale;       // 1 / min_subnormal (a power of two)
 };
 
 static int make_fmt(int exponent, int mantissa, float clip_min, float clip_max, FloatFmt* f, const char* what) {
@@ -40,6 +45,10 @@ static int make_fmt(int exponent, int mantissa, float clip_min, float clip_max, 
     f->exponent_min_p1 = exponent_min + 1;
     f->min_subnormal = 1.0f / (float)(1 << sub_shift);
     f->mantissa = mantissa;
+    f->half_m1 = mantissa <= 22 ? (1u << (22 - mantissa)) - 1u : 0u;
+    f->keep = mantissa <= 22 ? ~((1u << (23 - mantissa)) - 1u) : 0xFFFFFFFFu;
+    f->sub_limit = (uint32_t)(exponent_min + 1 + 127) << 23;
+    f->sub_scale = (float)(1 << sub_shift);
     return PPQHIP_OK;
 }
 
@@ -65,6 +74,34 @@ __device__ __forceinline__ float quant_float_scalar(float value, float scale, co
     return v > fmt.clip_max ? fmt.clip_max : (v < fmt.clip_min ? fmt.clip_min : v);
 }
 
+// The same function for the case every shipped FP8 configuration is in -- ROUND_HALF_EVEN and a power-of-two scale
+// (FP8Quantizer.py:99,196; the `floating` observer picks from {2^-7 .. 64}, observer/floating.py:97) -- without the two
+// IEEE divisions and the data-dependent branches, bit for bit (tests: all 2^32 input patterns):
+//   * value / 2^e == value * 2^-e (one exact scaling, rounded once either way; NaN payloads, infinities, underflow alike);
+//     u / min_subnormal likewise (min_subnormal = 2^-k);
+//   * round2int(frac) under HALF_EVEN with frac in [0, 1) is 1 iff the dropped mantissa bits exceed one half (a tie goes
+//     to 0 = the reference's round-toward-zero-on-ties quirk), i.e. a carry out of `dropped + half - 1`; adding on the
+//     whole magnitude pattern lets the carry run into the exponent exactly as `sign + m + exp` does (also for the
+//     all-ones NaN pattern, where both wrap through the sign bit: hence `+ sign`, not `| sign`);
+//   * (float)(int)rint(t) == rint(t) + 0.0f for |t| < 2^31 (the int round trip only loses the sign of a zero).
+__device__ __forceinline__ uint32_t pow2_reciprocal_bits(float s) {        // 0 when s is not 2^e with 2^-e normal too
+    const uint32_t b = __float_as_uint(s), e = b >> 23;
+    return ((b & 0x807FFFFFu) == 0u && e >= 1u && e <= 253u) ? ((254u - e) << 23) : 0u;
+}
+__device__ __forceinline__ float quant_float_rne_pow2(float value, float rcp, const FloatFmt& fmt) {
+    const float u = value * rcp;
+    const uint32_t bits = __float_as_uint(u), sign = bits & 0x80000000u, mag = bits & 0x7FFFFFFFu;
+    float vn = __uint_as_float(((mag + fmt.half_m1) & fmt.keep) + sign);
+    vn = vn > fmt.clip_max ? fmt.clip_max : (vn < fmt.clip_min ? fmt.clip_min : vn);
+    const float vs = (__builtin_rintf(u * fmt.sub_scale) + 0.0f) * fmt.min_subnormal;
+    float v = mag < fmt.sub_limit ? vs : vn;
+    v = u < fmt.lo ? fmt.lo : v;
+    v = u > fmt.hi ? fmt.hi : v;
+    return v;
+}
+template <int R>
+__device__ __forceinline__ bool float_fast_ok(const FloatFmt& fmt) { return R == ROUND_HALF_EVEN && fmt.mantissa <= 22; }
+
 // one contiguous tile of kBlock * U float4 per workgroup (see linear.hip)
 template <int R, int U, bool NT>
 __global__ __launch_bounds__(kBlock) void fq_float_t_tile_kernel(
@@ -77,6 +114,24 @@ __global__ __launch_bounds__(kBlock) void fq_float_t_tile_kernel(
 #pragma unroll
     for (int k = 0; k < U; k++)
         a[k] = load4<NT>(&x[min(base + k * kBlock, nvec - 1)]);   // branch-free (clamped) so all U loads issue back to back
+    const uint32_t rb = float_fast_ok<R>(fmt) ? pow2_reciprocal_bits(s) : 0u;
+    if (rb) {                                                     // kernel-uniform
+        const float rcp = __uint_as_float(rb);
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            if (base + k * kBlock < nvec) {
+                float4 r;
+                r.x = (quant_float_rne_pow2(a[k].x, rcp, fmt) - o) * s;
+                r.y = (quant_float_rne_pow2(a[k].y, rcp, fmt) - o) * s;
+                r.z = (quant_float_rne_pow2(a[k].z, rcp, fmt) - o) * s;
+                r.w = (quant_float_rne_pow2(a[k].w, rcp, fmt) - o) * s;
+                out[base + k * kBlock] = r;
+            }
+        }
+        if (blockIdx.x == 0 && (int)threadIdx.x < ntail)
+            otail[threadIdx.x] = (quant_float_rne_pow2(xtail[threadIdx.x], rcp, fmt) - o) * s;
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < U; k++) {
         if (base + k * kBlock < nvec) {
@@ -132,7 +187,16 @@ __global__ __launch_bounds__(kBlock) void fq_float_c_tile_kernel(
 #pragma unroll
     for (int k = 0; k < U; k++) {
         const uint32_t vv = base + k * kBlock;
-        if (vv < nvec) {
+        const uint32_t rb = float_fast_ok<R>(fmt) ? pow2_reciprocal_bits(s[k]) : 0u;
+        if (vv < nvec && rb) {                                     // diverges only where a wave straddles channels of both kinds
+            const float rcp = __uint_as_float(rb);
+            float4 r;
+            r.x = (quant_float_rne_pow2(a[k].x, rcp, fmt) - o[k]) * s[k];
+            r.y = (quant_float_rne_pow2(a[k].y, rcp, fmt) - o[k]) * s[k];
+            r.z = (quant_float_rne_pow2(a[k].z, rcp, fmt) - o[k]) * s[k];
+            r.w = (quant_float_rne_pow2(a[k].w, rcp, fmt) - o[k]) * s[k];
+            out[vv] = r;
+        } else if (vv < nvec) {
             float4 r;
             r.x = (quant_float_scalar<R>(a[k].x, s[k], fmt, rounding) - o[k]) * s[k];
             r.y = (quant_float_scalar<R>(a[k].y, s[k], fmt, rounding) - o[k]) * s[k];

@@ -83,7 +83,12 @@ def main():
         def fq_c():
             i = nxt(); lib.ppqhip_fq_linear_c(P(xs[i]), P(sc), P(oc), P(outs[i]), n, C, epc, 0, 255, 0, stream())
 
+        sp2 = torch.tensor([2.0 ** -5], device=dev)         # FP8 scales are powers of two in PPQ (observer/floating.py:97)
+
         def fq_f():
+            i = nxt(); lib.ppqhip_fq_float_t(P(xs[i]), P(sp2), P(o1), P(outs[i]), n, 4, 3, -448.0, 448.0, 0, stream())
+
+        def fq_f_generic():
             i = nxt(); lib.ppqhip_fq_float_t(P(xs[i]), P(s1), P(o1), P(outs[i]), n, 4, 3, -448.0, 448.0, 0, stream())
 
         def bwd_t():
@@ -95,7 +100,7 @@ def main():
         def copy():
             i = nxt(); outs[i].copy_(xs[i])
         cases = {
-            'fq_linear_t': (8, fq_t), 'fq_linear_c': (8, fq_c), 'fq_float_t (E4M3)': (8, fq_f),
+            'fq_linear_t': (8, fq_t), 'fq_linear_c': (8, fq_c), 'fq_float_t (E4M3, s=2^-5)': (8, fq_f), 'fq_float_t (generic s)': (8, fq_f_generic),
             'hist_sym_t (one-shot)': (4, lambda: lib.ppqhip_hist_sym_t(P(xs[nxt()]), n, hs, 1, P(hist), args.bins, P(ws), stream())),
             'hist_sym_t (rows)': (4, lambda: lib.ppqhip_hist_sym_t_rows(P(xs[nxt()]), n, hs, 1, P(rowsbuf), args.bins, stream())),
             'minmax_t (slots)': (4, lambda: lib.ppqhip_minmax_t_slots(P(xs[nxt()]), n, P(slots), stream())),
