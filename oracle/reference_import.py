@@ -101,7 +101,8 @@ def to_reference_graph(hgraph):
     return g
 
 
-def quantize_reference_graph(g, device: str, sample: torch.Tensor, bins: int = 2048, method: str = 'kl'):
+def quantize_reference_graph(g, device: str, sample: torch.Tensor, bins: int = 2048, method: str = 'kl',
+                             mutate=None):
     """The reference's own front half of quantize_native_model (api/interface.py:453-543) with the
     TensorRT INT8 quantizer: dispatch, per-op TQCs, QuantizeSimplifyPass, QuantizeFusionPass,
     ParameterQuantizePass.  Activation configs get `method` and the BASELINE's 2048-bin override
@@ -123,6 +124,7 @@ def quantize_reference_graph(g, device: str, sample: torch.Tensor, bins: int = 2
             if not v.is_parameter:
                 cfg.observer_algorithm = method
                 cfg.detail[OBSERVER_KL_HIST_BINS_MANUL_OVERRIDE] = bins
+            if mutate is not None: mutate(cfg, v)
     ex = TorchExecutor(g, device=device)
     PFL.Pipeline([QuantizeSimplifyPass(), QuantizeFusionPass(activation_type=quantizer.activation_fusion_types),
                   ParameterQuantizePass()]).optimize(graph=g, dataloader=[sample], executor=ex, calib_steps=8,
@@ -137,6 +139,23 @@ def calibrate(g, ex, batches: List[torch.Tensor], method: str = 'kl') -> float:
     t0 = time.perf_counter()
     p.optimize(graph=g, dataloader=batches, executor=ex, calib_steps=max(8, len(batches)), collate_fn=None)
     return time.perf_counter() - t0
+
+
+def lsq_finetune(g, ex, batches: List[torch.Tensor], steps: int, lr: float, block_size: int = 5, device: str = 'cuda'):
+    """The reference's LearnedStepSizePass (optim/training.py:569-863), unmodified, over `batches`.
+    Returns [(start op, end op, [member ops], pre_loss, post_loss)] in block order (its finetune() wrapped to record)."""
+    from ppq.quantization.optim import LearnedStepSizePass
+    p = LearnedStepSizePass(steps=steps, lr=lr, block_size=block_size, collecting_device=device)
+    report, inner = [], p.finetune
+
+    def recording(*a, **k):
+        pre, post = inner(*a, **k)
+        b = k['block']
+        report.append((b.sp.name, b.ep.name, [o.name for o in b.rps], float(pre), float(post)))
+        return pre, post
+    p.finetune = recording
+    p.optimize(graph=g, dataloader=batches, executor=ex, collate_fn=None)
+    return report
 
 
 def activation_scales(g) -> Dict[str, float]:

@@ -72,3 +72,77 @@ def test_reference_executor_and_calibration_pass_on_hip(topology, batch, size):
     assert set(ours) == set(ref_scales), (sorted(set(ours) ^ set(ref_scales)))
     worst = max(abs(ours[k] - ref_scales[k]) / ref_scales[k] for k in ours)
     assert worst <= 1e-6, (worst, {k: (ours[k], ref_scales[k]) for k in ours if abs(ours[k] - ref_scales[k]) > 1e-6 * ref_scales[k]})
+
+
+def test_reference_lsq_pass_on_hip_vs_this_package():
+    """the reference's OWN LearnedStepSizePass (block split, collect, LSQDelegator -> CuLSQ_LT / CuLSQ_LC ->
+    CUDA.LinearQuantize_T_B / _C_B = the HIP backward kernels) on the GPU, against ppq_amd.lsq on the same topology,
+    weights, INT4 weight configs, batches and hyper-parameters:
+      * the same blocks;  the same pre-training loss of the first block (forward kernels + calibration only: 1e-5);
+      * the FIRST optimizer step of every block sees the same trainable tensors (shapes, values to 1e-6) with the same
+        gradients (1e-3 relative wherever the gradient is above float noise) -- i.e. executor, delegators, forward and
+        backward kernels of both stacks compute the same thing;
+      * both reduce every block loss.  The trained end states are NOT compared tightly: the activation-scale gradients
+        are ~1e-8 (the order of Adam's eps), Adam turns their float noise (atomic summation order, in the reference's
+        CUDA kernels as here) into lr-sized steps, so two runs of either stack differ by tens of percent in post-loss."""
+    import ppq_amd
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    from ppq_amd.lsq import LearnedStepSizePass
+    RI.load()
+    ppq_amd.install_into_ppq()
+    from ppq.core import QuantizationProperty
+    g = torch.Generator().manual_seed(7)
+    batches = [torch.rand(8, 3, 24, 24, generator=g).to(DEV) for _ in range(8)]
+    steps, lr = 60, 1e-3
+    first_steps, seen = [], set()
+    orig_step = torch.optim.Adam.step
+
+    def recording_step(self, *a, **k):
+        if id(self) not in seen:
+            seen.add(id(self))
+            rows = [(tuple(p.shape), float(p.detach().double().norm()), 0.0 if p.grad is None else float(p.grad.double().norm()))
+                    for grp in self.param_groups for p in grp['params']]
+            first_steps.append(sorted(rows))
+        return orig_step(self, *a, **k)
+
+    def int4(cfg, v):
+        if v.is_parameter and cfg.policy.has_property(QuantizationProperty.PER_CHANNEL):
+            cfg.num_of_bits, cfg.quant_min, cfg.quant_max = 4, -8, 7
+    torch.optim.Adam.step = recording_step
+    try:
+        rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(harness.small_cnn_graph(seed=5, width=16)), DEV, batches[0],
+                                              method='minmax', mutate=int4)
+        RI.calibrate(rg, rex, batches, method='minmax')
+        ref = RI.lsq_finetune(rg, rex, batches, steps=steps, lr=lr, block_size=5, device=DEV)
+        ref_first = list(first_steps); first_steps.clear()
+
+        hg = harness.small_cnn_graph(seed=5, width=16)
+        harness.quantize_graph(hg, 'minmax')
+        for op in hg.operations.values():
+            for cfg, var in op.config_with_variable:
+                if var.is_parameter and cfg.state.value == 1: cfg.num_of_bits, cfg.quant_min, cfg.quant_max = 4, -8, 7
+        hex_ = harness.TorchExecutor(hg, DEV)
+        harness.ParameterQuantizePass().optimize(hg)
+        RuntimeCalibrationPass().optimize(hg, dataloader=batches, executor=hex_, calib_steps=8)
+        p = LearnedStepSizePass(steps=steps, lr=lr, block_size=5)
+        p.optimize(hg, batches, hex_)
+        ours, our_first = p.report, list(first_steps)
+    finally:
+        torch.optim.Adam.step = orig_step
+    print('reference:', [(r[0], r[1], r[3], r[4]) for r in ref]); print('ours     :', ours)
+    assert [f'[Graph Block from {r[0]} to {r[1]}]' for r in ref] == [r[0] for r in ours]
+    assert [r[2] for r in ref] == [[o.name for o in b.rps] for b in
+                                   __import__('ppq_amd.blocks', fromlist=['x']).split_graph_into_blocks(hg, hg.topological_sort(), 5)]
+    assert abs(ours[0][1] - ref[0][3]) <= 1e-5 * ref[0][3], (ours[0], ref[0])          # pre-training loss of the first block
+    # first optimizer step of the FIRST block: identical state on both sides -> identical tensors and gradients
+    a, b = ref_first[0], our_first[0]
+    assert [r[0] for r in a] == [r[0] for r in b], (a, b)
+    for (shape, val_r, grad_r), (_, val_o, grad_o) in zip(a, b):
+        assert abs(val_r - val_o) <= 1e-6 * max(val_r, 1e-12), (shape, val_r, val_o)
+        if grad_r > 1e-6: assert abs(grad_r - grad_o) <= 1e-3 * grad_r, (shape, grad_r, grad_o)
+        else: assert grad_o <= 1e-5, (shape, grad_r, grad_o)
+    assert len(ref_first) == len(our_first) == len(ref)
+    for (name, pre, post), r in zip(ours, ref):
+        assert post < pre and r[4] < r[3], (name, pre, post, r)
+        assert 0.33 * r[4] <= post <= 3.0 * r[4], (name, post, r[4])
