@@ -158,6 +158,24 @@ def lsq_finetune(g, ex, batches: List[torch.Tensor], steps: int, lr: float, bloc
     return report
 
 
+def bias_correction(g, ex, batches: List[torch.Tensor], block_size: int = 1, device: str = 'cuda'):
+    """The reference's BiasCorrectionPass (optim/training.py:338-566), unmodified.  Returns
+    ([(start op, pre_loss, post_loss, [member ops])], {bias variable name: value after the pass})."""
+    from ppq.quantization.optim import BiasCorrectionPass
+    p = BiasCorrectionPass(block_size=block_size, steps=len(batches), collecting_device=device)
+    report, inner = [], p.correct_bias
+
+    def recording(*a, **k):
+        pre, post = inner(*a, **k)
+        report.append((k['block'].sp.name, float(pre), float(post), [o.name for o in k['block'].rps]))
+        return pre, post
+    p.correct_bias = recording
+    p.optimize(graph=g, dataloader=batches, executor=ex, collate_fn=None)
+    biases = {op.inputs[-1].name: op.inputs[-1].value.detach().clone() for op in g.operations.values()
+              if op.type in ('Conv', 'Gemm', 'ConvTranspose') and len(op.inputs) == 3}
+    return report, biases
+
+
 def activation_scales(g) -> Dict[str, float]:
     """{variable name: rendered per-tensor scale} of every ACTIVATED activation config."""
     from ppq.core import QuantizationStates

@@ -39,6 +39,7 @@ class Variable:
     def __init__(self, name: str, value: torch.Tensor = None, is_parameter: bool = False):
         self.name = name
         self.value = value
+        self.stored_value = None         # QuantableVariable.stored_value, IR/quantize.py:183-205 (set when its op is quantised)
         self.is_parameter = is_parameter
         self.dest_ops: List['Operation'] = []
         self.source_op: Optional['Operation'] = None
@@ -73,6 +74,20 @@ class QuantableOperation(Operation):
     def __init__(self, op: Operation, config: OperationQuantizationConfig):
         super().__init__(op.name, op.type, op.attributes, op.inputs, op.outputs)
         self.config = config
+        self.store_parameter_value()
+
+    def store_parameter_value(self):
+        """IR/quantize.py:113-122: keep a copy of every parameter as it is when the operation is quantised."""
+        for var in self.inputs:
+            if var.is_parameter and isinstance(var.value, torch.Tensor): var.stored_value = var.value.detach().clone()
+        return self
+
+    def _swap_parameters(self) -> None:
+        for var in self.inputs:
+            if var.is_parameter and isinstance(var.value, torch.Tensor) and var.stored_value is not None:
+                parked = var.value
+                var.value = var.stored_value.to(parked.device)
+                var.stored_value = parked
 
     @ property
     def config_with_variable(self):
@@ -80,19 +95,24 @@ class QuantableOperation(Operation):
             list(zip(self.config.output_quantization_config, self.outputs))
 
     def dequantize(self):
-        """ppq/IR/quantize.py:124-141 (state part): park every config in FP32, remembering its state."""
+        """ppq/IR/quantize.py:124-141: park every config in FP32, remembering its state, AND swap every parameter with
+        its stored value -- a dequantised operation computes with the parameters it had when it was quantised (the
+        current, possibly finetuned / bias-corrected / baked ones wait in stored_value).  This is what makes the FP32
+        targets of the training based passes independent of what earlier blocks did to the parameters."""
         if getattr(self, '_dequantized', False): return self
         for cfg, _ in self.config_with_variable:
             cfg.detail['Stored State'] = cfg.state
             cfg.state = QuantizationStates.FP32
+        self._swap_parameters()
         self._dequantized = True
         return self
 
     def restore_quantize_state(self):
-        """ppq/IR/quantize.py:143-160."""
+        """ppq/IR/quantize.py:143-160: the states and the current parameters come back."""
         if not getattr(self, '_dequantized', False): return self
         for cfg, _ in self.config_with_variable:
             if 'Stored State' in cfg.detail: cfg.state = cfg.detail.pop('Stored State')
+        self._swap_parameters()
         self._dequantized = False
         return self
 

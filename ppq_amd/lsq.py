@@ -128,20 +128,12 @@ class LearnedStepSizePass:
     xGMI, so never one collective per tensor); block losses are averaged so every rank takes the same keep /
     withdraw decision.  ``report`` = [(block, pre_loss, post_loss)]."""
     def __init__(self, steps: int = 500, lr: float = 5e-5, gamma: float = 0.0, optimizer=None, process_group=None,
-                 block_size: int = None, interested_layers: List[str] = None, is_scale_trainable: bool = True,
-                 fp_reference: str = 'current'):
+                 block_size: int = None, interested_layers: List[str] = None, is_scale_trainable: bool = True):
         self.steps, self.lr, self.gamma, self.optimizer = steps, lr, gamma, optimizer
         self.process_group = process_group
         self.block_size = block_size
         self.interested_layers = interested_layers or []
         self.is_scale_trainable = is_scale_trainable
-        # 'current' (the reference, training.py:224-298): a block's FP32 target is collected right before it is
-        # trained, from the dequantised graph WITH the weights the earlier blocks have already moved -- Adam's
-        # sign-like steps on the latent FP32 weights are coherent over a whole fan-in, so on hard cases (INT4) the
-        # FP32 function itself drifts and later blocks chase a moving target.  'initial' (opt-in, not in the
-        # reference): every block's target comes from the ORIGINAL weights, collected once before any training.
-        if fp_reference not in ('current', 'initial'): raise ValueError("fp_reference: 'current' or 'initial'")
-        self.fp_reference = fp_reference
         self.report = []
 
     def _world(self) -> int:
@@ -239,12 +231,10 @@ class LearnedStepSizePass:
             blocks = split_graph_into_blocks(graph, graph.topological_sort(), self.block_size,
                                              interested_layers=self.interested_layers)
         self.report = []
-        initial = None
-        if self.fp_reference == 'initial':
-            from .blocks import collect_fp_outputs
-            initial = collect_fp_outputs(graph, blocks, executor, batches)
         for k, block in enumerate(blocks):
-            qt_inputs, fp_outputs = collect(graph, block, executor, batches, fp_outputs=None if initial is None else initial[k])
+            # FP32 targets: the graph dequantised, i.e. (IR/quantize.py:124-141) computing with the parameters stored at
+            # quantisation time -- what earlier blocks trained does not move the targets of later ones
+            qt_inputs, fp_outputs = collect(graph, block, executor, batches)
             pre_loss, post_loss = self.finetune(block, executor, qt_inputs, fp_outputs)
             self.report.append((str(block), pre_loss, post_loss))
         if not self.report: return 0.0, 0.0

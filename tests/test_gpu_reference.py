@@ -146,3 +146,45 @@ def test_reference_lsq_pass_on_hip_vs_this_package():
     for (name, pre, post), r in zip(ours, ref):
         assert post < pre and r[4] < r[3], (name, pre, post, r)
         assert 0.33 * r[4] <= post <= 3.0 * r[4], (name, post, r[4])
+
+
+@pytest.mark.parametrize('block_size', [1, 4])
+def test_reference_bias_correction_pass_on_hip_vs_this_package(block_size):
+    """The reference's OWN BiasCorrectionPass on the GPU vs ppq_amd.bias_correction (blocks from ppq_amd.blocks, DC terms from
+    the channel_sum kernel): deterministic, so the comparison is tight -- the same blocks, block losses to 2e-4 and every
+    corrected bias to 1e-4 of the bias range (float32 torch.mean there, the double-accumulating channel_sum kernel here)."""
+    import ppq_amd
+    from ppq_amd import harness
+    from ppq_amd.bias_correction import BiasCorrectionPass
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    RI.load()
+    ppq_amd.install_into_ppq()
+    g = torch.Generator().manual_seed(3)
+    batches = [torch.rand(8, 3, 24, 24, generator=g).to(DEV) for _ in range(8)]
+    rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(harness.small_cnn_graph(seed=5, width=16)), DEV, batches[0],
+                                          method='minmax')
+    RI.calibrate(rg, rex, batches, method='minmax')
+    ref_report, ref_bias = RI.bias_correction(rg, rex, batches, block_size=block_size, device=DEV)
+
+    hg = harness.small_cnn_graph(seed=5, width=16)
+    before = {v.name: v.value.clone() for op in hg.operations.values() for v in op.inputs if v.is_parameter}
+    harness.quantize_graph(hg, 'minmax')
+    hex_ = harness.TorchExecutor(hg, DEV)
+    harness.ParameterQuantizePass().optimize(hg)
+    RuntimeCalibrationPass().optimize(hg, dataloader=batches, executor=hex_, calib_steps=8)
+    p = BiasCorrectionPass(block_size=block_size, steps=len(batches))
+    p.optimize(hg, batches, hex_)
+    print('reference:', ref_report); print('ours     :', p.report)
+    assert [r[0] for r in ref_report] == [r[0] for r in p.report]
+    from ppq_amd.blocks import split_graph_into_blocks
+    assert [r[3] for r in ref_report] == [[o.name for o in b.rps] for b in split_graph_into_blocks(hg, hg.topological_sort(), block_size)]
+    for r, o in zip(ref_report, p.report):
+        assert abs(r[1] - o[1]) <= 2e-4 * max(r[1], 1e-12) and abs(r[2] - o[2]) <= 2e-4 * max(r[2], 1e-12), (r, o)
+    ours = {v.name: v.value for op in hg.operations.values() for v in op.inputs if v.is_parameter}
+    moved = 0
+    for name, want in ref_bias.items():
+        got = ours[name].to(want.device)
+        span = float(want.abs().max()) + 1e-6
+        assert float((got - want).abs().max()) <= 1e-4 * span, (name, float((got - want).abs().max()), span)
+        moved += int(not torch.equal(got.cpu(), before[name].cpu()))
+    assert moved > 0                                               # the pass did change biases (and identically on both sides)
