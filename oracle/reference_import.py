@@ -101,19 +101,21 @@ def to_reference_graph(hgraph):
     return g
 
 
-def quantize_reference_graph(g, device: str, sample: torch.Tensor, bins: int = 2048, method: str = 'kl',
-                             mutate=None):
+def quantize_reference_graph(g, device: str, sample: torch.Tensor, bins: int = 2048, method: Optional[str] = 'kl',
+                             mutate=None, platform: str = 'TRT_INT8'):
     """The reference's own front half of quantize_native_model (api/interface.py:453-543) with the
     TensorRT INT8 quantizer: dispatch, per-op TQCs, QuantizeSimplifyPass, QuantizeFusionPass,
     ParameterQuantizePass.  Activation configs get `method` and the BASELINE's 2048-bin override
-    (range.py:152-153).  Returns (graph, executor) ready for RuntimeCalibrationPass."""
+    (range.py:152-153); `method=None` keeps the quantizer's own algorithm (TRT_FP8: 'floating').  `platform`: a
+    TargetPlatform name.  Returns (graph, executor) ready for RuntimeCalibrationPass."""
     import ppq.lib as PFL
     from ppq import TargetPlatform, TorchExecutor
     from ppq.api import dispatch_graph
     from ppq.core import OBSERVER_KL_HIST_BINS_MANUL_OVERRIDE
     from ppq.quantization.optim import ParameterQuantizePass, QuantizeFusionPass, QuantizeSimplifyPass
-    g = dispatch_graph(g, TargetPlatform.TRT_INT8, 'conservative')
-    quantizer = PFL.Quantizer(platform=TargetPlatform.TRT_INT8, graph=g)
+    target = getattr(TargetPlatform, platform)
+    g = dispatch_graph(g, target, 'conservative')
+    quantizer = PFL.Quantizer(platform=target, graph=g)
     TorchExecutor(g, device=device).tracing_operation_meta(inputs=sample.to(device))
     for op in list(g.operations.values()):
         if op.platform not in (TargetPlatform.FP32, TargetPlatform.SOI):
@@ -121,7 +123,7 @@ def quantize_reference_graph(g, device: str, sample: torch.Tensor, bins: int = 2
     for op in g.operations.values():
         if not hasattr(op, 'config'): continue
         for cfg, v in op.config_with_variable:
-            if not v.is_parameter:
+            if not v.is_parameter and method is not None:
                 cfg.observer_algorithm = method
                 cfg.detail[OBSERVER_KL_HIST_BINS_MANUL_OVERRIDE] = bins
             if mutate is not None: mutate(cfg, v)
@@ -132,7 +134,7 @@ def quantize_reference_graph(g, device: str, sample: torch.Tensor, bins: int = 2
     return g, ex
 
 
-def calibrate(g, ex, batches: List[torch.Tensor], method: str = 'kl') -> float:
+def calibrate(g, ex, batches: List[torch.Tensor], method: Optional[str] = 'kl') -> float:
     """The reference's RuntimeCalibrationPass over `batches`; returns the seconds it took."""
     from ppq.quantization.optim import RuntimeCalibrationPass
     p = RuntimeCalibrationPass(method=method)
@@ -174,6 +176,18 @@ def bias_correction(g, ex, batches: List[torch.Tensor], block_size: int = 1, dev
     biases = {op.inputs[-1].name: op.inputs[-1].value.detach().clone() for op in g.operations.values()
               if op.type in ('Conv', 'Gemm', 'ConvTranspose') and len(op.inputs) == 3}
     return report, biases
+
+
+def all_scales(g) -> Dict[str, List[float]]:
+    """{"op:variable": scale values} of EVERY activated config (activations and parameters)."""
+    from ppq.core import QuantizationStates
+    out = {}
+    for op in g.operations.values():
+        if not hasattr(op, 'config'): continue
+        for cfg, v in op.config_with_variable:
+            if cfg.state == QuantizationStates.ACTIVATED and cfg.scale is not None:
+                out[f'{op.name}:{v.name}'] = [float(s) for s in cfg.scale.flatten().tolist()]
+    return out
 
 
 def activation_scales(g) -> Dict[str, float]:

@@ -662,13 +662,16 @@ def vit_graph(seed: int = 0, depth: int = 12, dim: int = 768, heads: int = 12, m
     return g
 
 
-def quantize_graph_fp8(graph: BaseGraph, exponent: int = 4, mantissa: int = 3) -> None:
+def quantize_graph_fp8(graph: BaseGraph, exponent: int = 4, mantissa: int = 3, operations=None) -> None:
     """TRT_FP8-style policy (quantizer/FP8Quantizer.py:107-200): only the inputs of Conv / Gemm / MatMul
     are quantised -- activations per tensor with the power-of-2 'floating' observer, weights per
-    channel (axis 0) with the same observer; everything else stays FP32."""
+    channel (axis 0) with the same observer; everything else stays FP32.  `operations`: names of the
+    operations a dispatcher chose to quantise (default: all; the reference's 'conservative' dispatcher
+    leaves everything downstream of a non-quantable type such as Add on the FP32 platform)."""
     from .core import FloatingQuantizationConfig
     qmax = 448.0 if (exponent, mantissa) == (4, 3) else 57344.0
     for name, op in list(graph.operations.items()):
+        if operations is not None and name not in operations: continue
         in_cfgs = []
         for i, v in enumerate(op.inputs):
             c = FloatingQuantizationConfig(exponent=exponent, mantissa=mantissa, quant_min=-qmax, quant_max=qmax,

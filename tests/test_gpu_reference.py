@@ -188,3 +188,41 @@ def test_reference_bias_correction_pass_on_hip_vs_this_package(block_size):
         assert float((got - want).abs().max()) <= 1e-4 * span, (name, float((got - want).abs().max()), span)
         moved += int(not torch.equal(got.cpu(), before[name].cpu()))
     assert moved > 0                                               # the pass did change biases (and identically on both sides)
+
+
+def test_reference_fp8_quantizer_and_floating_observers_on_hip_vs_this_package():
+    """BASELINE config 4's path with the reference's OWN stack: its TRT_FP8 quantizer (inputs of Conv / Gemm only, E4M3,
+    power-of-2 scales), its 'floating' observers (DirectMSEObserver -> CUDA.FloatingQuantize_T / _C = the HIP FP8 kernels)
+    and its RuntimeCalibrationPass, against harness.quantize_graph_fp8 + this package's pass on the same weights and
+    batches, with the global torch RNG (the observers' random fetches, utils/fetch.py:27-29) seeded alike: the same set
+    of activated configs and identical scales, activations and per-channel weights; then the same quantised forward."""
+    import ppq_amd
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    RI.load()
+    ppq_amd.install_into_ppq()
+    g = torch.Generator().manual_seed(11)
+    batches = [(torch.randn(4, 3, 32, 32, generator=g) * 1.5).to(DEV) for _ in range(8)]
+    rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(harness.small_cnn_graph(seed=2, width=16)), DEV, batches[0],
+                                          method=None, platform='TRT_FP8')
+    torch.manual_seed(1234)
+    RI.calibrate(rg, rex, batches, method=None)
+    ref = RI.all_scales(rg)
+    ref_out = rex.forward(batches[0])[0]
+
+    hg = harness.small_cnn_graph(seed=2, width=16)
+    # dispatching is the reference's control plane (out of scope): quantise exactly the operations its dispatcher chose
+    harness.quantize_graph_fp8(hg, operations={op.name for op in rg.operations.values() if hasattr(op, 'config')})
+    hex_ = harness.TorchExecutor(hg, DEV)
+    harness.ParameterQuantizePass().optimize(hg)
+    torch.manual_seed(1234)
+    RuntimeCalibrationPass().optimize(hg, dataloader=batches, executor=hex_, calib_steps=8)
+    ours = {f'{op.name}:{v.name}': [float(s) for s in c.scale.flatten().tolist()] for op in hg.operations.values()
+            if hasattr(op, 'config') for c, v in op.config_with_variable
+            if int(getattr(c.state, 'value', c.state)) == 4 and c.scale is not None}
+    assert set(ours) == set(ref) and len(ref) >= 4, sorted(set(ours) ^ set(ref))
+    assert ours == ref, {k: (ours[k], ref[k]) for k in ref if ours[k] != ref[k]}
+    assert any(len(v) > 1 for v in ref.values())                       # per-channel FP8 weights took part
+    out = hex_.forward(batches[0])[0]
+    # the two executors call the vendor convolution differently (explicit F.pad there): float noise of 1e-5, not FP8 steps (2^-4 relative)
+    assert torch.allclose(out, ref_out.to(out.device), rtol=1e-4, atol=1e-4)
