@@ -27,11 +27,14 @@ def test_reference_kernel_tests_run_unchanged_on_hip():
     assert 'reference kernel tests passed on libppq_hip.so' in r.stdout, tail
 
 
-@pytest.mark.parametrize('topology,batch,size', [('small_cnn', 4, 32), ('resnet50', 4, 224)])
-def test_reference_executor_and_calibration_pass_on_hip(topology, batch, size):
-    """The reference's OWN BaseGraph + TensorRT quantizer + TorchExecutor + RuntimeCalibrationPass('kl') on
+@pytest.mark.parametrize('topology,batch,size,method', [('small_cnn', 4, 32, 'kl'), ('small_cnn', 4, 32, 'mse'),
+                                                        ('small_cnn', 4, 32, 'percentile'), ('small_cnn', 4, 32, 'minmax'),
+                                                        ('resnet50', 4, 224, 'kl')])
+def test_reference_executor_and_calibration_pass_on_hip(topology, batch, size, method):
+    """The reference's OWN BaseGraph + TensorRT quantizer + TorchExecutor + RuntimeCalibrationPass(method) on
     the GPU after install_into_ppq() -- vs this package's harness + pass on the same weights and batches:
-    the same set of activation configs is calibrated and every rendered scale agrees to 1e-6."""
+    the same set of activation configs is calibrated and every rendered scale agrees to 1e-6 (kl / mse: Histogram_T +
+    the searches; percentile: Quantile_T; minmax: the reductions)."""
     import ppq_amd
     from ppq_amd import harness
     from ppq_amd.calibration import RuntimeCalibrationPass
@@ -54,18 +57,18 @@ def test_reference_executor_and_calibration_pass_on_hip(topology, batch, size):
             return w
         setattr(ext, name, make(getattr(type(ext), name)))
     try:
-        rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(build(seed=0)), DEV, batches[0], bins=2048)
-        RI.calibrate(rg, rex, batches)
+        rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(build(seed=0)), DEV, batches[0], bins=2048, method=method)
+        RI.calibrate(rg, rex, batches, method=method)
         ref_scales = RI.activation_scales(rg)
     finally:
         for name in ('QuantizeTensor_LC', 'QuantizeTensor_LT', 'Histogram_T'): delattr(ext, name)
-    assert counted.get('QuantizeTensor_LC', 0) > 0 and counted.get('Histogram_T', 0) > 0, counted
+    assert counted.get('QuantizeTensor_LC', 0) > 0 and (counted.get('Histogram_T', 0) > 0) == (method in ('kl', 'mse')), counted
     # this package's harness + pass
     hg = build(seed=0)
-    harness.quantize_graph(hg, 'kl', hist_bins=2048)
+    harness.quantize_graph(hg, method, hist_bins=2048)
     hex_ = harness.TorchExecutor(hg, DEV)
     harness.ParameterQuantizePass().optimize(hg)
-    RuntimeCalibrationPass(method='kl').optimize(hg, dataloader=batches, executor=hex_, calib_steps=8)
+    RuntimeCalibrationPass(method=method).optimize(hg, dataloader=batches, executor=hex_, calib_steps=8)
     ours = {v.name: float(c.scale.flatten()[0]) for op in hg.operations.values() if hasattr(op, 'config')
             for c, v in op.config_with_variable
             if not v.is_parameter and int(getattr(c.state, 'value', c.state)) == 4 and c.scale is not None}
@@ -226,3 +229,45 @@ def test_reference_fp8_quantizer_and_floating_observers_on_hip_vs_this_package()
     out = hex_.forward(batches[0])[0]
     # the two executors call the vendor convolution differently (explicit F.pad there): float noise of 1e-5, not FP8 steps (2^-4 relative)
     assert torch.allclose(out, ref_out.to(out.device), rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('method', ['mse', 'minmax', 'percentile'])
+def test_reference_asymmetric_calibration_on_hip(method):
+    """BASELINE config 3's policy through the reference's own stack: per-channel ASYMMETRIC [0, 255] weights and per-tensor
+    asymmetric activations (Histogram_Asymmetric_T + the asymmetric MSE search, or min / max, or quantiles) -- every
+    activation AND weight scale and offset equal this package's to 1e-6 / exactly."""
+    import ppq_amd
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    RI.load()
+    ppq_amd.install_into_ppq()
+    from ppq.core import QuantizationPolicy, QuantizationProperty as QP, QuantizationStates
+    g = torch.Generator().manual_seed(21)
+    batches = [torch.randn(4, 3, 32, 32, generator=g).to(DEV) for _ in range(8)]
+
+    def asym(cfg, v):
+        per = QP.PER_CHANNEL if cfg.policy.has_property(QP.PER_CHANNEL) else QP.PER_TENSOR
+        cfg.policy = QuantizationPolicy(QP.ASYMMETRICAL + QP.LINEAR + per)
+        cfg.quant_min, cfg.quant_max = 0, 255
+    rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(harness.small_cnn_graph(seed=4)), DEV, batches[0], bins=2048,
+                                          method=method, mutate=asym)
+    RI.calibrate(rg, rex, batches, method=method)
+    ref = {}
+    for op in rg.operations.values():
+        if not hasattr(op, 'config'): continue
+        for cfg, v in op.config_with_variable:
+            if cfg.state == QuantizationStates.ACTIVATED and cfg.scale is not None:
+                ref[f'{op.name}:{v.name}'] = (cfg.scale.flatten().cpu(), cfg.offset.flatten().cpu())
+    hg = harness.small_cnn_graph(seed=4)
+    harness.quantize_graph(hg, method, symmetrical=False, weight_symmetrical=False, hist_bins=2048)
+    hex_ = harness.TorchExecutor(hg, DEV)
+    harness.ParameterQuantizePass().optimize(hg)
+    RuntimeCalibrationPass(method=method).optimize(hg, dataloader=batches, executor=hex_, calib_steps=8)
+    ours = {f'{op.name}:{v.name}': (c.scale.flatten().cpu(), c.offset.flatten().cpu()) for op in hg.operations.values()
+            if hasattr(op, 'config') for c, v in op.config_with_variable
+            if int(getattr(c.state, 'value', c.state)) == 4 and c.scale is not None}
+    assert set(ours) == set(ref) and len(ref) >= 8, sorted(set(ours) ^ set(ref))
+    assert any(s.numel() > 1 for s, _ in ref.values())
+    for k, (s, o) in ref.items():
+        assert torch.allclose(ours[k][0], s, rtol=1e-6, atol=0), (k, ours[k][0], s)
+        assert torch.equal(ours[k][1], o), (k, ours[k][1], o)
