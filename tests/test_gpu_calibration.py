@@ -1175,3 +1175,103 @@ def test_yolov6s_int4_blockwise_lsq_and_bias_correction():
     assert e_after < 0.8 * e_before, (err0, err1, e_before, e_after)
     assert all(torch.isfinite(v.value).all() for v in graph.variables.values() if v.is_parameter)
     assert not ex._delegates
+
+
+@pytest.mark.parametrize('symmetrical', [True, False])
+def test_isotone_observer_never_worse_than_minmax_at_keeping_the_argmax(symmetrical):
+    """The property the reference's tests/test_isotone.py checks (10 000 random 10-class softmaxes per policy there, 1 500
+    here, on the GPU through the HIP fake-quant kernel): after isotone calibration the quantised arg-max is wrong no
+    more often than after min-max calibration of the same row."""
+    from ppq_amd.core import LinearQuantizationConfig, QuantizationStates
+    from ppq_amd.observer import OBSERVER_TABLE
+    from ppq_amd.qfunction import PPQLinearQuantFunction
+    cfg = LinearQuantizationConfig(symmetrical=symmetrical, quant_min=-128 if symmetrical else 0, quant_max=127 if symmetrical else 255,
+                                   num_of_bits=8, calibration='isotone')
+    var = type('V', (), {'name': 'TestVariable', 'is_parameter': False})()
+    g = torch.Generator().manual_seed(1)
+    rows = torch.sort(torch.softmax(torch.rand(1500, 10, generator=g), dim=-1), dim=-1)[0].to(DEV)
+    for i in range(rows.shape[0]):
+        value = rows[i: i + 1]
+        errors = []
+        for algo in ('isotone', 'minmax'):
+            cfg.state = QuantizationStates.INITIAL
+            ob = OBSERVER_TABLE[algo](var, cfg)
+            ob.observe(value)
+            ob.render_quantization_config()
+            q = PPQLinearQuantFunction(value, cfg)
+            errors.append(int(torch.sum(torch.argmax(value, dim=-1) != torch.argmax(q, dim=-1))))
+        assert errors[0] <= errors[1], (i, errors, value, cfg.scale)
+
+
+def test_isotone_calibration_pass_marks_softmax_outputs_and_they_calibrate():
+    """optim/calibration.py:325-423: IsotoneCalibrationPass rewrites the Softmax output configs (INITIAL, 'Isotone', axis);
+    the RuntimeCalibrationPass that follows renders them with the isotone observer, everything else as before."""
+    from ppq_amd import harness
+    from ppq_amd.calibration import IsotoneCalibrationPass, RuntimeCalibrationPass
+    from ppq_amd.core import OBSERVER_ISOTONE_OBSERVER_AXIS
+    graph = harness.vit_graph(seed=0, depth=1, dim=64, heads=2, mlp_dim=128, patch=16, num_classes=10)
+    harness.quantize_graph(graph, 'minmax')
+    ex = harness.TorchExecutor(graph, DEV)
+    harness.ParameterQuantizePass().optimize(graph)
+    IsotoneCalibrationPass(verbose=False).optimize(graph)
+    marked = [op for op in graph.operations.values() if op.type == 'Softmax'
+              and str(op.config.output_quantization_config[0].observer_algorithm).lower() == 'isotone']
+    assert marked and all(OBSERVER_ISOTONE_OBSERVER_AXIS in op.config.output_quantization_config[0].detail for op in marked)
+    g = torch.Generator().manual_seed(2)
+    batches = [torch.randn(2, 3, 224, 224, generator=g).to(DEV) for _ in range(8)]
+    seen = []
+    from ppq_amd import observer as obs_mod
+    orig = obs_mod.TorchIsotoneObserver.render_quantization_config
+
+    def spy(self):
+        seen.append(self)
+        return orig(self)
+    obs_mod.TorchIsotoneObserver.render_quantization_config = spy
+    try:
+        RuntimeCalibrationPass().optimize(graph, dataloader=batches, executor=ex, calib_steps=8)
+    finally:
+        obs_mod.TorchIsotoneObserver.render_quantization_config = orig
+    assert len(seen) == len(marked)
+    for op in marked:
+        c = op.config.output_quantization_config[0]
+        assert c.state.value == 4 and float(c.scale) > 0
+    assert torch.isfinite(ex.forward(batches[0])[0]).all()
+
+
+def test_floating_observer_merged_squared_errors_pick_the_same_scale():
+    """Data-parallel FP8 calibration: the per-candidate squared-error sums a rank contributes to the merge
+    (DirectMSEObserver.reducible) select, after a merge, the same scale the stand-alone render selects from the same
+    fetches -- per tensor and per channel; summing two ranks' contributions == observing both shards on one rank."""
+    from ppq_amd.core import FloatingQuantizationConfig
+    from ppq_amd.observer import DirectMSEObserver
+    g = torch.Generator().manual_seed(8)
+    var = type('V', (), {'name': 'x', 'is_parameter': False})()
+    shards = [[(torch.randn(4, 16, 8, 8, generator=g) * s).to(DEV) for _ in range(3)] for s in (0.05, 30.0)]
+
+    def observed(batches, seed):
+        cfg = FloatingQuantizationConfig(calibration='floating')
+        ob = DirectMSEObserver(var, cfg)
+        torch.manual_seed(seed)
+        for b in batches: ob.observe(b)
+        return ob, cfg
+    a, ca = observed(shards[0] + shards[1], 3)          # one rank sees everything
+    a.render_quantization_config()
+    b, cb = observed(shards[0] + shards[1], 3)          # the same fetches through the merged path
+    bufs = b.reducible()
+    assert [k for _, k in bufs] == ['sum', 'sum'] and bufs[0][0].dtype == torch.float64
+    b.render_quantization_config()
+    assert torch.equal(ca.scale, cb.scale)
+    torch.manual_seed(3)                                # two ranks: contributions add up to the single-rank sums
+    r0, _ = observed(shards[0], 3)
+    r1, c1 = observed(shards[1], 4)
+    s0, s1 = r0.reducible(), r1.reducible()
+    for (x, _), (y, _) in zip(s0, s1): y += x            # what the SUM all-reduce does
+    r1.render_quantization_config()
+    assert float(c1.scale) in DirectMSEObserver.SCALE_CANDIDATES
+    w = type('V', (), {'name': 'w', 'is_parameter': True})()
+    cw = FloatingQuantizationConfig(calibration='floating', channel_axis=0)
+    ow = DirectMSEObserver(w, cw); weight = (torch.randn(8, 4, 3, 3, generator=g) * torch.logspace(-3, 2, 8).view(8, 1, 1, 1)).to(DEV)
+    ow.observe(weight); ow.render_quantization_config()
+    cw2 = FloatingQuantizationConfig(calibration='floating', channel_axis=0)
+    ow2 = DirectMSEObserver(w, cw2); ow2.observe(weight); ow2.reducible(); ow2.render_quantization_config()
+    assert torch.equal(cw.scale, cw2.scale) and cw.scale.numel() == 8 and len(set(cw.scale.tolist())) > 1

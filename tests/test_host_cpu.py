@@ -217,16 +217,24 @@ def _merge_worker(rank, world, port, q):
         def __init__(self, bufs): self.bufs = bufs
         def reducible(self): return self.bufs
 
+    class FakeRowSet:                       # the isotone observer's protocol: rows are gathered, not reduced
+        def __init__(self, rows): self.rows, self.got = rows, None
+        def reducible(self): return []
+        def gatherable(self): return [self.rows]
+        def take_gathered(self, merged): self.got = merged[0]
+
     g = torch.Generator().manual_seed(100 + rank)
     rng1 = torch.tensor([float(torch.randn(1, generator=g)) - 1, float(torch.randn(1, generator=g)) + 1])
     chan = torch.stack([torch.randn(5, generator=g) - 1, torch.randn(5, generator=g) + 1])
     hist = torch.randint(0, 1000, [64], generator=g, dtype=torch.int32)
     pct = torch.tensor([1.5 * (rank + 1), -2.0 * (rank + 1), 4.0])
+    sse = torch.tensor([0.25 * (rank + 1), 1.0], dtype=torch.float64)          # FP8 'floating': per-candidate squared errors
+    pairs = FakeRowSet(torch.tensor([[10.0 * rank + i, float(i)] for i in range(rank + 2)]))     # 2 rows on rank 0, 3 on rank 1
     obs = [FakeObserver([(rng1[0:1], 'min'), (rng1[1:2], 'max')]), FakeObserver([(chan[0], 'min'), (chan[1], 'max')]),
-           FakeObserver([(hist, 'sum')]), FakeObserver([(pct, 'sum')]), FakeObserver([])]
+           FakeObserver([(hist, 'sum')]), FakeObserver([(pct, 'sum')]), FakeObserver([]), FakeObserver([(sse, 'sum')]), pairs]
     issued = merge_observers(obs)
     shard = shard_batches(list(range(10)))
-    q.put((rank, issued, rng1.tolist(), chan.tolist(), hist.tolist(), pct.tolist(), shard))
+    q.put((rank, issued, rng1.tolist(), chan.tolist(), hist.tolist(), pct.tolist(), shard, sse.tolist(), pairs.got.tolist()))
     dist.destroy_process_group()
 
 
@@ -252,10 +260,12 @@ def test_merge_observers_gloo_world2():
     want_rng = [min(exp[0][0][0], exp[1][0][0]).item(), max(exp[0][0][1], exp[1][0][1]).item()]
     want_chan = [torch.minimum(exp[0][1][0], exp[1][1][0]).tolist(), torch.maximum(exp[0][1][1], exp[1][1][1]).tolist()]
     want_hist = (exp[0][2] + exp[1][2]).tolist()
-    for rank, issued, rng1, chan, hist, pct, shard in res:
-        assert issued == 3                                   # MIN(float) + SUM(int32) + SUM(float32)
+    for rank, issued, rng1, chan, hist, pct, shard, sse, pairs in res:
+        assert issued == 6                                   # MIN(float) + SUM(int32, float32, float64) + 2 all-gathers (row counts, rows)
         assert rng1 == want_rng and chan == want_chan and hist == want_hist
         assert pct == [4.5, -6.0, 8.0]
+        assert sse == [0.75, 2.0]
+        assert pairs == [[0.0, 0.0], [1.0, 1.0], [10.0, 0.0], [11.0, 1.0], [12.0, 2.0]]      # rank order, ragged row counts
         assert shard == list(range(rank, 10, 2))
 
 
@@ -393,6 +403,12 @@ def _mismatch_worker(rank, world, port, q):
     class FakeObserver:
         def __init__(self, bufs): self.bufs = bufs
         def reducible(self): return self.bufs
+
+    class FakeRowSet:                       # the isotone observer's protocol: rows are gathered, not reduced
+        def __init__(self, rows): self.rows, self.got = rows, None
+        def reducible(self): return []
+        def gatherable(self): return [self.rows]
+        def take_gathered(self, merged): self.got = merged[0]
     obs = [FakeObserver([(torch.zeros(64, dtype=torch.int32), 'sum')])]
     if rank == 0: obs.append(FakeObserver([(torch.zeros(64, dtype=torch.int32), 'sum')]))    # rank 1 saw no batch for it
     try:
