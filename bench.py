@@ -124,10 +124,26 @@ def barrier(world):
 TRACE_STEPS = None
 
 
+WORKLOAD = 'resnet50'      # --workload: which BASELINE.json config the line measures (default: config 2, the metric's own)
+WORKLOADS = {
+    # name: (description, calibration method or None = the args' / the quantizer's own)
+    'resnet50': ('ResNet-50 topology (53 Conv + 1 Gemm, BN folded, seeded He init), per-tensor INT8 activations, per-channel INT8 weights', None),
+    'resnet50_cfg3': ('BASELINE config 3: ResNet-50 topology, per-channel ASYMMETRIC INT8 weights + per-tensor asymmetric activations, MSE clipping search', 'mse'),
+    'vit_b16_fp8': ('BASELINE config 4: ViT-B/16 topology (86.6 M parameters), TRT_FP8 policy: FP8 E4M3 inputs of Conv / Gemm / MatMul, power-of-2 scales from the floating observer', 'floating'),
+}
+
+
 def build_workload(dev, bins, method, cache_params=False, fuse_params=True, channels_last=False):
     from ppq_amd import harness
-    graph = harness.resnet50_graph(seed=0)
-    harness.quantize_graph(graph, method, hist_bins=bins)
+    if WORKLOAD == 'vit_b16_fp8':
+        graph = harness.vit_graph(seed=0)
+        harness.quantize_graph_fp8(graph)
+    elif WORKLOAD == 'resnet50_cfg3':
+        graph = harness.resnet50_graph(seed=0)
+        harness.quantize_graph(graph, method, symmetrical=False, weight_symmetrical=False, hist_bins=bins)
+    else:
+        graph = harness.resnet50_graph(seed=0)
+        harness.quantize_graph(graph, method, hist_bins=bins)
     ex = harness.TorchExecutor(graph, dev)
     ex.cache_parameter_quantization = bool(cache_params)
     ex.fuse_parameter_quantization = bool(fuse_params)
@@ -267,6 +283,8 @@ def main():
     ap.add_argument('--batch', type=int, default=32)
     ap.add_argument('--bins', type=int, default=2048)
     ap.add_argument('--method', type=str, default='kl')
+    ap.add_argument('--workload', type=str, default='resnet50', choices=sorted(WORKLOADS),
+                    help='resnet50 = BASELINE config 2 (the metric); resnet50_cfg3 / vit_b16_fp8 = configs 3 / 4 at size')
     ap.add_argument('--repeats', type=int, default=3, help='timed passes (each exactly K steps); value = median')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cpu-ops', action='store_true')
@@ -292,6 +310,12 @@ def main():
     ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
     args = ap.parse_args()
 
+    global WORKLOAD
+    WORKLOAD = args.workload
+    if WORKLOADS[WORKLOAD][1] is not None: args.method = WORKLOADS[WORKLOAD][1]
+    if WORKLOAD != 'resnet50':              # the reference-CPU legs and the batch-1 variant describe config 2 only
+        args.no_cpu_baseline = args.no_cpu_ops = True
+        args.variants = 0
     maybe_spawn(args)
     if args.host_selftest: return host_selftest(args)
     rank, world, local = setup_dist(args.gpus, args.backend, bool(args.single_device))
@@ -349,7 +373,8 @@ def main():
         del ex
     elapsed = sorted(times)[len(times) // 2]
     if args.pmc_child: return                      # the rocprofv3 --pmc child: counters only, no JSON line
-    n_obs = sum(len(o.observers()) for o in p._observers.values())
+    n_obs = sum(1 for op in graph.operations.values() if hasattr(op, 'config') for c, v in op.config_with_variable
+                if not v.is_parameter and int(getattr(c.state, 'value', c.state)) == 4)      # activation configs this pass calibrated
     scale_checksum = float(sum(float(c.scale.sum()) for op in graph.operations.values() if hasattr(op, 'config')
                                for c, v in op.config_with_variable if not v.is_parameter and c.scale is not None
                                and int(getattr(c.state, 'value', c.state)) == 4))
@@ -414,7 +439,7 @@ def main():
     if roof is not None and world == 1 and args.pmc:
         child = ['--pmc-child', '--no-cpu-baseline', '--no-cpu-ops', '--pmc', '0', '--variants', '0', '--steps', str(min(args.steps, 2)),
                  '--warmup', '0', '--repeats', '1', '--batch', str(args.batch), '--bins', str(args.bins),
-                 '--method', args.method, '--hip-graph', '0', '--miopen-find', '0', '--fuse-params', str(args.fuse_params),
+                 '--method', args.method, '--workload', args.workload, '--hip-graph', '0', '--miopen-find', '0', '--fuse-params', str(args.fuse_params),
                  '--batch-observations', str(args.batch_observations), '--channels-last', str(args.channels_last)]
         roof['traffic'], roof['traffic_source'] = pmc_traffic(roof['kernel'], child)
 
@@ -429,16 +454,17 @@ def main():
     if rank == 0:
         samples = world * args.steps * args.batch
         out = {
-            'metric': ('calibration samples/sec (RuntimeCalibrationPass, KL 2048-bin, ResNet-50 INT8)' if args.method == 'kl' and args.bins == 2048
-                       else f'calibration samples/sec (RuntimeCalibrationPass, {args.method}, {args.bins} bins, ResNet-50 INT8)'),
+            'metric': ('calibration samples/sec (RuntimeCalibrationPass, KL 2048-bin, ResNet-50 INT8)' if (args.method == 'kl' and args.bins == 2048 and WORKLOAD == 'resnet50')
+                       else f'calibration samples/sec (RuntimeCalibrationPass, {args.method}, {args.bins} bins, {WORKLOAD})'),
             'value': round(samples / elapsed, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if WORKLOAD != 'vit_b16_fp8' else 'f32 (FP8 E4M3 simulated)', 'data': 'synthetic',
             'repeats': len(times), 'values': [round(samples / t, 2) for t in times],
             'spread_pct': round(100.0 * (max(times) - min(times)) / elapsed, 2),
-            'config': {'workload': f'ResNet-50 topology (53 Conv + 1 Gemm, BN folded, seeded He init), '
-                                   f'RuntimeCalibrationPass {args.method} {args.bins} bins, per-tensor INT8 activations, '
-                                   f'per-channel INT8 weights, {args.steps} batches x {args.batch} x 3x224x224 per GPU',
+            'config': {'workload': (f'ResNet-50 topology (53 Conv + 1 Gemm, BN folded, seeded He init), '
+                                    f'RuntimeCalibrationPass {args.method} {args.bins} bins, per-tensor INT8 activations, '
+                                    f'per-channel INT8 weights, {args.steps} batches x {args.batch} x 3x224x224 per GPU') if WORKLOAD == 'resnet50'
+                       else f'{WORKLOADS[WORKLOAD][0]}; RuntimeCalibrationPass {args.method}, {args.bins} bins, {args.steps} batches x {args.batch} x 3x224x224 per GPU',
                        'samples': samples, 'batch': args.batch, 'observed_tensors': n_obs,
                        'parallelism': f'dp{world} (batches sharded, 1 all-reduce per phase)',
                        'rccl_ranks': world, 'backend': args.backend if world > 1 else None, 'merge': merge_stats,
