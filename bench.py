@@ -395,6 +395,22 @@ def main():
                          'value': round(256 / vtimes[-1], 2), 'unit': 'samples/s', 'ms_per_step': round(vtimes[-1] / 256 * 1e3, 3),
                          'graph_replays': pv.graph_replays})
         del vb, pv
+    if args.variants and world == 1 and not args.reuse_activations:
+        # MI355X-first variant of the SAME pass (not the headline: the reference's protocol runs every batch twice):
+        # phase 2 bins the phase-1 activations kept resident in HBM instead of recomputing them with a second forward
+        graph_v, ex_v = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params, bool(args.channels_last))
+        barrier(world); tv = time.perf_counter()
+        pv = run_pass(graph_v, ex_v, batches, args.steps, args.method, False, False, True, True)
+        barrier(world); tv = time.perf_counter() - tv
+        check_v = float(sum(float(c.scale.sum()) for op in graph_v.operations.values() if hasattr(op, 'config')
+                            for c, v in op.config_with_variable if not v.is_parameter and c.scale is not None
+                            and int(getattr(c.state, 'value', c.state)) == 4))
+        variants.append({'workload': f'the same {args.steps} x {args.batch} pass with reuse_activations: phase 2 bins the phase-1 activations '
+                                     'kept in HBM, no second forward (identical scales)', 'samples': args.steps * args.batch,
+                         'value': round(args.steps * args.batch / tv, 2), 'unit': 'samples/s', 'ms_per_step': round(tv / args.steps * 1e3, 3),
+                         'replayed_batches': pv.replayed_batches, 'resident_MiB': round(pv.replay_peak_bytes / 2 ** 20),
+                         'scale_checksum': check_v})
+        del graph_v, ex_v, pv
 
     # roofline leg: the identical pass once more with hipEvent pairs around every library launch
     roof = None

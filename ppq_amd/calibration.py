@@ -74,6 +74,7 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         self._reuse_budget = reuse_budget_bytes
         self._replay: list = []            # per phase-1 batch: [(hist observer, activation tensor)]
         self._replay_bytes = 0
+        self.replay_peak_bytes = 0          # most activation bytes ever kept resident for a phase-2 replay
         self.replayed_batches = 0
         self._recording = False
         self.graph_replays = 0
@@ -113,6 +114,7 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
             size = sum(v.numel() * 4 for _, v in rec)
             if self._replay_bytes + size <= self._reuse_budget:
                 self._replay.append(rec); self._replay_bytes += size
+                self.replay_peak_bytes = max(self.replay_peak_bytes, self._replay_bytes)
             else: self._recording = False                     # budget reached: later batches run their forward again
 
     def _replay_phase2(self, batches: list) -> int:
