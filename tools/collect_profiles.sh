@@ -18,6 +18,9 @@ python tools/multi_bench.py > $O/multi_bench.txt 2>&1
 python bench.py --workload resnet50_cfg3 --pmc 0 > $O/bench_cfg3.json 2>/dev/null
 python bench.py --workload vit_b16_fp8 --pmc 0 --batch 16 > $O/bench_cfg4.json 2>/dev/null
 for b in 1 8; do python bench.py --no-cpu-baseline --no-cpu-ops --pmc 0 --variants 0 --batch $b --steps $((256 / b)) > $O/bench_batch$b.json 2>/dev/null; done
+python -W ignore tools/reference_on_hip_bench.py 32 8 2>/dev/null | tail -1 > $O/reference_on_hip.txt
+python -W ignore tools/reference_on_hip_bench.py 1 64 2>/dev/null | tail -1 >> $O/reference_on_hip.txt
+python -m pytest tests/test_gpu_reference.py -m gpu -q -W ignore -v 2>&1 | grep -E "PASSED|FAILED|SKIPPED|passed|failed" > $O/reference_tests.txt
 cd /tmp
 rocprofv3 --output-format csv --kernel-trace --stats -d $O/micro_trace -o micro -- python $R/tools/microbench.py --tensors B,Bx32 > /dev/null 2>&1
 cd $R
