@@ -463,3 +463,25 @@ def test_block_builder_blocks_satisfy_the_reference_definition():
     g = harness.resnet50_graph(seed=0); harness.quantize_graph(g, 'minmax')
     by_sp = {b.sp.name: b for b in split_graph_into_blocks(g, None, 4)}
     assert len(by_sp['down5'].rps) == 1 and by_sp['conv2'].ep.name == 'conv4'
+
+
+def test_isotone_observer_equals_reference_goldens(golden_dir):
+    """OBSERVER_TABLE['isotone'] (observer/order.py) against 12 results rendered by the reference's TorchIsotoneObserver
+    (tests/golden/make_golden.py::gen_isotone): multi-batch, single row, 3-D, class axis in the middle, logits with
+    negative entries, the no-candidate fall-back to min-max; symmetric and asymmetric -- scale and offset bit for bit.
+    The observer launches no kernel (top-2 via torch, the interval sweep on the host), so this runs on the CPU."""
+    import torch
+    from ppq_amd.core import OBSERVER_ISOTONE_OBSERVER_AXIS, LinearQuantizationConfig
+    from ppq_amd.observer import OBSERVER_TABLE
+    z = np.load(os.path.join(golden_dir, 'isotone.npz'))
+    var = type('V', (), {'name': 'x', 'is_parameter': False})()
+    for k in range(int(z['iso_n'])):
+        sym, axis, qmin, qmax = (int(v) for v in z[f'iso_{k}_meta'])
+        cfg = LinearQuantizationConfig(symmetrical=bool(sym), quant_min=qmin, quant_max=qmax, num_of_bits=8, calibration='isotone')
+        cfg.detail[OBSERVER_ISOTONE_OBSERVER_AXIS] = axis
+        ob = OBSERVER_TABLE['isotone'](var, cfg)
+        for i in range(int(z[f'iso_{k}_n'])): ob.observe(torch.from_numpy(z[f'iso_{k}_x{i}']))
+        ob.render_quantization_config()
+        assert int(getattr(cfg.state, 'value', cfg.state)) == 4
+        assert np.array_equal(cfg.scale.reshape(-1).numpy().view(np.uint32), z[f'iso_{k}_scale'].view(np.uint32)), (k, cfg.scale, z[f'iso_{k}_scale'])
+        assert np.array_equal(cfg.offset.reshape(-1).numpy(), z[f'iso_{k}_offset']), (k, cfg.offset, z[f'iso_{k}_offset'])
