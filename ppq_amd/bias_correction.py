@@ -13,7 +13,7 @@ What runs where:
     depth limit (default 1: every computing op is its own block, as in the reference's default).
 """
 from collections import defaultdict
-from typing import Callable, Dict, Iterable, List, Tuple
+from typing import Callable, Iterable, List, Tuple
 
 import torch
 

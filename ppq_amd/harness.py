@@ -24,10 +24,9 @@ from typing import Callable, Dict, List, Optional
 import torch
 import torch.nn.functional as F
 
-from .core import (LinearQuantizationConfig, QuantizationPolicy, QuantizationStates, TensorQuantizationConfig,
-                   is_initial)
+from .core import LinearQuantizationConfig, QuantizationStates, TensorQuantizationConfig, is_initial
 from .core import QuantizationProperty as P
-from .observer import OperationObserver, TensorObserverFactroy
+from .observer import TensorObserverFactroy
 from .qfunction import PPQuantFunction
 
 PASSIVE_OPERATIONS = {'MaxPool', 'GlobalMaxPool', 'Reshape', 'Flatten', 'Identity', 'Dropout', 'Slice', 'Pad', 'Resize',

@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ppq_amd import CUDA, _lib
-from ppq_amd.ffi import HIP_EXTENSION, _stream
+from ppq_amd.ffi import _stream
 x = torch.randn(4096, device='cuda'); s = torch.tensor([0.1], device='cuda'); o = torch.zeros(1, device='cuda')
 mm = torch.tensor([float('inf'), float('-inf')], device='cuda')
 hist = torch.zeros(2048, dtype=torch.int32, device='cuda')
