@@ -386,7 +386,7 @@ struct HotCounter {
         if (act == 0ull) return;
         const int cand = __builtin_amdgcn_readlane(b, __ffsll((long long)act) - 1);
         if (cand == hot_bin) return;
-        if (__popcll(__ballot(valid && b == cand)) >= min_lanes) { flush(); hot_bin = cand; }
+        if ((int)__popcll(__ballot(valid && b == cand)) >= min_lanes) { flush(); hot_bin = cand; }
     }
     __device__ __forceinline__ void add(int slot) {
         const bool hit = slot == hot_bin;

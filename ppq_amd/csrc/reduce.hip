@@ -318,6 +318,8 @@ __device__ __forceinline__ uint32_t f2key(float f) {
 __device__ __forceinline__ float key2f(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
 }
+// (an explicit unsigned max: `max` resolves to the int overload in the host pass of this translation unit)
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
@@ -962,7 +964,7 @@ void quantile_pass1_persistent_kernel(const QuantileJobs jobs) {
                             tie_hi += acc.popc_mask(__builtin_amdgcn_ballot_w64(k0 == t_hi));
                             tie_lo += acc.popc_mask(__builtin_amdgcn_ballot_w64(k0 == t_lo));
                         }
-                        if (max(max(d0, d1), max(d2, d3)) > span) {
+                        if (umax(umax(d0, d1), umax(d2, d3)) > span) {
                             if (d0 > span) rare(k0);
                             if (d1 > span) rare(k1_);
                             if (d2 > span) rare(k2);
