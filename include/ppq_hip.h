@@ -100,6 +100,24 @@ int ppqhip_fq_float_c(const float* x, const float* scale, const float* offset, f
                       int exponent, int mantissa, float clip_min, float clip_max,
                       int rounding, void* stream);
 
+/* many tensors, one launch (MI355X-native addition; the FP8 twin of ppqhip_fq_linear_multi): every job is
+ * fake-quantised exactly as ppqhip_fq_float_c would (a per-tensor job has num_channel = 1, elem_per_channel = n).
+ * Meant for the per-channel FP8 weights the TRT_FP8 policy re-quantises on every forward.  `jobs` is a HOST
+ * array; `device_table` is caller-owned device memory of ppqhip_fq_float_multi_table_bytes(num_jobs) bytes; pass
+ * upload = 1 on the first call and whenever a pointer, shape or format in `jobs` changed, 0 otherwise. */
+typedef struct ppqhip_fq_float_job {
+    const float* x;
+    const float* scale;
+    const float* offset;
+    float* out;
+    int64_t n, num_channel, elem_per_channel;
+    int32_t exponent, mantissa;
+    float clip_min, clip_max;
+} ppqhip_fq_float_job;
+int64_t ppqhip_fq_float_multi_table_bytes(int num_jobs);
+int ppqhip_fq_float_multi(const ppqhip_fq_float_job* jobs, int num_jobs, int rounding, void* device_table,
+                          int upload, void* stream);
+
 /* replace QuantizeTensor_FT_B / _FC_B, floating.cu:186-221 / :286-331 (ffi.py:308-344; no
  * Python caller in the reference).  grad_s is OVERWRITTEN.  For the per-tensor form pass
  * num_channel = 1, elem_per_channel = n. */

@@ -7,6 +7,8 @@
 // Same streaming structure as linear.hip (one contiguous tile of float4s per workgroup).
 #include "common.hpp"
 
+#include <vector>
+
 namespace ppqhip {
 
 struct FloatFmt {
@@ -232,6 +234,86 @@ __global__ __launch_bounds__(kBlock) void fq_float_bwd_kernel(
     }
 }
 
+// ---- many tensors, one launch (the design of fq_linear_multi_kernel, linear.hip) ---------------------------
+// The TRT_FP8 policy fake-quantises the weight of every Conv / Gemm / MatMul per channel on every forward
+// (ViT-B/16: 50 weights): one launch serves them all.  Device job table + workgroup-count prefix in the arguments.
+constexpr int kFqFloatMultiMax = 128;
+struct FqFloatJob {
+    const float* x;
+    float* out;
+    const float* scale;
+    const float* offset;
+    uint32_t n;
+    uint32_t vec_ok;
+    FastDiv per;          // vec_ok: float4 per channel row; else elements per channel row
+    FastDiv nc;
+    FloatFmt fmt;
+};
+struct FqFloatMultiArgs {
+    uint32_t first_block[kFqFloatMultiMax];
+    uint32_t count;
+    int rounding;
+    const FqFloatJob* jobs;
+};
+
+template <int R, int U>
+__global__ __launch_bounds__(kBlock) void fq_float_multi_kernel(const FqFloatMultiArgs args) {
+    uint32_t lo = 0, hi = args.count;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (args.first_block[mid] <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const FqFloatJob j = args.jobs[lo];                 // uniform address: scalar loads
+    const uint32_t base = (blockIdx.x - args.first_block[lo]) * (kBlock * U) + threadIdx.x;
+    const uint32_t C = j.nc.d;
+    auto one = [&](float v, float s, float o, uint32_t rb) {
+        const float q = rb ? quant_float_rne_pow2(v, __uint_as_float(rb), j.fmt) : quant_float_scalar<R>(v, s, j.fmt, args.rounding);
+        return (q - o) * s;
+    };
+    if (j.vec_ok) {
+        const uint32_t nvec = j.n >> 2;
+        const float4* xv = reinterpret_cast<const float4*>(j.x);
+        float4* ov = reinterpret_cast<float4*>(j.out);
+        float4 a[U];
+        float s[U], o[U];
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const uint32_t vv = min(base + k * kBlock, nvec - 1);
+            a[k] = xv[vv];
+            const uint32_t row = fdiv(vv, j.per);
+            const uint32_t c = row - fdiv(row, j.nc) * C;
+            s[k] = j.scale[c];
+            o[k] = j.offset[c];
+        }
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const uint32_t vv = base + k * kBlock;
+            if (vv < nvec) {
+                const uint32_t rb = float_fast_ok<R>(j.fmt) ? pow2_reciprocal_bits(s[k]) : 0u;
+                float4 r;
+                r.x = one(a[k].x, s[k], o[k], rb); r.y = one(a[k].y, s[k], o[k], rb);
+                r.z = one(a[k].z, s[k], o[k], rb); r.w = one(a[k].w, s[k], o[k], rb);
+                ov[vv] = r;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const uint32_t e0 = (base + k * kBlock) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t e = e0 + q;
+                if (e < j.n) {
+                    const uint32_t row = fdiv(e, j.per);
+                    const uint32_t c = row - fdiv(row, j.nc) * C;
+                    const float sc = j.scale[c];
+                    j.out[e] = one(j.x[e], sc, j.offset[c], float_fast_ok<R>(j.fmt) ? pow2_reciprocal_bits(sc) : 0u);
+                }
+            }
+        }
+    }
+}
+
 static int validate(int64_t n, const char* what) {
     if (n <= 0) { set_error("%s: tensor is empty", what); return PPQHIP_ERR_INVALID_VALUE; }
     if (n > 0x7fffffffLL) { set_error("%s: too many elements", what); return PPQHIP_ERR_INVALID_VALUE; }
@@ -316,6 +398,69 @@ int ppqhip_fq_float_c(const float* x, const float* scale, const float* offset, f
         launch_fc<ROUND_HALF_EVEN>(x, scale, offset, out, n, num_channel, elem_per_channel, fmt, rounding, s);
     else launch_fc<-1>(x, scale, offset, out, n, num_channel, elem_per_channel, fmt, rounding, s);
     return finish_launch("fq_float_c");
+}
+
+int64_t ppqhip_fq_float_multi_table_bytes(int num_jobs) {
+    return num_jobs > 0 ? (int64_t)sizeof(FqFloatJob) * num_jobs : 0;
+}
+
+int ppqhip_fq_float_multi(const ppqhip_fq_float_job* jobs, int num_jobs, int rounding, void* device_table, int upload,
+                          void* stream) {
+    if (num_jobs <= 0) return PPQHIP_OK;
+    if (jobs == nullptr || device_table == nullptr) {
+        set_error("fq_float_multi: jobs / device_table is null"); return PPQHIP_ERR_INVALID_VALUE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    double bytes = 0.0;
+    for (int k = 0; k < num_jobs; k++) {
+        const ppqhip_fq_float_job& j = jobs[k];
+        if (int st = validate(j.n, "fq_float_multi")) return st;
+        if (j.num_channel <= 0 || j.elem_per_channel <= 0 || j.n % (j.num_channel * j.elem_per_channel) != 0) {
+            set_error("fq_float_multi: job %d has a bad channel geometry", k); return PPQHIP_ERR_INVALID_VALUE;
+        }
+        if (!j.x || !j.out || !j.scale || !j.offset) {
+            set_error("fq_float_multi: job %d has a null pointer", k); return PPQHIP_ERR_INVALID_VALUE;
+        }
+        FloatFmt probe;
+        if (int st = make_fmt(j.exponent, j.mantissa, j.clip_min, j.clip_max, &probe, "fq_float_multi")) return st;
+        bytes += 8.0 * (double)j.n;
+    }
+    LaunchScope scope(K_FQ_FLOAT_C, bytes, s);
+    constexpr int U = 2;
+    for (int base = 0; base < num_jobs; base += kFqFloatMultiMax) {
+        const int count = (num_jobs - base) < kFqFloatMultiMax ? (num_jobs - base) : kFqFloatMultiMax;
+        FqFloatMultiArgs args;
+        args.count = (uint32_t)count; args.rounding = rounding;
+        args.jobs = (const FqFloatJob*)device_table + base;
+        std::vector<FqFloatJob> table(upload ? count : 0);
+        uint32_t blocks = 0;
+        for (int k = 0; k < count; k++) {
+            const ppqhip_fq_float_job& src = jobs[base + k];
+            const bool vec = aligned16(src.x) && aligned16(src.out) && (src.elem_per_channel % 4 == 0);
+            args.first_block[k] = blocks;
+            const uint64_t quads = ((uint64_t)src.n + 3) / 4;
+            blocks += (uint32_t)((quads + kBlock * U - 1) / (kBlock * U));
+            if (upload) {
+                FqFloatJob& d = table[k];
+                d.x = src.x; d.out = src.out; d.scale = src.scale; d.offset = src.offset;
+                d.n = (uint32_t)src.n; d.vec_ok = vec ? 1u : 0u;
+                d.per = make_fastdiv((uint32_t)(vec ? src.elem_per_channel / 4 : src.elem_per_channel));
+                d.nc = make_fastdiv((uint32_t)src.num_channel);
+                make_fmt(src.exponent, src.mantissa, src.clip_min, src.clip_max, &d.fmt, "fq_float_multi");
+            }
+        }
+        if (upload) {
+            // pageable source: the runtime stages the copy before returning, `table` may go out of scope
+            if (int st = check_hip(hipMemcpyAsync((FqFloatJob*)device_table + base, table.data(), sizeof(FqFloatJob) * count,
+                                                  hipMemcpyHostToDevice, s), "fq_float_multi table upload"))
+                return st;
+        }
+        if (rounding == ROUND_HALF_EVEN)
+            hipLaunchKernelGGL((fq_float_multi_kernel<ROUND_HALF_EVEN, U>), dim3(blocks), dim3(kBlock), 0, s, args);
+        else
+            hipLaunchKernelGGL((fq_float_multi_kernel<-1, U>), dim3(blocks), dim3(kBlock), 0, s, args);
+    }
+    return finish_launch("fq_float_multi");
 }
 
 int ppqhip_fq_float_c_bwd(const float* x, const float* scale, const float* offset, const float* grad_y,

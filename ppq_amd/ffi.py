@@ -131,6 +131,9 @@ def _workspace(device: torch.device, nbytes: int) -> torch.Tensor:
 _MINMAX_JOB = np.dtype([('x', '<u8'), ('slots', '<u8'), ('n', '<i8')])
 _FQ_JOB = np.dtype([('x', '<u8'), ('scale', '<u8'), ('offset', '<u8'), ('out', '<u8'), ('n', '<i8'),
                     ('num_channel', '<i8'), ('elem_per_channel', '<i8'), ('clip_min', '<i4'), ('clip_max', '<i4')])
+_FQ_FLOAT_JOB = np.dtype([('x', '<u8'), ('scale', '<u8'), ('offset', '<u8'), ('out', '<u8'), ('n', '<i8'),
+                          ('num_channel', '<i8'), ('elem_per_channel', '<i8'), ('exponent', '<i4'), ('mantissa', '<i4'),
+                          ('clip_min', '<f4'), ('clip_max', '<f4')])
 _QUANTILE_JOB = np.dtype([('x', '<u8'), ('dest', '<u8'), ('n', '<i8')])
 _HIST_JOB = np.dtype([('x', '<u8'), ('rows', '<u8'), ('n', '<i8'), ('p0', '<f4'), ('p1', '<f4')])
 
@@ -189,6 +192,56 @@ class LinearQuantizePlan:
         with _DeviceOf(self._arena):
             _raise(lib.ppqhip_fq_linear_multi(self._jobs.ctypes.data, len(self._jobs), self._rounding,
                                               self._table.data_ptr(), 0 if self._uploaded else 1, _stream()))
+        self._uploaded = True
+        return self._outs
+
+
+class FloatingQuantizePlan:
+    """The FP8 twin of LinearQuantizePlan (``ppqhip_fq_float_multi``): items are
+    ``(value, scale, offset, channel_axis | None, exponent, mantissa, clip_min, clip_max)`` sharing a rounding policy --
+    the per-channel FP8 weights the TRT_FP8 policy fake-quantises again on every forward (ViT-B/16: 50 of them).
+    Values identical to ``CUDA.FloatingQuantize_C`` / ``_T`` per item; same pointer / accepts() rules."""
+    accepts = staticmethod(LinearQuantizePlan.accepts)
+
+    def __init__(self, items, rounding: int = 0):
+        if not items: raise ValueError('FloatingQuantizePlan needs at least one item')
+        self._keep = []
+        dev = items[0][0].device
+        total = 0
+        for value, scale, offset, axis, *_ in items:
+            _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset')
+            if value.device != dev or scale.device != dev or offset.device != dev:
+                raise RuntimeError(_KERNEL_FAILURE + 'FloatingQuantizePlan: every tensor must live on one device')
+            if not self.accepts(value, scale, offset, axis):
+                raise RuntimeError(_KERNEL_FAILURE + 'FloatingQuantizePlan: value must be dense in storage order and '
+                                   'scale / offset contiguous (a private copy would go stale); see accepts()')
+            total += (value.numel() + 3) // 4 * 4
+        self._arena = torch.empty(total, dtype=torch.float32, device=dev)
+        self._jobs = np.zeros(len(items), dtype=_FQ_FLOAT_JOB)
+        self._outs = []
+        at = 0
+        for k, (v, scale, offset, axis, exponent, mantissa, clip_min, clip_max) in enumerate(items):
+            if exponent <= 0: raise ValueError('Floating Quantization requires exponent > 0')          # ffi.py:283
+            sc, of = scale.reshape(-1), offset.reshape(-1)
+            if axis is None: C, epc = 1, v.numel()
+            else: C, epc = _geometry(v.shape, axis)
+            if sc.numel() != C or of.numel() != C:
+                raise RuntimeError(_KERNEL_FAILURE + f'FloatingQuantizePlan: item {k} needs {C} scales / offsets')
+            out = self._arena[at: at + v.numel()].as_strided(v.shape, v.stride())
+            at += (v.numel() + 3) // 4 * 4
+            self._keep.append((v, sc, of))
+            self._outs.append(out)
+            self._jobs[k] = (v.data_ptr(), sc.data_ptr(), of.data_ptr(), out.data_ptr(), v.numel(), C, epc, int(exponent),
+                             int(mantissa), float(clip_min), float(clip_max))
+        self._rounding = int(getattr(rounding, 'value', rounding))
+        self._table = torch.empty(int(lib.ppqhip_fq_float_multi_table_bytes(len(items))), dtype=torch.uint8, device=dev)
+        self._uploaded = False
+        self.bytes = 8 * sum(v.numel() for v, _, _ in self._keep)
+
+    def run(self) -> List[torch.Tensor]:
+        with _DeviceOf(self._arena):
+            _raise(lib.ppqhip_fq_float_multi(self._jobs.ctypes.data, len(self._jobs), self._rounding,
+                                             self._table.data_ptr(), 0 if self._uploaded else 1, _stream()))
         self._uploaded = True
         return self._outs
 

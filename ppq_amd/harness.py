@@ -260,7 +260,7 @@ class TorchExecutor:
         weights / scales need no rebuild; replaced tensors or edited configs do (signature check)."""
         self._fused = {}
         if not self.fuse_parameter_quantization or self._default_quant_fn is not PPQuantFunction: return
-        from .ffi import LinearQuantizePlan
+        from .ffi import FloatingQuantizePlan, LinearQuantizePlan
         todo, sig = [], []
         for op in self._graph.operations.values():
             if not isinstance(op, QuantableOperation): continue
@@ -268,26 +268,32 @@ class TorchExecutor:
                 if not (v.is_parameter and isinstance(v.value, torch.Tensor) and v.value.is_cuda): continue
                 if not QuantizationStates.is_activated(c.state) or c in self._delegates: continue
                 pol = c.policy
-                if not pol.has_property(P.LINEAR) or pol.has_property(P.DYNAMIC): continue
+                floating = pol.has_property(P.FLOATING)
+                if not (pol.has_property(P.LINEAR) or floating) or pol.has_property(P.DYNAMIC): continue
                 if v.value.dtype != torch.float32 or v.value.requires_grad or v.value.numel() == 0: continue
                 if not (isinstance(c.scale, torch.Tensor) and isinstance(c.offset, torch.Tensor)): continue
                 axis = c.channel_axis if pol.has_property(P.PER_CHANNEL) else None
                 if not LinearQuantizePlan.accepts(v.value, c.scale, c.offset, axis): continue   # per-tensor launch instead
                 rnd = int(getattr(c.rounding, 'value', c.rounding))
-                todo.append((v, c, axis, rnd))
+                todo.append((v, c, axis, rnd, floating))
                 sig.append((v.name, id(c), v.value.data_ptr(), c.scale.data_ptr(), c.offset.data_ptr(), tuple(v.value.shape), c.scale.numel(),
-                            axis, c.quant_min, c.quant_max, rnd))
+                            axis, c.quant_min, c.quant_max, rnd, floating,
+                            (c.exponent_bits, c.mantissa_bits) if floating else None))
         if not todo:
             self._plans, self._plan_signature = [], None
             return
         if sig != self._plan_signature:
-            groups: Dict[int, list] = {}
-            for item in todo: groups.setdefault(item[3], []).append(item)
+            groups: Dict[tuple, list] = {}
+            for item in todo: groups.setdefault((item[3], item[4]), []).append(item)
             self._plans = []
-            for rnd, items in groups.items():
-                plan = LinearQuantizePlan([(v.value, c.scale, c.offset, axis, c.quant_min, c.quant_max)
-                                           for v, c, axis, _ in items], rounding=rnd)
-                self._plans.append((plan, [(v.name, id(c)) for v, c, _, _ in items]))
+            for (rnd, floating), items in groups.items():
+                if floating:        # TRT_FP8 policy: per-channel FP8 weights (one launch for all of them too)
+                    plan = FloatingQuantizePlan([(v.value, c.scale, c.offset, axis, c.exponent_bits, c.mantissa_bits,
+                                                  c.quant_min, c.quant_max) for v, c, axis, _, _ in items], rounding=rnd)
+                else:
+                    plan = LinearQuantizePlan([(v.value, c.scale, c.offset, axis, c.quant_min, c.quant_max)
+                                               for v, c, axis, _, _ in items], rounding=rnd)
+                self._plans.append((plan, [(v.name, id(c)) for v, c, _, _, _ in items]))
             self._plan_signature = sig
         for plan, keys in self._plans:
             for key, out in zip(keys, plan.run()): self._fused[key] = out

@@ -696,6 +696,39 @@ def test_linear_quantize_plan_equals_per_tensor_kernels(CUDA, rounding):
     for got, ref in zip(plan.run(), reference()): assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize('rounding', [0, 1])
+def test_floating_quantize_plan_equals_per_tensor_kernels(CUDA, rounding):
+    """FloatingQuantizePlan (ppqhip_fq_float_multi: one launch for all FP8 weights of a forward) == FloatingQuantize_C / _T
+    item by item, bit-exact: E4M3 and E5M2 in one plan, power-of-two and odd scales (both arithmetic paths), per-channel and
+    per-tensor items, elem_per_channel % 4 != 0, an unaligned view, > 128 items; in-place updates need no rebuild."""
+    from ppq_amd.ffi import FloatingQuantizePlan
+    g = torch.Generator().manual_seed(32)
+    shapes = [(64, 3, 7, 7), (768, 768), (128, 64, 3, 3), (1000, 512), (7, 5, 3), (1, 1), (33, 1, 3, 3), (2304, 768)]
+    pw = torch.tensor([.0078125, .03125, .125, 1.0, 4.0, 16.0, 64.0, 0.3])
+    items = []
+    for rep in range(17):
+        for i, shp in enumerate(shapes):
+            w = (torch.randn(*shp, generator=g) * (0.05 if i % 2 else 2.0)).to(DEV)
+            if (rep + i) % 5 == 0:
+                w = torch.cat([w.flatten(), w.flatten()[:1]])[1:].view(shp) if w.numel() > 1 else w
+            per_channel = (rep + i) % 3 != 0
+            C = shp[0] if per_channel else 1
+            scale = pw[torch.randint(0, 8, [C], generator=g)].to(DEV)
+            fmt = (4, 3, -448.0, 448.0) if (rep + i) % 2 else (5, 2, -57344.0, 57344.0)
+            items.append((w, scale, torch.zeros(C, device=DEV), 0 if per_channel else None) + fmt)
+    assert len(items) == 136
+    plan = FloatingQuantizePlan(items, rounding=rounding)
+
+    def reference():
+        return [CUDA.FloatingQuantize_C(w, s, o, ax, e, m, lo, hi, rounding) if ax is not None
+                else CUDA.FloatingQuantize_T(w, s, o, e, m, lo, hi, rounding) for w, s, o, ax, e, m, lo, hi in items]
+    for got, ref, it in zip(plan.run(), reference(), items):
+        assert got.shape == it[0].shape and torch.equal(got, ref)
+    for w, s, *_ in items[::7]:
+        w.mul_(1.5); s.mul_(2.0)
+    for got, ref in zip(plan.run(), reference()): assert torch.equal(got, ref)
+
+
 def test_fused_parameter_quantization_equals_per_weight_launches():
     """TorchExecutor(fuse_parameter_quantization=True): one launch for all weights per forward gives the
     forward outputs of the per-weight launches, follows re-rendered scales, and leaves delegated configs alone."""
