@@ -100,6 +100,23 @@ int ppqhip_fq_float_c(const float* x, const float* scale, const float* offset, f
                       int exponent, int mantissa, float clip_min, float clip_max,
                       int rounding, void* stream);
 
+/* the scale search of the FP8 `floating` observer (DirectMSEObserver, observer/floating.py:88-143), batched
+ * (MI355X-native addition): for every row of every job -- a job is `rows` x `row_len` contiguous floats: one row per
+ * per-tensor collection, one row per channel of a weight -- and every candidate scale,
+ *     out[row][c] = sum over the row of (fake_quant(x; scale = candidates[c], offset = 0) - x)^2      (double)
+ * with rows numbered consecutively over the jobs.  ONE launch per 128 jobs; the caller takes the arg-min per row.
+ * `jobs`, `candidates` are HOST arrays; `device_table`: ppqhip_float_scale_search_table_bytes(num_jobs) bytes of
+ * device scratch; `out`: device, total_rows * num_candidates doubles. */
+typedef struct ppqhip_float_search_job {
+    const float* x;
+    int64_t rows, row_len;
+    int32_t exponent, mantissa;
+    float clip_min, clip_max;
+} ppqhip_float_search_job;
+int64_t ppqhip_float_scale_search_table_bytes(int num_jobs);
+int ppqhip_float_scale_search(const ppqhip_float_search_job* jobs, int num_jobs, const float* candidates,
+                              int num_candidates, int rounding, void* device_table, double* out, void* stream);
+
 /* many tensors, one launch (MI355X-native addition; the FP8 twin of ppqhip_fq_linear_multi): every job is
  * fake-quantised exactly as ppqhip_fq_float_c would (a per-tensor job has num_channel = 1, elem_per_channel = n).
  * Meant for the per-channel FP8 weights the TRT_FP8 policy re-quantises on every forward.  `jobs` is a HOST

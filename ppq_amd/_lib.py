@@ -55,6 +55,8 @@ PROTOTYPES = {
     'ppqhip_minmax_c': (c_int, [c_f32p, c_i64, c_i64, c_i64, c_f32p, c_f32p, c_vp]),
     'ppqhip_fq_linear_multi_table_bytes': (c_i64, [c_int]),
     'ppqhip_fq_linear_multi': (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_vp]),
+    'ppqhip_float_scale_search_table_bytes': (c_i64, [c_int]),
+    'ppqhip_float_scale_search': (c_int, [c_vp, c_int, c_vp, c_int, c_int, c_vp, c_vp, c_vp]),
     'ppqhip_fq_float_multi_table_bytes': (c_i64, [c_int]),
     'ppqhip_fq_float_multi': (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     'ppqhip_quantile_multi_workspace_bytes': (c_i64, [c_int, c_i64]),

@@ -314,6 +314,77 @@ __global__ __launch_bounds__(kBlock) void fq_float_multi_kernel(const FqFloatMul
     }
 }
 
+// ---- the scale search of the FP8 'floating' observer, batched ------------------------------------------------
+// DirectMSEObserver (observer/floating.py:88-143) fake-quantises its collected values with each of 7 candidate
+// scales and keeps the one with the least mean squared error: 7 x (quantise, subtract, square, mean) launches and a
+// host synchronisation PER CONFIG -- 148 configs on ViT-B/16, 29 ms of a 100 ms calibration.  Here ONE launch
+// serves every config of the graph: a workgroup owns one row (a per-tensor collection, or one channel of a weight),
+// reads it once, evaluates all candidates on the value in registers and writes the squared-error sums (double,
+// fixed summation order: deterministic).  The dequantised value is formed in float32 exactly as the fake-quant
+// kernels form it, so err = float32 result of fq - x as the reference's `qt - fp`.
+constexpr int kSearchMaxCandidates = 8;
+constexpr int kSearchMaxJobs = 128;
+struct FloatSearchJob {
+    const float* x;       // rows x row_len, contiguous
+    uint32_t row_len;
+    FloatFmt fmt;
+};
+struct FloatSearchArgs {
+    uint32_t first_row[kSearchMaxJobs];      // prefix of row counts: workgroup -> job
+    uint32_t count;
+    int rounding, num_candidates;
+    float candidate[kSearchMaxCandidates];
+    const FloatSearchJob* jobs;
+    double* out;                              // [total rows][num_candidates]
+    uint32_t out_row0;
+};
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void float_scale_search_kernel(const FloatSearchArgs args) {
+    __shared__ double red[kSearchMaxCandidates][kBlock / kWave];
+    uint32_t lo = 0, hi = args.count;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (args.first_row[mid] <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const FloatSearchJob j = args.jobs[lo];
+    const float* __restrict__ row = j.x + (size_t)(blockIdx.x - args.first_row[lo]) * j.row_len;
+    double acc[kSearchMaxCandidates];
+    uint32_t rb[kSearchMaxCandidates];
+#pragma unroll
+    for (int c = 0; c < kSearchMaxCandidates; c++) {
+        acc[c] = 0.0;
+        rb[c] = (c < args.num_candidates && float_fast_ok<R>(j.fmt)) ? pow2_reciprocal_bits(args.candidate[c]) : 0u;
+    }
+    for (uint32_t i = threadIdx.x; i < j.row_len; i += kBlock) {
+        const float v = row[i];
+#pragma unroll
+        for (int c = 0; c < kSearchMaxCandidates; c++) {
+            if (c < args.num_candidates) {
+                const float s = args.candidate[c];
+                const float q = rb[c] ? quant_float_rne_pow2(v, __uint_as_float(rb[c]), j.fmt)
+                                      : quant_float_scalar<R>(v, s, j.fmt, args.rounding);
+                const float e = (q - 0.0f) * s - v;          // offset 0 (floating.py:112,129); float32 like the fake-quant output
+                acc[c] += (double)e * (double)e;
+            }
+        }
+    }
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < kSearchMaxCandidates; c++) {
+        double v = acc[c];
+#pragma unroll
+        for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+        if (lane == 0) red[c][wid] = v;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < args.num_candidates) {
+        double v = 0.0;
+        for (int w = 0; w < kBlock / kWave; w++) v += red[threadIdx.x][w];
+        args.out[(size_t)(args.out_row0 + blockIdx.x) * args.num_candidates + threadIdx.x] = v;
+    }
+}
+
 static int validate(int64_t n, const char* what) {
     if (n <= 0) { set_error("%s: tensor is empty", what); return PPQHIP_ERR_INVALID_VALUE; }
     if (n > 0x7fffffffLL) { set_error("%s: too many elements", what); return PPQHIP_ERR_INVALID_VALUE; }
@@ -461,6 +532,59 @@ int ppqhip_fq_float_multi(const ppqhip_fq_float_job* jobs, int num_jobs, int rou
             hipLaunchKernelGGL((fq_float_multi_kernel<-1, U>), dim3(blocks), dim3(kBlock), 0, s, args);
     }
     return finish_launch("fq_float_multi");
+}
+
+int64_t ppqhip_float_scale_search_table_bytes(int num_jobs) {
+    return num_jobs > 0 ? (int64_t)sizeof(FloatSearchJob) * num_jobs : 0;
+}
+
+int ppqhip_float_scale_search(const ppqhip_float_search_job* jobs, int num_jobs, const float* candidates, int num_candidates,
+                              int rounding, void* device_table, double* out, void* stream) {
+    if (num_jobs <= 0) return PPQHIP_OK;
+    if (jobs == nullptr || candidates == nullptr || device_table == nullptr || out == nullptr) {
+        set_error("float_scale_search: null argument"); return PPQHIP_ERR_INVALID_VALUE;
+    }
+    if (num_candidates <= 0 || num_candidates > kSearchMaxCandidates) {
+        set_error("float_scale_search: 1 .. %d candidate scales are supported, got %d", kSearchMaxCandidates, num_candidates);
+        return PPQHIP_ERR_INVALID_VALUE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    double bytes = 0.0;
+    for (int k = 0; k < num_jobs; k++) {
+        const ppqhip_float_search_job& j = jobs[k];
+        if (j.x == nullptr || j.rows <= 0 || j.row_len <= 0 || j.rows > 0x7fffffffLL || j.row_len > 0x7fffffffLL) {
+            set_error("float_scale_search: job %d is empty or too large", k); return PPQHIP_ERR_INVALID_VALUE;
+        }
+        FloatFmt probe;
+        if (int st = make_fmt(j.exponent, j.mantissa, j.clip_min, j.clip_max, &probe, "float_scale_search")) return st;
+        bytes += 4.0 * (double)j.rows * (double)j.row_len;
+    }
+    LaunchScope scope(K_FLOAT_SCALE_SEARCH, bytes, s);
+    uint32_t row0 = 0;
+    for (int base = 0; base < num_jobs; base += kSearchMaxJobs) {
+        const int count = (num_jobs - base) < kSearchMaxJobs ? (num_jobs - base) : kSearchMaxJobs;
+        FloatSearchArgs args;
+        args.count = (uint32_t)count; args.rounding = rounding; args.num_candidates = num_candidates;
+        for (int c = 0; c < kSearchMaxCandidates; c++) args.candidate[c] = c < num_candidates ? candidates[c] : 1.0f;
+        args.jobs = (const FloatSearchJob*)device_table + base;
+        args.out = out; args.out_row0 = row0;
+        std::vector<FloatSearchJob> table(count);
+        uint32_t rows = 0;
+        for (int k = 0; k < count; k++) {
+            const ppqhip_float_search_job& src = jobs[base + k];
+            args.first_row[k] = rows;
+            rows += (uint32_t)src.rows;
+            table[k].x = src.x; table[k].row_len = (uint32_t)src.row_len;
+            make_fmt(src.exponent, src.mantissa, src.clip_min, src.clip_max, &table[k].fmt, "float_scale_search");
+        }
+        if (int st = check_hip(hipMemcpyAsync((FloatSearchJob*)device_table + base, table.data(), sizeof(FloatSearchJob) * count,
+                                              hipMemcpyHostToDevice, s), "float_scale_search table upload"))
+            return st;
+        if (rounding == ROUND_HALF_EVEN) hipLaunchKernelGGL((float_scale_search_kernel<ROUND_HALF_EVEN>), dim3(rows), dim3(kBlock), 0, s, args);
+        else hipLaunchKernelGGL((float_scale_search_kernel<-1>), dim3(rows), dim3(kBlock), 0, s, args);
+        row0 += rows;
+    }
+    return finish_launch("float_scale_search");
 }
 
 int ppqhip_fq_float_c_bwd(const float* x, const float* scale, const float* offset, const float* grad_y,

@@ -134,6 +134,8 @@ _FQ_JOB = np.dtype([('x', '<u8'), ('scale', '<u8'), ('offset', '<u8'), ('out', '
 _FQ_FLOAT_JOB = np.dtype([('x', '<u8'), ('scale', '<u8'), ('offset', '<u8'), ('out', '<u8'), ('n', '<i8'),
                           ('num_channel', '<i8'), ('elem_per_channel', '<i8'), ('exponent', '<i4'), ('mantissa', '<i4'),
                           ('clip_min', '<f4'), ('clip_max', '<f4')])
+_FLOAT_SEARCH_JOB = np.dtype([('x', '<u8'), ('rows', '<i8'), ('row_len', '<i8'), ('exponent', '<i4'), ('mantissa', '<i4'),
+                              ('clip_min', '<f4'), ('clip_max', '<f4')])
 _QUANTILE_JOB = np.dtype([('x', '<u8'), ('dest', '<u8'), ('n', '<i8')])
 _HIST_JOB = np.dtype([('x', '<u8'), ('rows', '<u8'), ('n', '<i8'), ('p0', '<f4'), ('p1', '<f4')])
 
@@ -658,6 +660,31 @@ class _HipExtension:
             _raise(lib.ppqhip_channel_sum(v.data_ptr(), v.numel(), C, epc, sums.data_ptr(), _stream()))
 
     @ staticmethod
+    def FloatScaleSearch(items, candidates, rounding: int = 0) -> torch.Tensor:
+        """ppqhip_float_scale_search: `items` = [(values [rows, row_len] contiguous float32, exponent, mantissa, clip_min,
+        clip_max)]; returns float64 [total rows, len(candidates)]: the squared fake-quant error sums of every row under
+        every candidate scale, rows numbered over the items in order.  One launch per 128 items."""
+        if not items: raise ValueError('FloatScaleSearch needs at least one item')
+        dev = items[0][0].device
+        jobs = np.zeros(len(items), dtype=_FLOAT_SEARCH_JOB)
+        keep, total = [], 0
+        for k, (v, e, m, lo, hi) in enumerate(items):
+            _f32(v, 'Value')
+            if v.ndim != 2 or not v.is_contiguous() or v.device != dev:
+                raise RuntimeError(_KERNEL_FAILURE + 'FloatScaleSearch: values must be contiguous [rows, row_len] tensors on one device')
+            if e <= 0: raise ValueError('Floating Quantization requires exponent > 0')
+            keep.append(v)
+            jobs[k] = (v.data_ptr(), v.shape[0], v.shape[1], int(e), int(m), float(lo), float(hi))
+            total += v.shape[0]
+        cand = np.asarray(candidates, dtype=np.float32)
+        out = torch.empty(total, len(cand), dtype=torch.float64, device=dev)
+        table = _workspace(dev, int(lib.ppqhip_float_scale_search_table_bytes(len(items))))
+        with _DeviceOf(out):
+            _raise(lib.ppqhip_float_scale_search(jobs.ctypes.data, len(jobs), cand.ctypes.data, len(cand),
+                                                 int(getattr(rounding, 'value', rounding)), table.data_ptr(), out.data_ptr(), _stream()))
+        return out
+
+    @ staticmethod
     def KL_Losses(hist, num_of_bits: int) -> torch.Tensor:
         """hist: int32 [num_hist, bins] (or [bins]) -> float64 [num_hist, candidates]."""
         _check(hist, torch.int32, 'Histogram(Expect to be INT32)')
@@ -900,6 +927,10 @@ class CUDA:
     def Histogram_Rows_Finish(rows, histogram):
         HIP_EXTENSION.Histogram_Rows_Finish(rows, histogram)
         return histogram
+
+    @ staticmethod
+    def FloatScaleSearch(items, candidates, rounding: int = 0):
+        return HIP_EXTENSION.FloatScaleSearch(items, candidates, rounding)
 
     @ staticmethod
     def KLLosses(histogram, num_of_bits: int = 8):

@@ -1308,3 +1308,58 @@ def test_floating_observer_merged_squared_errors_pick_the_same_scale():
     cw2 = FloatingQuantizationConfig(calibration='floating', channel_axis=0)
     ow2 = DirectMSEObserver(w, cw2); ow2.observe(weight); ow2.reducible(); ow2.render_quantization_config()
     assert torch.equal(cw.scale, cw2.scale) and cw.scale.numel() == 8 and len(set(cw.scale.tolist())) > 1
+
+
+def test_float_scale_search_kernel_and_batched_floating_render(CUDA):
+    """ppqhip_float_scale_search: the squared fake-quant error of every row under every candidate == the sum over
+    (FloatingQuantize_T(row, s) - row)^2 -- the float32 difference the reference forms, squared and summed in float64 (1e-12: only the
+    summation order differs), for E4M3 / E5M2, power-of-two
+    and odd candidates, HALF_EVEN and HALF_UP, rows of 1 .. 40000 values, > 128 items.  And render_observers() -- one search
+    launch + one device->host copy for all 'floating' configs -- picks exactly the scales the stand-alone
+    DirectMSEObserver.render_quantization_config() (the reference's literal arithmetic) picks."""
+    from ppq_amd.core import FloatingQuantizationConfig
+    from ppq_amd.observer import DirectMSEObserver, render_observers
+    g = torch.Generator().manual_seed(12)
+    items = []
+    for k in range(140):
+        rows, row_len = [(1, 40000), (7, 33), (64, 768), (3, 1), (16, 4097)][k % 5]
+        v = (torch.randn(rows, row_len, generator=g) * float(10 ** ((k % 7) - 3))).to(DEV)
+        items.append((v,) + ((4, 3, -448.0, 448.0) if k % 2 else (5, 2, -57344.0, 57344.0)))
+    cands = [.0078125, .03125, .125, 1.0, 4.0, 16.0, 64.0, 0.3]
+    zero = torch.zeros(1, device=DEV)
+    for rounding in (0, 1):
+        got = CUDA.FloatScaleSearch(items, cands, rounding)
+        assert got.shape == (sum(it[0].shape[0] for it in items), len(cands)) and got.dtype == torch.float64
+        starts = np.cumsum([0] + [it[0].shape[0] for it in items])
+        for k in range(0, len(items), 9):
+            (v, e, m, lo, hi), at = items[k], int(starts[k])
+            for c, s in enumerate(cands):
+                q = CUDA.FloatingQuantize_T(v, torch.full([1], s, device=DEV), zero, e, m, lo, hi, rounding)
+                want = torch.sum(torch.square((q - v).double()), dim=-1)          # `qt - fp` in float32 as the reference forms it
+                assert torch.allclose(got[at: at + v.shape[0], c], want, rtol=1e-12, atol=0), (e, m, s, rounding)
+    # batched render == stand-alone render
+    act = type('V', (), {'name': 'a', 'is_parameter': False})()
+    par = type('V', (), {'name': 'w', 'is_parameter': True})()
+
+    def build():
+        gg = torch.Generator().manual_seed(77)
+        obs = []
+        for k in range(12):
+            cfg = FloatingQuantizationConfig(calibration='floating')
+            ob = DirectMSEObserver(act, cfg)
+            torch.manual_seed(100 + k)
+            for _ in range(3): ob.observe((torch.randn(2, 8, 16, 16, generator=gg) * float(4 ** (k % 6 - 3))).to(DEV))
+            obs.append(ob)
+        for k in range(6):
+            cfg = FloatingQuantizationConfig(calibration='floating', channel_axis=0)
+            ob = DirectMSEObserver(par, cfg)
+            ob.observe((torch.randn(10, 4, 3, 3, generator=gg) * torch.logspace(-3, 2, 10).view(10, 1, 1, 1)).to(DEV))
+            obs.append(ob)
+        return obs
+    alone, batched = build(), build()
+    for ob in alone: ob.render_quantization_config()
+    render_observers(batched)
+    for a, b in zip(alone, batched):
+        assert b._quant_cfg.state.value == 4
+        assert torch.equal(a._quant_cfg.scale, b._quant_cfg.scale) and torch.equal(a._quant_cfg.offset, b._quant_cfg.offset)
+    assert len({float(ob._quant_cfg.scale.flatten()[0]) for ob in batched}) >= 4          # the candidates were really exercised
