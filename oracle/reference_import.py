@@ -93,6 +93,8 @@ def to_reference_graph(hgraph):
         elif op.type == 'Gemm': attrs = {'alpha': 1.0, 'beta': 1.0, 'transA': 0, 'transB': 1}
         elif op.type == 'Flatten': attrs = {'axis': 1}
         elif op.type in ('Relu', 'Add', 'GlobalAveragePool'): attrs = {}
+        elif op.type == 'Concat': attrs = {'axis': int(a.get('axis', 1))}
+        elif op.type == 'Resize': attrs = {'mode': a.get('mode', 'nearest'), 'scale': a.get('scale', 2)}       # topology only: not executable there
         else: raise NotImplementedError(f'to_reference_graph: {op.type}')
         g.create_operation(op_type=op.type, name=op.name, attributes=attrs,
                            inputs=[var(v) for v in op.inputs], outputs=[var(v) for v in op.outputs])
@@ -132,6 +134,20 @@ def quantize_reference_graph(g, device: str, sample: torch.Tensor, bins: int = 2
                   ParameterQuantizePass()]).optimize(graph=g, dataloader=[sample], executor=ex, calib_steps=8,
                                                      collate_fn=None, verbose=False)
     return g, ex
+
+
+def quantize_reference_topology(g):
+    """Dispatch + per-op TQCs WITHOUT tracing or running anything (for graph-only algorithms such as the block
+    builder; lets topologies through whose ops the conversion above cannot make executable, e.g. Resize)."""
+    import ppq.lib as PFL
+    from ppq import TargetPlatform
+    from ppq.api import dispatch_graph
+    g = dispatch_graph(g, TargetPlatform.TRT_INT8, 'conservative')
+    quantizer = PFL.Quantizer(platform=TargetPlatform.TRT_INT8, graph=g)
+    for op in list(g.operations.values()):
+        if op.platform not in (TargetPlatform.FP32, TargetPlatform.SOI):
+            quantizer.quantize_operation(op.name, platform=op.platform)
+    return g
 
 
 def calibrate(g, ex, batches: List[torch.Tensor], method: Optional[str] = 'kl') -> float:

@@ -485,3 +485,37 @@ def test_isotone_observer_equals_reference_goldens(golden_dir):
         assert int(getattr(cfg.state, 'value', cfg.state)) == 4
         assert np.array_equal(cfg.scale.reshape(-1).numpy().view(np.uint32), z[f'iso_{k}_scale'].view(np.uint32)), (k, cfg.scale, z[f'iso_{k}_scale'])
         assert np.array_equal(cfg.offset.reshape(-1).numpy(), z[f'iso_{k}_offset']), (k, cfg.offset, z[f'iso_{k}_offset'])
+
+
+def test_block_split_equals_the_reference_on_resnet50_and_yolov6s():
+    """ppq_amd.blocks (one forward sweep) vs the reference's BlockBuilder / split_graph_into_blocks
+    (algorithm/training.py:191-315, optim/training.py:177-222) on the ResNet-50 topology -- residual fan-out / fan-in,
+    down-sample branches -- for depth limits 1, 2, 3, 4, 5 and 8: the same blocks in the same order, each with the same
+    start, end and member set (the order of members inside a block follows each graph's own topological sort)."""
+    import torch
+    from oracle import reference_import as RI
+    if RI.find_reference() is None: pytest.skip('reference not present on this machine')
+    from ppq_amd import harness
+    from ppq_amd.blocks import split_graph_into_blocks
+    RI.load()
+    from ppq.quantization.optim.training import TrainingBasedPass
+    rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(harness.resnet50_graph(seed=0)), 'cpu', torch.rand(1, 3, 224, 224),
+                                          method='minmax')
+    hg = harness.resnet50_graph(seed=0)
+    harness.quantize_graph(hg, 'minmax')
+    p = TrainingBasedPass()
+    for limit in (1, 2, 3, 4, 5, 8):
+        ref = [(b.sp.name, b.ep.name, frozenset(o.name for o in b.rps)) for b in p.split_graph_into_blocks(rg, rex._executing_order, limit)]
+        ours = [(b.sp.name, b.ep.name, frozenset(o.name for o in b.rps)) for b in split_graph_into_blocks(hg, hg.topological_sort(), limit)]
+        assert ref == ours, (limit, [a for a, b in zip(ref, ours) if a != b][:1], [b for a, b in zip(ref, ours) if a != b][:1])
+    assert len(ours) == 20
+    # BASELINE config 5's topology (EfficientRep + SPPF fan-out closing at its Concat, Rep-PAN neck with Resize, six heads);
+    # graph-only on the reference side (no tracing: Resize is not executable through the conversion)
+    rg = RI.quantize_reference_topology(RI.to_reference_graph(harness.yolov6s_graph(seed=0)))
+    hg = harness.yolov6s_graph(seed=0)
+    harness.quantize_graph(hg, 'minmax')
+    order = rg.topological_sort()
+    for limit, count in ((1, 56), (2, 32), (4, 27), (5, 27), (8, 20)):
+        ref = [(b.sp.name, b.ep.name, frozenset(o.name for o in b.rps)) for b in p.split_graph_into_blocks(rg, order, limit)]
+        ours = [(b.sp.name, b.ep.name, frozenset(o.name for o in b.rps)) for b in split_graph_into_blocks(hg, hg.topological_sort(), limit)]
+        assert ref == ours and len(ours) == count, (limit, len(ref), len(ours))
