@@ -499,13 +499,12 @@ def test_block_split_equals_the_reference_on_resnet50_and_yolov6s():
     from ppq_amd.blocks import split_graph_into_blocks
     RI.load()
     from ppq.quantization.optim.training import TrainingBasedPass
-    rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(harness.resnet50_graph(seed=0)), 'cpu', torch.rand(1, 3, 224, 224),
-                                          method='minmax')
+    rg = RI.quantize_reference_topology(RI.to_reference_graph(harness.resnet50_graph(seed=0)))
     hg = harness.resnet50_graph(seed=0)
     harness.quantize_graph(hg, 'minmax')
     p = TrainingBasedPass()
     for limit in (1, 2, 3, 4, 5, 8):
-        ref = [(b.sp.name, b.ep.name, frozenset(o.name for o in b.rps)) for b in p.split_graph_into_blocks(rg, rex._executing_order, limit)]
+        ref = [(b.sp.name, b.ep.name, frozenset(o.name for o in b.rps)) for b in p.split_graph_into_blocks(rg, rg.topological_sort(), limit)]
         ours = [(b.sp.name, b.ep.name, frozenset(o.name for o in b.rps)) for b in split_graph_into_blocks(hg, hg.topological_sort(), limit)]
         assert ref == ours, (limit, [a for a, b in zip(ref, ours) if a != b][:1], [b for a, b in zip(ref, ours) if a != b][:1])
     assert len(ours) == 20
