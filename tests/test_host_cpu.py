@@ -518,3 +518,45 @@ def test_block_split_equals_the_reference_on_resnet50_and_yolov6s():
         ref = [(b.sp.name, b.ep.name, frozenset(o.name for o in b.rps)) for b in p.split_graph_into_blocks(rg, order, limit)]
         ours = [(b.sp.name, b.ep.name, frozenset(o.name for o in b.rps)) for b in split_graph_into_blocks(hg, hg.topological_sort(), limit)]
         assert ref == ours and len(ours) == count, (limit, len(ref), len(ours))
+
+
+def _isotone_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ppq_amd.core import LinearQuantizationConfig
+    from ppq_amd.distributed import merge_observers
+    from ppq_amd.observer import OBSERVER_TABLE
+    g = torch.Generator().manual_seed(55)
+    batches = [torch.softmax(torch.randn(16 + 3 * i, 10, generator=g) * 3, dim=-1) for i in range(5)]     # ragged row counts
+    cfg = LinearQuantizationConfig(symmetrical=True, quant_min=-128, quant_max=127, num_of_bits=8, calibration='isotone')
+    ob = OBSERVER_TABLE['isotone'](type('V', (), {'name': 'x', 'is_parameter': False})(), cfg)
+    for i, b in enumerate(batches):
+        if i % world == rank: ob.observe(b)
+    issued = merge_observers([ob])
+    ob.render_quantization_config()
+    q.put((rank, issued, float(cfg.scale), float(cfg.offset)))
+    dist.destroy_process_group()
+
+
+def test_isotone_observer_data_parallel_gather_equals_union():
+    """Two gloo ranks observe disjoint (ragged) shards with the real isotone observer; after merge_observers (all-gather of
+    the top-2 pairs) both render the scale a single process renders from all batches."""
+    import torch.multiprocessing as mp
+    from ppq_amd.core import LinearQuantizationConfig
+    from ppq_amd.observer import OBSERVER_TABLE
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 77) % 2000)
+    procs = [ctx.Process(target=_isotone_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)])
+    for p in procs: p.join(timeout=60)
+    g = torch.Generator().manual_seed(55)
+    batches = [torch.softmax(torch.randn(16 + 3 * i, 10, generator=g) * 3, dim=-1) for i in range(5)]
+    cfg = LinearQuantizationConfig(symmetrical=True, quant_min=-128, quant_max=127, num_of_bits=8, calibration='isotone')
+    ob = OBSERVER_TABLE['isotone'](type('V', (), {'name': 'x', 'is_parameter': False})(), cfg)
+    for b in batches: ob.observe(b)
+    ob.render_quantization_config()
+    for rank, issued, scale, offset in res:
+        assert issued == 2 and scale == float(cfg.scale) and offset == float(cfg.offset), (rank, issued, scale, float(cfg.scale))
