@@ -33,6 +33,11 @@ def test_no_cpu_fallback_and_error_convention():
         CUDA.LinearQuantize_T(t.double(), torch.ones(1), torch.zeros(1))
     with pytest.raises(RuntimeError, match='empty'):
         CUDA.Histogram_T(torch.zeros(0), torch.zeros(4, dtype=torch.int32), 0.1)
+    from ppq_amd.ffi import FloatingQuantizePlan, LinearQuantizePlan
+    for call in (lambda: CUDA.FloatScaleSearch([(torch.zeros(2, 8), 4, 3, -448., 448.)], [1.0]),
+                 lambda: FloatingQuantizePlan([(torch.zeros(2, 8), torch.ones(2), torch.zeros(2), 0, 4, 3, -448., 448.)]),
+                 lambda: LinearQuantizePlan([(torch.zeros(2, 8), torch.ones(2), torch.zeros(2), 0, -128, 127)])):
+        with pytest.raises(RuntimeError, match='not on the GPU'): call()        # the multi-tensor entry points refuse host tensors too
     cfg = LinearQuantizationConfig()
     assert qfunction.PPQuantFunction(t, cfg) is t              # INITIAL state: untouched (quant.py:358-359)
     cfg.state = QuantizationStates.ACTIVATED; cfg.scale = torch.ones(1); cfg.offset = torch.zeros(1)
