@@ -429,7 +429,7 @@ constexpr int kQTrash = 64;
 //
 // Speculation (round 2): for the extreme order statistics calibration asks for (q = 0.9999) the answer lies among a
 // few thousand elements, and reading the whole tensor again just to look at them is what kept this kernel at
-// ~0.5 passes^-1 of the roofline.  A SAMPLE launch (1 KB-element heads of the workgroup chunks, ~1 % of the data)
+// ~0.5 passes^-1 of the roofline.  A SAMPLE launch (64 jittered 64-B granules per 128 KB chunk, ~1-3 % of the data)
 // histograms the top 12 key bits, and how many of each bucket's keys are the bucket's round key; select0
 // picks KEY thresholds T_hi / T_lo such that ~1.3-2x the wanted number of elements lies beyond them; pass 1
 // then, while building the exact histogram, STAGES every key beyond a threshold for a list (one compare per float4 in
@@ -583,11 +583,22 @@ __device__ __forceinline__ void quantile_sample_body(const QuantileCtx& c, uint3
     const uint32_t per = (tiles + nblk - 1) / nblk;
     float4 a[kQSampleStride];
     bool ok[kQSampleStride];
+    // 64 granules of 64 B (4 float4: one memory sector each) per chunk, one every chunk / 64 with a hashed offset inside
+    // its window -- NOT the contiguous head of the chunk: activations are channel-structured ([N, C, H, W]; the extreme
+    // quantile lives in a few channels), a contiguous 4 KB run sees one channel's rows and on real networks the
+    // thresholds came out wrong often enough to send half of the data through the fall-back passes (ResNet-50, 72
+    // tensors: 978 us per forward); the jitter breaks any period the channel stride shares with the window.
+    const uint32_t chunk_vec = per * tile, window = chunk_vec / 64u, granule = threadIdx.x >> 2, sub = threadIdx.x & 3u;
 #pragma unroll
     for (uint32_t j = 0; j < kQSampleStride; j++) {
-        const uint32_t lo = (bidx + j) * per * tile;
-        const uint32_t v = lo + threadIdx.x;
-        ok[j] = bidx + j < nblk && threadIdx.x < kQSampleVec && v < nvec;
+        const uint32_t lo = (bidx + j) * chunk_vec;
+        uint32_t v = lo + threadIdx.x;                                  // tiny chunks: the contiguous head
+        if (window >= 8u) {
+            const uint32_t slots = window / 4u;                         // 64-B aligned positions inside the window
+            const uint32_t h = ((granule * 2654435761u) ^ ((bidx + j) * 40503u + 0x9E3779B9u)) >> 9;
+            v = lo + granule * window + (h % slots) * 4u + sub;
+        }
+        ok[j] = bidx + j < nblk && threadIdx.x < kQSampleVec && v < nvec && v < lo + chunk_vec;
         a[j] = reinterpret_cast<const float4*>(c.x)[ok[j] ? v : 0u];
     }
 #pragma unroll
