@@ -565,3 +565,39 @@ def test_isotone_observer_data_parallel_gather_equals_union():
     ob.render_quantization_config()
     for rank, issued, scale, offset in res:
         assert issued == 2 and scale == float(cfg.scale) and offset == float(cfg.offset), (rank, issued, scale, float(cfg.scale))
+
+
+def test_harness_quantizer_assigns_the_reference_config_states_on_resnet50():
+    """harness.quantize_graph (TensorRT-style policy + the state edits of QuantizeSimplifyPass / QuantizeFusionPass) vs the
+    reference's own dispatcher + TensorRT quantizer + those passes on the ResNet-50 topology: the same 368 (operation, variable)
+    configs with the same state, policy bits, range and channel axis -- except that the reference driver has already run
+    its ParameterQuantizePass (54 weight configs ACTIVATED there, still INITIAL here)."""
+    import torch
+    from oracle import reference_import as RI
+    if RI.find_reference() is None: pytest.skip('reference not present on this machine')
+    from ppq_amd import harness
+    RI.load()
+    rg, _ = RI.quantize_reference_graph(RI.to_reference_graph(harness.resnet50_graph(seed=0)), 'cpu', torch.rand(1, 3, 64, 64), method='kl')
+    hg = harness.resnet50_graph(seed=0)
+    harness.quantize_graph(hg, 'kl', hist_bins=2048)
+
+    def table(graph):
+        out = {}
+        for op in graph.operations.values():
+            if not hasattr(op, 'config'): continue
+            for i, (c, v) in enumerate(op.config_with_variable):
+                out[(op.name, v.name, i)] = (c.state.name, int(getattr(c.policy, '_policy', 0)), c.quant_min, c.quant_max, c.num_of_bits,
+                                             c.channel_axis if v.is_parameter and i == 1 else None, v.is_parameter)
+        return out
+    ours, ref = table(hg), table(rg)
+    assert set(ours) == set(ref) and len(ours) == 368
+    weights = 0
+    for k, o in ours.items():
+        r = ref[k]
+        if o[-1] and o[0] == 'INITIAL':                       # a weight: rendered there already
+            assert r[0] == 'ACTIVATED', (k, o, r); weights += 1
+            assert o[1:] == r[1:], (k, o, r)
+        else:
+            assert o[0] == r[0], (k, o, r)
+            if o[0] != 'FP32': assert o[1:] == r[1:], (k, o, r)
+    assert weights == 54
