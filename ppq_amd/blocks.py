@@ -20,7 +20,7 @@ from typing import Dict, Iterable, List, Optional, Tuple
 import torch
 
 OPTIM_ADVOPT_GRAPH_MAXDEPTH = 4                                  # ppq/core/common.py
-COMPUTING_OP = {'Conv', 'Gemm', 'ConvTranspose', 'MatMul'}      # ppq/core/common.py:56
+COMPUTING_OP = {'Conv', 'Gemm', 'ConvTranspose', 'MatMul', 'Attention', 'PPQBiasFusedMatMul'}      # ppq/core/common.py:55
 
 
 class TrainableBlock:

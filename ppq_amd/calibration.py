@@ -280,44 +280,3 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
             self.calibrate(desc='Calibration Progress(Phase 2)', dataloader=dataloader, executor=executor,
                            hooks=hooks, output_names=None)
             self._render()
-
-
-class IsotoneCalibrationPass(RuntimeCalibrationPass):
-    """optim/calibration.py:325-423: switches the calibration of classification outputs to the order-preserving
-    'isotone' observer -- by default the output of every Softmax whose config is not dominated by another one, or the
-    variables named in `variables` (with `axis` as the classification axis).  Like the reference's, this pass only
-    rewrites the configs (state INITIAL, algorithm 'Isotone'); the RuntimeCalibrationPass that follows observes them."""
-    def __init__(self, variables: List[str] = None, axis: int = -1, verbose: bool = True, calib_steps: int = 32) -> None:
-        super().__init__(calib_steps=calib_steps)
-        self.name = 'Isotone Calibration Pass'
-        self.variables = variables
-        self.axis = axis
-        self.verbose = verbose
-
-    def optimize(self, graph, **kwargs) -> None:
-        from .core import OBSERVER_ISOTONE_OBSERVER_AXIS
-        if self.variables is None:
-            for op in graph.operations.values():
-                if op.type == 'Softmax' and hasattr(op, 'config'):
-                    cfg = op.config.output_quantization_config[0]
-                    if cfg.dominated_by == cfg:
-                        cfg.state = type(cfg.state).INITIAL
-                        cfg.observer_algorithm = 'Isotone'
-                        cfg.detail[OBSERVER_ISOTONE_OBSERVER_AXIS] = op.attributes.get('axis', -1)
-                        if self.verbose:
-                            print(f'Calibration Method of Op {op.name} has been changed to Isotone[axis={op.attributes.get("axis", -1)}].')
-            return
-        if not isinstance(self.variables, list):
-            raise TypeError('Isotone Calibration Pass needs a list of variable name as its input.')
-        for name in self.variables:
-            if not isinstance(name, str):
-                raise TypeError('Isotone Calibration Pass needs a list of variable name as its input.')
-            if name not in graph.variables: raise ValueError(f'Variable {name} not in current graph.')
-            var = graph.variables[name]
-            op = var.source_op
-            if op is None or not hasattr(op, 'config'): continue
-            cfg = op.config.output_quantization_config[op.outputs.index(var)]
-            cfg.state = type(cfg.state).INITIAL
-            cfg.observer_algorithm = 'Isotone'
-            cfg.detail[OBSERVER_ISOTONE_OBSERVER_AXIS] = self.axis
-            if self.verbose: print(f'Calibration Method of Variable {var.name} has been changed to Isotone[axis={self.axis}].')

@@ -15,6 +15,7 @@ from torch.autograd import Function
 
 from .core import QuantizationProperty as P
 from .core import QuantizationStates, rounding_value, state_value
+from .blocks import COMPUTING_OP
 from .ffi import CUDA
 from .qfunction import PPQuantFunction, _as_1d
 
@@ -121,14 +122,14 @@ class LearnedStepSizePass:
     {weights, scales, offsets} through ``partial_graph_forward`` (forward fake-quant kernels, backward LSQ
     kernels), loss = MSE against the FP32 block output (+ gamma * weight quantisation error), withdraw when
     the block loss did not improve (training.py:728-826).  ``block_size=None`` treats the whole graph as ONE
-    block (round 1's form, kept for graphs with one input and one output).
+    block; it is refused for graphs with more than one output (a block has ONE end point).
 
     Data-parallel finetuning (one process per GPU, each with its shard of the batches): the gradients of ALL
     trainable tensors of a block travel in ONE flat all-reduce per step (a few MB at most -- latency bound on
     xGMI, so never one collective per tensor); block losses are averaged so every rank takes the same keep /
     withdraw decision.  ``report`` = [(block, pre_loss, post_loss)]."""
     def __init__(self, steps: int = 500, lr: float = 5e-5, gamma: float = 0.0, optimizer=None, process_group=None,
-                 block_size: int = None, interested_layers: List[str] = None, is_scale_trainable: bool = True):
+                 block_size: int = 5, interested_layers: List[str] = None, is_scale_trainable: bool = True):
         self.steps, self.lr, self.gamma, self.optimizer = steps, lr, gamma, optimizer
         self.process_group = process_group
         self.block_size = block_size
@@ -163,29 +164,54 @@ class LearnedStepSizePass:
         self._average([loss])
         return float(loss)
 
+    @ staticmethod
+    def enable_block_gradient(block) -> None:
+        """training.py:150-168: every float parameter of the block (Clip bounds excepted) and every config scale."""
+        for op in block.rps:
+            for var in list(op.inputs) + list(op.outputs):
+                if var.is_parameter and isinstance(var.value, torch.Tensor):
+                    if op.type == 'Clip': continue
+                    if var.value.dtype == torch.float32: var.value.requires_grad = True
+            if hasattr(op, 'config'):
+                for cfg, _ in op.config_with_variable:
+                    if isinstance(cfg.scale, torch.Tensor) and cfg.scale.is_floating_point(): cfg.scale.requires_grad = True
+
+    @ staticmethod
+    def disable_block_gradient(block) -> None:
+        """training.py:170-183 -- plus the offsets: nothing of the block keeps ``requires_grad`` or a ``.grad`` after
+        the pass, whether it was handed to the optimizer or not (a later ``.numpy()`` / export must not raise)."""
+        for op in block.rps:
+            for var in list(op.inputs) + list(op.outputs):
+                if var.is_parameter and isinstance(var.value, torch.Tensor) and var.value.is_leaf:
+                    var.value.requires_grad = False; var.value.grad = None
+            if hasattr(op, 'config'):
+                for cfg, _ in op.config_with_variable:
+                    for t in (cfg.scale, cfg.offset):
+                        if isinstance(t, torch.Tensor) and t.is_leaf and t.is_floating_point():
+                            t.requires_grad = False; t.grad = None
+
     def finetune(self, block, executor, qt_inputs, fp_outputs):
         """training.py:728-826 for one block."""
+        self.enable_block_gradient(block)
         pre_loss = self._block_loss(block, qt_inputs, fp_outputs, executor)
         delegators, tensors = {}, []
         for op in block.rps:
             if not hasattr(op, 'config'): continue
-            if op.type in {'Conv', 'Gemm', 'ConvTranspose', 'MatMul', 'Add', 'Mul'}:
+            if op.type in COMPUTING_OP or op.type in {'Add', 'Mul'}:          # a lone Add / Mul trains its constant too
                 for var in op.inputs:
-                    if var.is_parameter and isinstance(var.value, torch.Tensor) and var.value.dtype == torch.float32:
-                        var.value.requires_grad_(True); tensors.append(var.value)
+                    if var.is_parameter and isinstance(var.value, torch.Tensor): tensors.append(var.value)
             for cfg, var in op.config_with_variable:
                 if state_value(cfg.state) in (QuantizationStates.ACTIVATED.value, QuantizationStates.PASSIVE.value):
-                    for t in (cfg.scale, cfg.offset):
-                        if isinstance(t, torch.Tensor) and t.is_floating_point(): t.requires_grad_(True)
                     d = LSQDelegator(config=cfg, var=var, is_scale_trainable=self.is_scale_trainable)
                     tensors.extend(d.trainable_tensors())
                     executor.register_quantize_delegate(cfg, d)
                     delegators[cfg] = d
         uniq, seen = [], set()
-        for t in tensors:
+        for t in tensors:                              # offsets never carry requires_grad: CuLSQ has no offset gradient
             if t.requires_grad and id(t) not in seen: seen.add(id(t)); uniq.append(t)
         if not uniq:
             for cfg in delegators: executor.remove_quantize_delegate(cfg)
+            self.disable_block_gradient(block)
             return 0.0, 0.0
         # parameters whose config carries no delegator (FP32 bias: this harness has no PassiveParameterQuantizePass,
         # where the reference would hold a PASSIVE config + delegator backup) are trained too -- keep their own backup
@@ -194,6 +220,7 @@ class LearnedStepSizePass:
                  and not any(t is c.scale or t is c.offset for c in delegators)]
         opt = torch.optim.Adam(uniq, lr=self.lr) if self.optimizer is None else self.optimizer(uniq, lr=self.lr)
         names = [v.name for v in block.ep.outputs]
+        if len(qt_inputs) == 0: raise ValueError('Dataset is empty.')
         for step in range(self.steps):
             qt_input, fp_output = qt_inputs[step % len(qt_inputs)], fp_outputs[step % len(qt_inputs)]
             opt.zero_grad()
@@ -201,10 +228,10 @@ class LearnedStepSizePass:
                 outs = executor.partial_graph_forward(block.rps, qt_input, names)
                 loss = sum(self._loss(y, fp_output[n]) for n, y in zip(names, outs))
                 if self.gamma:
-                    for op in block.rps:
-                        if hasattr(op, 'config') and op.type in {'Conv', 'Gemm', 'ConvTranspose', 'MatMul'}:
+                    for op in block.rps:                                  # training.py:793-798 (the STE gradient passes)
+                        if hasattr(op, 'config') and op.type in COMPUTING_OP:
                             w, wc = op.inputs[1].value, op.config.input_quantization_config[1]
-                            loss = loss + self._loss(w, PPQuantFunction(w, wc).detach()) * self.gamma
+                            loss = loss + self._loss(w, PPQuantFunction(w, wc)) * self.gamma
             loss.backward()
             with torch.no_grad():
                 self._average([t.grad for t in uniq if t.grad is not None])
@@ -217,14 +244,16 @@ class LearnedStepSizePass:
         if post_loss > pre_loss:
             with torch.no_grad():
                 for t, backup in loose: t.copy_(backup)
-        for t in uniq:
-            t.requires_grad_(False); t.grad = None
+        self.disable_block_gradient(block)
         return pre_loss, post_loss
 
     def optimize(self, graph, dataloader, executor, collate_fn=None, **kwargs):
         from .blocks import TrainableBlock, collect, split_graph_into_blocks
         batches = [collate_fn(b) if collate_fn is not None else b for b in dataloader]
         if self.block_size is None:
+            if len(graph.outputs) != 1:
+                raise ValueError('LearnedStepSizePass(block_size=None) trains the whole graph against ONE output; '
+                                 f'this graph has {len(graph.outputs)} -- pass a block_size')
             ops = graph.topological_sort()
             blocks = [TrainableBlock(sp=ops[0], ep=ops[-1], rps=ops)]
         else:

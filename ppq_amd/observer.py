@@ -26,7 +26,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .core import (OBSERVER_FLOATING_MSE_FETCHES, OBSERVER_ISOTONE_OBSERVER_AXIS, OBSERVER_KL_HIST_BINS, OBSERVER_KL_HIST_BINS_MANUL_OVERRIDE,
+from .core import (OBSERVER_FLOATING_MSE_FETCHES, OBSERVER_KL_HIST_BINS, OBSERVER_KL_HIST_BINS_MANUL_OVERRIDE,
                    OBSERVER_MIN_SCALE, OBSERVER_MIN_SCALE_MANUL_OVERRIDE, OBSERVER_MSE_HIST_BINS,
                    OBSERVER_PERCENTILE, OBSERVER_PERCENTILE_MANUL_OVERRIDE, is_initial, set_activated)
 from .core import QuantizationProperty as P
@@ -197,15 +197,6 @@ class BaseTensorObserver:
         """Device buffers + reduction ('min' | 'max' | 'sum') that merge shards of a data-parallel
         calibration; applied in place before rendering."""
         return []
-
-    def gatherable(self) -> List[torch.Tensor]:
-        """2-D device buffers [rows, k] whose ROWS must be collected from every rank (statistics that are a set,
-        not a reduction: the isotone observer's top-2 pairs).  ``take_gathered`` receives, per buffer, the
-        concatenation over ranks in rank order -- identical on every rank."""
-        return []
-
-    def take_gathered(self, merged: List[torch.Tensor]) -> None:
-        pass
 
 
 _RANGE_SEEDS: Dict[object, tuple] = {}
@@ -816,77 +807,6 @@ class DirectMSEObserver(BaseTensorObserver):
         set_activated(cfg)
 
 
-class TorchIsotoneObserver(BaseTensorObserver):
-    """observer/order.py:12-103 ('isotone'): an order-preserving scale for classification outputs -- the largest
-    element L1 of every row must stay apart from the second largest L2 (scale < 2 (L1 - L2)) while L2 is not
-    clipped (scale > L2 / (quant_max - .51)); the scale that satisfies the most rows wins.
-
-    The top-2 of every row stay on the device (one [rows, 2] buffer per batch), rendering fetches them with one
-    copy and runs the reference's interval sweep on the same float32 values in the same order, so the result is the
-    reference's.  Data parallel: the pairs of all ranks are gathered (``gatherable``), not reduced."""
-    def __init__(self, watch_on, quant_cfg):
-        super().__init__(watch_on, quant_cfg)
-        self._cache = []
-        self.axis = quant_cfg.detail.get(OBSERVER_ISOTONE_OBSERVER_AXIS, -1)
-
-    @ torch.no_grad()
-    def observe(self, value: torch.Tensor):
-        if not is_initial(self._quant_cfg): return
-        assert isinstance(value, torch.Tensor), 'IsotoneObserver can only deal with torch Tensor values'
-        assert value.numel() > 0, f'You are observing an empty tensor({getattr(self._watch_on, "name", "?")}).'
-        cfg = self._quant_cfg
-        if cfg.policy.has_property(P.PER_TENSOR):
-            if value.ndim > 1:
-                value = value.transpose(dim0=self.axis, dim1=-1)
-                value = value.flatten(start_dim=0, end_dim=-2)
-            value, _ = torch.topk(value, k=2, dim=self.axis, largest=True, sorted=True)     # order.py:52 (dim = the ORIGINAL axis)
-            if value.ndim <= 1: value = value.unsqueeze(0)
-            self._cache.append(value)
-        elif cfg.policy.has_property(P.PER_CHANNEL):
-            raise TypeError('Isotone Observer is not designed for channelwise quantization.')
-        else:
-            raise TypeError('Isotone Observer only work with per-tensor or per-channel quantize policy.')
-
-    def gatherable(self):
-        if not is_initial(self._quant_cfg) or not self._cache: return []
-        self._cache = [torch.cat(self._cache, dim=0).contiguous()]
-        return [self._cache[0]]
-
-    def take_gathered(self, merged):
-        self._cache = [merged[0]]
-
-    def render_quantization_config(self):
-        if not is_initial(self._quant_cfg): return
-        cfg = self._quant_cfg
-        device = self._cache[-1].device
-        collected = torch.cat(self._cache, dim=0).cpu().numpy()
-        s_candidates = []
-        for l1, l2 in collected:                                         # order.py:71-79, numpy float32 scalars as there
-            if cfg.policy.has_property(P.SYMMETRICAL): l1, l2 = abs(l1), abs(l2)
-            scale_min = max(l2 / (cfg.quant_max - .51), 0)
-            scale_max = 2 * (l1 - max(l2, 0))
-            if scale_max > scale_min and l1 > 0:
-                s_candidates.append((scale_min, 'min'))
-                s_candidates.append((scale_max, 'max'))
-        if len(s_candidates) <= 0:                                       # fall back to min-max calibration (order.py:81-91)
-            scale, offset = minmax_to_scale_offset(min_val=0, max_val=l1, config=cfg)
-            cfg.scale = torch.tensor([scale], dtype=torch.float32, device=device).squeeze(0)
-            cfg.offset = torch.tensor([offset], dtype=torch.float32, device=device).squeeze(0)
-            set_activated(cfg)
-            return
-        s_candidates, best_satisfied, satisfied = sorted(s_candidates), 0, 0
-        for s_candidate, T in s_candidates:
-            if T == 'min': satisfied += 1
-            if T == 'max': satisfied -= 1
-            if satisfied > best_satisfied:
-                best_satisfied = satisfied
-                best_scale = s_candidate
-        cfg.scale = torch.tensor([best_scale], dtype=torch.float32, device=device).squeeze(0)
-        cfg.offset = torch.tensor([0], dtype=torch.float32, device=device).squeeze(0)
-        set_activated(cfg)
-        self.s_candidates = s_candidates
-
-
 # observer/__init__.py:15-23
 OBSERVER_TABLE = {
     'minmax': TorchMinMaxObserver,
@@ -895,7 +815,6 @@ OBSERVER_TABLE = {
     'percentile': TorchPercentileObserver,
     'mse': TorchMSEObserver,
     'mse_channel': ChannelwiseMSEObserver,     # extension, not in the reference's table
-    'isotone': TorchIsotoneObserver,
     'constant': ConstantObserver,
     'floating': DirectMSEObserver,
 }

@@ -18,8 +18,17 @@ def pytest_configure(config):
         __graft_entry__.build()
 
 
+# Collection order (the driver runs `pytest -x`): kernel-level bit-exact parity first, then the unmodified reference
+# on these kernels, then the host layer, and the training-based passes LAST, so that no single test further down the
+# stack can hide the parity suite (round 2: one optimizer-outcome threshold masked 234 tests).
+_ORDER = ['test_oracle_golden.py', 'test_host_cpu.py', 'test_gpu_kernels.py', 'test_gpu_fp8_reference.py', 'test_gpu_reference.py',
+          'test_gpu_plugin_seam.py', 'test_gpu_calibration.py', 'test_gpu_rccl.py', 'test_gpu_finetune.py']
+
+
 def pytest_collection_modifyitems(config, items):
-    """GPU tests are skipped (not failed) when no device is visible, so `pytest tests/` is safe anywhere."""
+    """Fixed file order (above); GPU tests are skipped (not failed) when no device is visible."""
+    rank = {name: i for i, name in enumerate(_ORDER)}
+    items.sort(key=lambda it: rank.get(os.path.basename(str(it.fspath)), len(_ORDER) - 1.5))      # stable: in-file order kept
     try:
         import torch
         has_gpu = torch.cuda.is_available()
