@@ -231,3 +231,81 @@ def timed_calibrate(hgraph, batches: List[torch.Tensor], bins: int = 2048):
     steps = max(8, len(batches))
     secs = calibrate(g, ex, batches)
     return secs * len(batches) / steps, activation_scales(g)
+
+
+class ReplayExecutor:
+    """A deterministic stand-in for ``ppq.TorchExecutor`` in calibration comparisons -- TEST INFRASTRUCTURE.
+
+    The vendor convolutions are not bit-reproducible from one forward to the next on large topologies (the algorithm
+    picked depends on the workspace the allocator can offer at that moment), so two calibration passes that each run
+    their own forwards can see activations that differ in the last bit -- enough to move one histogram count and flip a
+    KL arg-min.  This wrapper runs the REFERENCE executor once per batch, records what its hooks are shown (the raw and
+    quantised inputs / outputs of every quantable operation, executor/torch.py:523-549), and afterwards REPLAYS exactly
+    those tensors into whatever hooks a pass hands it -- the reference's pass with its own observers, the reference's
+    pass with this package's observers, this package's pass: all see identical bits.  Valid while no activation config is
+    switched on between the recording and a replay (true for every calibration pass: activations stay INITIAL until the
+    last render; `reset_activation_configs` restores that state between passes).
+
+    ``target_graph``: replay into hooks built on ANOTHER graph with the same operation names (a ppq_amd.harness graph):
+    the recorded configs are translated by (operation, position)."""
+    def __init__(self, inner, target_graph=None):
+        load()
+        self._inner = inner
+        self._ref_graph = inner._graph
+        self._graph = target_graph if target_graph is not None else inner._graph
+        self._translate = target_graph is not None
+        self._tape: Dict[int, list] = {}
+        self.recorded_forwards = 0
+        self.replayed_forwards = 0
+
+    def _record(self, inputs) -> list:
+        from ppq.executor.base import QuantOPRuntimeHook
+        from ppq.IR import QuantableOperation
+        tape = []
+
+        class Spy(QuantOPRuntimeHook):
+            def __init__(self, op): self._op = op; super().__init__(op)
+
+            def pre_forward_hook(self, inputs, quant_inputs, quant_configs):
+                tape.append((self._op.name, 'pre', list(inputs), list(quant_inputs), list(quant_configs)))
+                return quant_inputs
+
+            def post_forward_hook(self, outputs, quant_outputs, quant_configs):
+                tape.append((self._op.name, 'post', list(outputs), list(quant_outputs), list(quant_configs)))
+                return quant_outputs
+        spies = {name: Spy(op) for name, op in self._ref_graph.operations.items() if isinstance(op, QuantableOperation)}
+        self._inner.forward(inputs=inputs, hooks=spies)
+        self.recorded_forwards += 1
+        return tape
+
+    def forward(self, inputs, output_names=None, hooks=None):
+        key = (inputs.data_ptr(), tuple(inputs.shape))
+        if key not in self._tape: self._tape[key] = self._record(inputs)
+        self.replayed_forwards += 1
+        for name, kind, raw, quant, cfgs in self._tape[key]:
+            hook = hooks.get(name) if hooks else None
+            if hook is None: continue
+            if self._translate:
+                op = self._graph.operations[name]
+                cfgs = list(op.config.input_quantization_config if kind == 'pre' else op.config.output_quantization_config)
+            if kind == 'pre': hook.pre_forward_hook(inputs=raw, quant_inputs=quant, quant_configs=cfgs)
+            else: hook.post_forward_hook(outputs=raw, quant_outputs=quant, quant_configs=cfgs)
+        return []
+
+    def for_graph(self, target_graph) -> 'ReplayExecutor':
+        """A view on the SAME recording that replays into hooks built on `target_graph` (same operation names)."""
+        view = ReplayExecutor(self._inner, target_graph)
+        view._tape = self._tape
+        return view
+
+    def reset_activation_configs(self):
+        """Put every non-parameter config of the (reference) graph back to INITIAL with no scale: the next pass starts
+        from the state the recording was made in."""
+        from ppq.core import QuantizationStates
+        from ppq.IR import QuantableOperation
+        for op in self._ref_graph.operations.values():
+            if not isinstance(op, QuantableOperation): continue
+            for cfg, v in op.config_with_variable:
+                if not v.is_parameter and cfg.state == QuantizationStates.ACTIVATED and cfg.dominated_by == cfg:
+                    cfg.state = QuantizationStates.INITIAL
+                    cfg.scale = None; cfg.offset = None

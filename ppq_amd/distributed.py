@@ -43,13 +43,17 @@ def _check_layout(dist, lengths: List[int], device, group) -> None:
                            'least one batch with every observer before a merge (calib_steps >= world_size)')
 
 
-def merge_observers(observers: Sequence, group=None) -> int:
+def merge_observers(observers: Sequence, group=None, even_if_single_rank: bool = False) -> int:
     """All-reduce, in place, every buffer the observers declare ``reducible()``.  Returns the number
-    of data collectives issued (0 when not distributed); sizes and time land in ``last_merge_stats``."""
+    of data collectives issued (0 when not distributed); sizes and time land in ``last_merge_stats``.
+    ``even_if_single_rank``: issue the collectives on a 1-rank group too (a no-op on the data; it proves the
+    backend -- RCCL -- loads and accepts every (dtype, reduction) pair used, tests/test_gpu_rccl.py)."""
     global last_merge_stats
     if not is_distributed(group):
-        last_merge_stats = {}
-        return 0
+        import torch.distributed as dist
+        if not (even_if_single_rank and dist.is_available() and dist.is_initialized()):
+            last_merge_stats = {}
+            return 0
     import time
     import torch.distributed as dist
     mins: List[torch.Tensor] = []     # reduced with MIN ('max' buffers are negated into this list)

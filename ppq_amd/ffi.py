@@ -744,6 +744,37 @@ def install_into_ppq() -> None:
     REF_CONFIG.USING_CUDA_KERNEL = True
 
 
+def install_plugins_into_ppq(observers: bool = True) -> None:
+    """The higher seams (last row), on top of :func:`install_into_ppq`: make this package's observers and
+    passes first-class citizens of an importable, UNMODIFIED PPQ -- nothing of PPQ is edited, only its own registration
+    points are used:
+
+    * ``ppq.executor.base.QuantOPRuntimeHook`` is an ABC and PPQ's executor admits a hook by ``isinstance``
+      (executor/torch.py:525-531): this package's ``CalibrationHook`` is registered as a virtual subclass, so
+      ``ppq.TorchExecutor.forward(hooks=...)`` fires it;
+    * ``ppq.quantization.optim.base.QuantizationOptimizationPass`` is an ABC and PPQ's pipeline admits a pass by
+      ``isinstance`` (optim/base.py:60-82): this package's pass base class is registered, so
+      ``ppq_amd.calibration.RuntimeCalibrationPass`` (and the LSQ / bias-correction passes) go into ``ppq.lib.Pipeline``;
+    * with ``observers=True`` PPQ's ``OBSERVER_TABLE`` (observer/__init__.py:15-23) is updated with the HIP-backed
+      observers, so PPQ's OWN ``RuntimeCalibrationPass`` builds them; its two-phase test is by exact type
+      (optim/calibration.py:196: ``type(ob) not in {TorchHistObserver, TorchMSEObserver}``), so the two names that module
+      imported are re-bound to the classes now in the table (the per-channel extensions 'kl_channel' / 'mse_channel'
+      are two-phase too and therefore need this package's pass)."""
+    install_into_ppq()
+    from ppq.executor.base import QuantOPRuntimeHook
+    from ppq.quantization.optim.base import QuantizationOptimizationPass as RefPass
+
+    from . import calibration, observer
+    QuantOPRuntimeHook.register(observer.CalibrationHook)
+    RefPass.register(calibration.QuantizationOptimizationPass)
+    if observers:
+        import ppq.quantization.observer as ref_observer
+        import ppq.quantization.optim.calibration as ref_calibration
+        ref_observer.OBSERVER_TABLE.update(observer.OBSERVER_TABLE)
+        ref_calibration.TorchHistObserver = observer.TorchHistObserver
+        ref_calibration.TorchMSEObserver = observer.TorchMSEObserver
+
+
 class CUDA:
     """Mirror of ppq.core.ffi.CUDA (ffi.py:51-350): same names, argument order and defaults."""
 

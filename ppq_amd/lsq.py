@@ -16,6 +16,7 @@ from torch.autograd import Function
 from .core import QuantizationProperty as P
 from .core import QuantizationStates, rounding_value, state_value
 from .blocks import COMPUTING_OP
+from .calibration import QuantizationOptimizationPass
 from .ffi import CUDA
 from .qfunction import PPQuantFunction, _as_1d
 
@@ -113,7 +114,7 @@ class LSQDelegator:
         raise ValueError('LSQDelegator: unsupported quantization policy')
 
 
-class LearnedStepSizePass:
+class LearnedStepSizePass(QuantizationOptimizationPass):
     """ppq/quantization/optim/training.py:569-863: block-wise LSQ finetuning.
 
     The graph is cut into TrainableBlocks (ppq_amd/blocks.py; ``block_size`` = the reference's depth limit,
@@ -130,6 +131,7 @@ class LearnedStepSizePass:
     withdraw decision.  ``report`` = [(block, pre_loss, post_loss)]."""
     def __init__(self, steps: int = 500, lr: float = 5e-5, gamma: float = 0.0, optimizer=None, process_group=None,
                  block_size: int = 5, interested_layers: List[str] = None, is_scale_trainable: bool = True):
+        super().__init__(name='PPQ LSQ Optimization')
         self.steps, self.lr, self.gamma, self.optimizer = steps, lr, gamma, optimizer
         self.process_group = process_group
         self.block_size = block_size

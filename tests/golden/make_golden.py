@@ -11,6 +11,8 @@ kernels.  Outputs (committed, all small):
     tests/golden/linear_fq.npz        per-tensor / per-channel linear fake-quant
     tests/golden/rounding.npz         ppq_tensor_round / ppq_numerical_round tables
     tests/golden/observers.npz        minmax / percentile / kl / mse observer results
+    tests/golden/fp8_ref.npz          FP8 fake-quant + the 8 rounding modes, from the reference's common.cuh compiled on the host
+                                      (--fp8-only regenerates just this file)
 
 Import shims (the container has no onnx and a newer protobuf/numpy than ppq expects):
 stub `onnx*` modules, PROTOCOL_BUFFERS_PYTHON_IMPLEMENTATION=python, and a float() cast in
@@ -324,10 +326,37 @@ def gen_observers_cuda_rule():
     print('observers_cuda_rule.npz', {n: int(out[n]) for n in ('kl_n', 'mse_n')})
 
 
+def gen_fp8_ref():
+    """FP8 outputs PRODUCED BY THE REFERENCE'S OWN SOURCE: ppq/csrc/cuda/common.cuh (QuantizeScalarFloating, _round2int,
+    DequantizeScalar) compiled as host C++ where it lies (oracle/_ref/libref_common.so, `make -C oracle ref`), on the
+    structured sweep of oracle/ref_common.py::sweep_bits (+ 8192 random bit patterns, seed 0).  Inputs are regenerated by
+    the tests from the same function; only the outputs (uint32 bit patterns) are stored."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import ref_common as R
+    assert R.available(), 'run `make -C oracle ref` first'
+    out = {}
+    for key, fmt, scale, offset, clip, rounding in R.fp8_ref_cases():
+        E, M, c = R.FORMATS[fmt]
+        if clip is not None: c = clip
+        x = R.sweep_bits(M, n_random=8192, seed=0)
+        y = R.fq_float_t(x, [scale], [offset], E, M, -c, c, rounding)
+        out[key] = y.view(np.uint32)
+    # _round2int, all 8 modes, on the values where the modes differ
+    v = np.concatenate([np.arange(-64, 65) / 8.0, np.array([0.49999997, -0.49999997, 8388607.5, -8388607.5, 1e9, -1e9, 2.5e-7]),
+                        np.random.default_rng(3).standard_normal(4096) * 300]).astype(np.float32)
+    out['round_values'] = v
+    out['round_results'] = np.array([[R.round2int(float(a), r) for a in v] for r in range(8)], np.int32)
+    np.savez_compressed(os.path.join(HERE, 'fp8_ref.npz'), **out)
+    print('fp8_ref.npz', len(out), 'arrays,', os.path.getsize(os.path.join(HERE, 'fp8_ref.npz')), 'bytes')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
+    if '--fp8-only' in sys.argv:
+        gen_fp8_ref(); sys.exit(0)
     if '--cuda-rule-only' not in sys.argv:
         gen_linear()
         gen_rounding()
         gen_observers()
     gen_observers_cuda_rule()
+    gen_fp8_ref()

@@ -1,0 +1,144 @@
+"""The plugin seams of SURVEY 8(b), last row, exercised INSIDE the unmodified reference ("drops into ppq.executor unchanged"):
+
+  A. ``ppq.quantization.observer.OBSERVER_TABLE`` <- this package's HIP observers; the reference's OWN
+     ``RuntimeCalibrationPass`` + ``TorchExecutor`` + ``CalibrationHook`` drive them;
+  B. ``ppq_amd.calibration.RuntimeCalibrationPass`` inside the reference's ``ppq.lib.Pipeline`` on the reference's
+     ``TorchExecutor`` and ``BaseGraph`` (its hooks admitted through the QuantOPRuntimeHook ABC);
+  C. the same pass on this package's harness graph.
+
+All against the reference's own pass with its own observers (kernels: libppq_hip.so through install_into_ppq()).
+Every stack is shown the SAME activation bits (oracle.reference_import.ReplayExecutor records the reference executor's
+forward once per batch and replays it), so every scale must agree to 1e-6 and every offset exactly -- on ResNet-50 all
+72 activation configs, no allowance.  Needs an importable reference (the staged copy on the GPU box)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import reference_import as RI  # noqa: E402
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(RI.find_reference() is None, reason='no importable reference (stage one)')]
+DEV = 'cuda'
+
+
+def _scales(graph):
+    out = {}
+    for op in graph.operations.values():
+        if not hasattr(op, 'config'): continue
+        for cfg, v in op.config_with_variable:
+            if not v.is_parameter and int(getattr(cfg.state, 'value', cfg.state)) == 4 and cfg.scale is not None and cfg.dominated_by == cfg:
+                out[v.name] = (cfg.scale.detach().flatten().cpu().clone(), cfg.offset.detach().flatten().cpu().clone())
+    return out
+
+
+def _assert_equal(name, got, want):
+    assert set(got) == set(want), (name, sorted(set(got) ^ set(want)))
+    bad = {k: (got[k], want[k]) for k in want
+           if not (torch.allclose(got[k][0], want[k][0], rtol=1e-6, atol=0) and torch.equal(got[k][1], want[k][1]))}
+    assert not bad, (name, len(bad), list(bad.items())[:3])
+
+
+@pytest.fixture(autouse=True)
+def _restore_reference_tables():
+    """install_plugins_into_ppq() edits the reference's registration points; put them back for the tests that follow."""
+    RI.load()
+    import ppq.quantization.observer as ro
+    import ppq.quantization.optim.calibration as rc
+    table, hist, mse = dict(ro.OBSERVER_TABLE), rc.TorchHistObserver, rc.TorchMSEObserver
+    yield
+    ro.OBSERVER_TABLE.clear(); ro.OBSERVER_TABLE.update(table)
+    rc.TorchHistObserver, rc.TorchMSEObserver = hist, mse
+
+
+@pytest.mark.parametrize('topology,batch,size,method,symmetric', [
+    ('resnet50', 4, 224, 'kl', True), ('small_cnn', 4, 32, 'kl', True), ('small_cnn', 4, 32, 'mse', True), ('small_cnn', 4, 32, 'mse', False),
+    ('small_cnn', 4, 32, 'percentile', True), ('small_cnn', 4, 32, 'percentile', False), ('small_cnn', 4, 32, 'minmax', True),
+    ('small_cnn', 4, 32, 'minmax', False), ('resnet50', 2, 224, 'mse', False), ('resnet50', 2, 224, 'percentile', True)])
+def test_observers_and_pass_plugged_into_the_reference(topology, batch, size, method, symmetric):
+    import ppq_amd
+    from ppq_amd import harness
+    from ppq_amd import observer as our_observer
+    from ppq_amd.calibration import RuntimeCalibrationPass as OurPass
+    RI.load()
+    ppq_amd.install_into_ppq()
+    import ppq.lib as PFL
+    import ppq.quantization.observer as ref_observer
+    from ppq.core import QuantizationPolicy, QuantizationProperty as QP
+    from ppq.quantization.optim import RuntimeCalibrationPass as RefPass
+    build = harness.small_cnn_graph if topology == 'small_cnn' else harness.resnet50_graph
+    g = torch.Generator().manual_seed(13)
+    batches = [torch.rand(batch, 3, size, size, generator=g).to(DEV) for _ in range(8)]
+
+    def asym(cfg, v):
+        if symmetric or v.is_parameter: return
+        cfg.policy = QuantizationPolicy(QP.ASYMMETRICAL + QP.LINEAR + QP.PER_TENSOR)
+        cfg.quant_min, cfg.quant_max = 0, 255
+    rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(build(seed=0)), DEV, batches[0], bins=2048, method=method, mutate=asym)
+    replay = RI.ReplayExecutor(rex)
+
+    # 0. the reference's pass with the reference's observers
+    built = []
+    ref_build = ref_observer.TensorObserverFactroy.build_observer.__func__
+
+    def counting_build(cls, variable, config):
+        ob = ref_build(cls, variable, config); built.append(type(ob)); return ob
+    ref_observer.TensorObserverFactroy.build_observer = classmethod(counting_build)
+    try:
+        RefPass(method=method).optimize(graph=rg, dataloader=batches, executor=replay, calib_steps=8, collate_fn=None)
+        want = _scales(rg)
+        assert len(want) >= (60 if topology == 'resnet50' else 4)
+        assert built and all(t.__module__.startswith('ppq.') for t in built)
+        assert replay.recorded_forwards == 8
+
+        # A. the reference's pass, this package's observers from the reference's table
+        replay.reset_activation_configs(); built.clear()
+        ppq_amd.install_plugins_into_ppq()
+        RefPass(method=method).optimize(graph=rg, dataloader=batches, executor=replay, calib_steps=8, collate_fn=None)
+        assert built and all(t.__module__ == our_observer.__name__ for t in built), set(built)
+        _assert_equal('A: reference pass + HIP observers', _scales(rg), want)
+    finally:
+        ref_observer.TensorObserverFactroy.build_observer = classmethod(ref_build)
+
+    # B. this package's pass in the reference's pipeline, on the reference's graph and executor protocol
+    replay.reset_activation_configs()
+    ours = OurPass(method=method)
+    PFL.Pipeline([ours]).optimize(graph=rg, dataloader=batches, executor=replay, calib_steps=8, collate_fn=None, verbose=False)
+    assert ours._queue is not None and ours._queue.launches > 0            # the multi-tensor launches carried it
+    _assert_equal('B: HIP pass in the reference pipeline', _scales(rg), want)
+    assert replay.recorded_forwards == 8                                   # nothing ran the network again
+
+    # C. this package's pass on its own harness graph, shown the reference executor's activations
+    hg = build(seed=0)
+    harness.quantize_graph(hg, method, symmetrical=symmetric, hist_bins=2048)
+    hex_ = harness.TorchExecutor(hg, DEV)
+    harness.ParameterQuantizePass().optimize(hg)
+    OurPass(method=method).optimize(hg, dataloader=batches, executor=replay.for_graph(hg), calib_steps=8)
+    _assert_equal('C: HIP pass on the harness graph', _scales(hg), want)
+    assert replay.recorded_forwards == 8
+
+
+def test_pass_plugged_into_the_reference_executor_runs_the_network_itself():
+    """Seam B without the replay double: ppq_amd's pass drives the REAL ppq.TorchExecutor (forward(inputs, hooks=...) fires
+    this package's CalibrationHook through the QuantOPRuntimeHook ABC) on a topology small enough for the vendor
+    convolutions to be reproducible; scales equal the reference's own pass on the same executor."""
+    import ppq_amd
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass as OurPass
+    RI.load()
+    ppq_amd.install_plugins_into_ppq(observers=False)
+    import ppq.lib as PFL
+    from ppq.quantization.optim import RuntimeCalibrationPass as RefPass
+    g = torch.Generator().manual_seed(17)
+    batches = [torch.rand(4, 3, 32, 32, generator=g).to(DEV) for _ in range(8)]
+    for method in ('kl', 'mse', 'minmax', 'percentile'):
+        rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(harness.small_cnn_graph(seed=1)), DEV, batches[0], bins=2048, method=method)
+        RefPass(method=method).optimize(graph=rg, dataloader=batches, executor=rex, calib_steps=8, collate_fn=None)
+        want = _scales(rg)
+        rg2, rex2 = RI.quantize_reference_graph(RI.to_reference_graph(harness.small_cnn_graph(seed=1)), DEV, batches[0], bins=2048, method=method)
+        PFL.Pipeline([OurPass(method=method)]).optimize(graph=rg2, dataloader=batches, executor=rex2, calib_steps=8, collate_fn=None, verbose=False)
+        _assert_equal(f'{method}: HIP pass on ppq.TorchExecutor', _scales(rg2), want)
+        out = rex2.forward(batches[0])[0]
+        assert torch.isfinite(out).all()

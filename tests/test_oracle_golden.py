@@ -381,3 +381,71 @@ def test_fp8_integer_derivation_equals_c_restatement():
     # the tie quirk, stated once in numbers: E4M3 1.1875 = 1.0011|0 is a tie between 1.125 and 1.25 -> DOWN
     assert float(F.fq_float_t(torch.tensor([1.1875, 1.3125, -1.1875]), 1.0)[0]) == 1.125
     assert F.fq_float_t(torch.tensor([1.3125]), 1.0).item() == 1.25 and F.fq_float_t(torch.tensor([-1.1875]), 1.0).item() == -1.125
+
+
+def _nan_equal_bits(a, b):
+    return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+
+
+def test_fp8_and_rounding_restatement_equals_the_reference_source_compiled_on_the_host():
+    """Pins SURVEY 8(a5) / (a1): oracle/ppq_oracle.c against the reference's OWN ppq/csrc/cuda/common.cuh --
+    QuantizeScalarFloating, _round2int, QuantizeScalar, DequantizeScalar -- compiled as host C++ where it lies
+    (oracle/_ref/libref_common.so, `make -C oracle ref`; only where /root/reference exists).  Bit for bit on the
+    structured sweep (every sign / exponent / kept-mantissa pattern x all tie positions + 1 M random patterns) x
+    {E4M3, E5M2, E3M4, E2M5, E5M10} x 5 scales (power-of-two and not) x ALL 8 rounding modes, raw float offsets, clip
+    bounds wider than the format; per-channel layout; the linear path with every mode."""
+    from oracle import ref_common as R
+    if not R.available(): pytest.skip('oracle/_ref/libref_common.so is built only where /root/reference exists')
+    formats = dict(R.FORMATS); formats.update({'e3m4': (3, 4, 30.0), 'e2m5': (2, 5, 7.5), 'e5m10': (5, 10, 65504.0)})
+    for name, (E, M, c) in formats.items():
+        x = R.sweep_bits(M, n_random=1_000_000 if name in R.FORMATS else 100_000, seed=1)
+        for scale in (1.0, 0.125, 4.0, 0.3, 7.3e-3):
+            for rounding in range(8):
+                if name not in R.FORMATS and (rounding not in (0, 4) or scale not in (1.0, 0.3)): continue
+                a = R.fq_float_t(x, [scale], [0.0], E, M, -c, c, rounding)
+                b = O.fq_float_t(x, [np.float32(scale)], [np.float32(0)], E, M, -c, c, rounding)
+                same = _nan_equal_bits(a, b)
+                assert same.all(), (name, scale, rounding, [(hex(int(x.view(np.uint32)[i])), a[i], b[i]) for i in np.nonzero(~same)[0][:5]])
+        for offset, clip in ((3.0, c), (-0.75, c), (0.0, 1e30)):
+            a = R.fq_float_t(x, [0.5], [offset], E, M, -clip, clip, 0)
+            b = O.fq_float_t(x, [np.float32(0.5)], [np.float32(offset)], E, M, -clip, clip, 0)
+            assert _nan_equal_bits(a, b).all(), (name, offset, clip)
+    # per-channel layout (floating.cu:86-95)
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((3, 5, 7, 2)) * 20).astype(np.float32)
+    s = (2.0 ** rng.integers(-4, 3, 5)).astype(np.float32); o = rng.integers(-2, 3, 5).astype(np.float32)
+    assert np.array_equal(R.fq_float_c(x, s, o, 1).view(np.uint32), O.fq_float_c(x, s, o, 1).view(np.uint32))
+    # _round2int: every mode on ties, near-ties and ordinary values (|v| < 2^31: host float->int conversion is defined there)
+    v = np.concatenate([np.arange(-64, 65) / 8.0, [0.49999997, -0.49999997, 8388607.5, -8388607.5, 1e9, -1e9, 2.5e-7],
+                        rng.standard_normal(20000) * 1000]).astype(np.float32)
+    for rounding in range(8):
+        for a in v: assert R.round2int(float(a), rounding) == O.round2int(float(a), rounding), (rounding, a)
+    # the linear kernel body (linear.cu:49-57) with the reference's QuantizeScalar / DequantizeScalar, every mode, fractional offsets
+    x = (rng.standard_normal(200_000) * 40).astype(np.float32)
+    for rounding in range(8):
+        for scale, offset, qmin, qmax in ((0.31, 0.0, -128, 127), (0.05, 127.5, 0, 255), (1.7, -2.5, -8, 7)):
+            a = R.fq_linear_t(x, [scale], [offset], qmin, qmax, rounding)
+            b = O.fq_linear_t(x, np.float32([scale]), np.float32([offset]), qmin, qmax, rounding)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (rounding, scale, offset)
+
+
+def test_fp8_and_rounding_restatement_equals_reference_goldens(golden_dir):
+    """The same pin without the reference on the machine: tests/golden/fp8_ref.npz holds outputs the reference's
+    common.cuh produced (make_golden.py::gen_fp8_ref) -- 2 formats x (4 scales RNE + 7 other rounding modes + a raw
+    offset + a clip wider than the format) on the structured sweep, and _round2int in all 8 modes."""
+    from oracle import ref_common as R
+    z = np.load(os.path.join(golden_dir, 'fp8_ref.npz'))
+    for key, fmt, scale, offset, clip, rounding in R.fp8_ref_cases():
+        E, M, c = R.FORMATS[fmt]
+        if clip is not None: c = clip
+        x = R.sweep_bits(M, n_random=8192, seed=0)
+        got = O.fq_float_t(x, np.float32([scale]), np.float32([offset]), E, M, -c, c, rounding)
+        want = z[key].view(np.float32)
+        same = _nan_equal_bits(got, want)
+        assert same.all(), (key, [(hex(int(x.view(np.uint32)[i])), got[i], want[i]) for i in np.nonzero(~same)[0][:5]])
+    v, want = z['round_values'], z['round_results']
+    for rounding in range(8):
+        got = np.array([O.round2int(float(a), rounding) for a in v], np.int32)
+        ok = got == want[rounding]
+        if not ok.all():       # host conversion of |v| >= 2^31 is undefined in the golden's producer; the oracle saturates
+            assert all(abs(float(v[i])) >= 2.0 ** 31 for i in np.nonzero(~ok)[0]), (rounding, v[~ok], got[~ok], want[rounding][~ok])
