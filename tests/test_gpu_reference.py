@@ -73,15 +73,32 @@ def test_reference_executor_and_calibration_pass_on_hip(topology, batch, size, m
             for c, v in op.config_with_variable
             if not v.is_parameter and int(getattr(c.state, 'value', c.state)) == 4 and c.scale is not None}
     assert set(ours) == set(ref_scales), (sorted(set(ours) ^ set(ref_scales)))
-    off = {k: (ours[k], ref_scales[k]) for k in ours if abs(ours[k] - ref_scales[k]) > 1e-6 * ref_scales[k]}
-    # The two executors run the vendor convolutions separately and those are not bit-reproducible from call to call on
-    # the large topology (algorithm choice depends on the workspace the allocator can offer at that moment): a histogram
-    # count that moves by one can flip the KL arg-min of a tensor to the neighbouring candidate.  Seen once in three full
-    # suite runs, never in isolation.  So: every scale equal on the small topologies; on ResNet-50 at most 2 of 72 may
-    # land on a neighbouring candidate (< 15 % apart), the rest equal to 1e-6.
-    allowed = 2 if topology == 'resnet50' else 0
-    assert len(off) <= allowed, off
-    assert all(abs(a - b) <= 0.15 * b for a, b in off.values()), off
+    if topology == 'small_cnn':
+        off = {k: (ours[k], ref_scales[k]) for k in ours if abs(ours[k] - ref_scales[k]) > 1e-6 * ref_scales[k]}
+        assert not off, off
+        return
+    # ResNet-50: the two executors run the vendor convolutions separately, and those are not bit-reproducible from call to
+    # call on the large topology (a histogram count that moves by one can flip a KL arg-min to the neighbouring candidate).
+    # Scale equality on ResNet-50 is therefore asserted where both stacks are shown the SAME bits -- all 72 configs, no
+    # allowance: tests/test_gpu_plugin_seam.py (the reference executor's activations recorded once, replayed into the
+    # reference's pass, into this package's observers inside it, and into this package's pass).  Here: the two executors
+    # compute the same network (every calibrated activation agrees to float noise), and the scales agree to within one KL
+    # candidate step everywhere.
+    names = sorted(ref_scales)
+    rg2, rex2 = RI.quantize_reference_graph(RI.to_reference_graph(build(seed=0)), DEV, batches[0], bins=2048, method=method)
+    hg2 = build(seed=0)
+    harness.quantize_graph(hg2, method, hist_bins=2048)
+    hex2 = harness.TorchExecutor(hg2, DEV)
+    harness.ParameterQuantizePass().optimize(hg2)                      # weights quantised, activations still INITIAL (pass-through)
+    a = rex2.forward(batches[0], output_names=names)
+    b = hex2.forward(batches[0], names)
+    compared = 0
+    for n, x, y in zip(names, a, b):
+        if x is None or y is None: continue                               # a graph input: neither executor returns it
+        assert x.shape == y.shape and float((x - y).abs().max()) <= 1e-4 * max(float(x.abs().max()), 1e-6), n
+        compared += 1
+    assert compared >= 70
+    assert all(abs(ours[k] - ref_scales[k]) <= 0.15 * ref_scales[k] for k in ours)
 
 
 def test_reference_lsq_pass_on_hip_vs_this_package():
