@@ -22,6 +22,16 @@ separately, gfx950 correction applied -- null when rocprofv3 is unavailable), `c
 USING_CUDA_KERNEL=False PyTorch-CPU path (oracle/torch_cpu_path.py, or the reference itself when a staged
 copy is importable) on a bounded sample of the same workload, `cpu_ops` the per-op table of BASELINE.md
 section 3 (N == 1 only).
+
+`config.variants` (N == 1, default run) also carries, each timed on this box in this run:
+  * SURVEY 8(d)'s own protocol (batch 1 x 256 steps) with its wall time decomposed by phase / render and the eager step's
+    host-issue vs device time;
+  * the same pass with `reuse_activations`;
+  * the two PLUGIN SEAMS inside the unmodified reference (when a staged copy is importable): reference executor + pass +
+    observers on these kernels (`install_into_ppq`), and reference executor driving THIS package's pass + observers
+    (`install_plugins_into_ppq`) -- the reference is the host there, what is measured is this library underneath it;
+  * BASELINE configs 3, 4 and 5 as short child runs of this file (`--workload resnet50_cfg3 | vit_b16_fp8 |
+    yolov6s_int4_lsq`), each with the roofline entry of ITS dominant kernel (hist_asym_t, fq_float_*, lsq_bwd_*).
 """
 import argparse
 import csv
@@ -130,6 +140,8 @@ WORKLOADS = {
     'resnet50': ('ResNet-50 topology (53 Conv + 1 Gemm, BN folded, seeded He init), per-tensor INT8 activations, per-channel INT8 weights', None),
     'resnet50_cfg3': ('BASELINE config 3: ResNet-50 topology, per-channel ASYMMETRIC INT8 weights + per-tensor asymmetric activations, MSE clipping search', 'mse'),
     'vit_b16_fp8': ('BASELINE config 4: ViT-B/16 topology (86.6 M parameters), TRT_FP8 policy: FP8 E4M3 inputs of Conv / Gemm / MatMul, power-of-2 scales from the floating observer', 'floating'),
+    'yolov6s_int4_lsq': ('BASELINE config 5: YOLOv6-s-like detector (56 Conv, 17 M parameters, 6 outputs), INT4 per-channel weights + INT8 activations, '
+                         'block-wise LearnedStepSizePass (block_size 5: 27 blocks) through the HIP forward / LSQ-backward kernels', 'minmax'),
 }
 
 
@@ -153,7 +165,7 @@ def build_workload(dev, bins, method, cache_params=False, fuse_params=True, chan
 
 
 def run_pass(graph, ex, batches, steps, method, async_observe=False, hip_graph=False, batch_observations=True,
-             reuse_activations=False, queue_bytes=None):
+             reuse_activations=False, queue_bytes=None, decompose=None):
     from ppq_amd.calibration import RuntimeCalibrationPass
     p = RuntimeCalibrationPass(method=method, check_steps=False, async_observe=async_observe, use_hip_graph=hip_graph,
                                batch_observations=batch_observations, reuse_activations=reuse_activations,
@@ -173,6 +185,19 @@ def run_pass(graph, ex, batches, steps, method, async_observe=False, hip_graph=F
             inner_render()
             torch.cuda.synchronize(); TRACE_STEPS.append((a, time.perf_counter()))
         p._render = traced_render
+    if decompose is not None:            # wall time of each forward loop and each render (synchronised on both sides)
+        inner_cal, inner_ren = p.calibrate, p._render
+
+        def cal(**kw):
+            torch.cuda.synchronize(); a = time.perf_counter()
+            inner_cal(**kw)
+            torch.cuda.synchronize(); decompose.setdefault('forward_loops_ms', []).append(round((time.perf_counter() - a) * 1e3, 2))
+
+        def ren():
+            torch.cuda.synchronize(); a = time.perf_counter()
+            inner_ren()
+            torch.cuda.synchronize(); decompose.setdefault('renders_ms', []).append(round((time.perf_counter() - a) * 1e3, 2))
+        p.calibrate, p._render = cal, ren
     p.optimize(graph, dataloader=batches, executor=ex, calib_steps=steps)
     return p
 
@@ -275,6 +300,177 @@ def cpu_baseline(bins, target_samples=32, batch_samples=4, budget_s=30.0):
                               'sample': f'4 samples, torch-CPU dense ops + single-threaded C restatement of the kernels; {psecs:.1f} s'}}
 
 
+def roofline_entry(prof_rows, prefer=None):
+    """The `roofline` object for the dominant library kernel of `prof_rows` (or the first row whose name starts with one of
+    `prefer`).  An event pair reports kernel duration + the command processor's timestamp / dispatch overhead; the library
+    measures that overhead with EMPTY pairs on the same stream and it is subtracted, so avg_launch_us is comparable with
+    rocprofv3's begin->end kernel duration.  The raw pair time is reported next to it."""
+    from ppq_amd import _lib
+    if not prof_rows: return None
+    _lib.lib.ppqhip_prof_event_overhead_us(torch.cuda.current_stream().cuda_stream, 16)      # warm
+    overhead_us = max(0.0, float(_lib.lib.ppqhip_prof_event_overhead_us(torch.cuda.current_stream().cuda_stream, 256)))
+    rows = [r for r in prof_rows if prefer and r['name'].startswith(tuple(prefer))] or prof_rows
+    dom = max(rows, key=lambda r: r['total_ms'])
+    raw_s = dom['total_ms'] * 1e-3 / dom['launches']
+    avg_s = max(raw_s - overhead_us * 1e-6, 0.25 * raw_s)
+    avg_b = dom['total_bytes'] / dom['launches']
+    ach = avg_b / avg_s / 1e9
+    return {'kernel': dom['name'], 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS,
+            'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': None, 'traffic_source': None,
+            'launches': dom['launches'], 'avg_launch_us': round(avg_s * 1e6, 2),
+            'avg_event_pair_us': round(raw_s * 1e6, 2), 'event_overhead_us': round(overhead_us, 2),
+            'algorithmic_bytes_per_launch': round(avg_b),
+            'frac_of_measured_copy_ceiling': round(ach / 6290.0, 4)}      # MI355X_MICROARCH.md: 6.29 TB/s float4 copy
+
+
+def seam_variants(dev, batches, steps, bins, method):
+    """The plugin seams INSIDE the unmodified reference, timed on this box: the reference's own BaseGraph +
+    TensorRT quantizer + TorchExecutor are the host (driven through oracle/reference_import.py, which only imports and calls
+    the staged reference); what runs underneath, and what is measured, is this library:
+      kernels : reference pass + reference observers, kernels = libppq_hip.so              (ppq_amd.install_into_ppq)
+      pass    : THIS package's RuntimeCalibrationPass + observers in the reference's ppq.lib.Pipeline on the reference's
+                executor                                                                   (ppq_amd.install_plugins_into_ppq)
+    One warm pass (MIOpen, allocator) + two timed ones each; the better one is reported."""
+    stage = staged_reference()
+    if stage is None: return []
+    out = []
+    try:
+        import ppq_amd
+        from ppq_amd import harness
+        from ppq_amd.calibration import RuntimeCalibrationPass as OurPass
+        from oracle import reference_import as RI
+        RI.load(stage)
+        ppq_amd.install_plugins_into_ppq(observers=False)
+        import ppq.lib as PFL
+        from ppq.quantization.optim import RuntimeCalibrationPass as RefPass
+        n = max(8, steps)                                   # the reference asserts calib_steps >= 8 and cycles the loader
+        for stack in ('kernels', 'pass'):
+            times, checksum = [], None
+            for rep in range(3):
+                rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(harness.resnet50_graph(seed=0)), dev, batches[0], bins=bins, method=method)
+                p = RefPass(method=method) if stack == 'kernels' else OurPass(method=method, check_steps=False)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                if stack == 'kernels': p.optimize(graph=rg, dataloader=batches, executor=rex, calib_steps=n, collate_fn=None)
+                else: PFL.Pipeline([p]).optimize(graph=rg, dataloader=batches, executor=rex, calib_steps=n, collate_fn=None, verbose=False)
+                torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+                checksum = float(sum(RI.activation_scales(rg).values()))
+                del rg, rex, p
+            best = min(times[1:])
+            samples = n * batches[0].shape[0]
+            out.append({'workload': {'kernels': "UNMODIFIED reference (its executor, RuntimeCalibrationPass and observers) with libppq_hip.so as its kernel extension: install_into_ppq()",
+                                     'pass': "reference executor + BaseGraph driving ppq_amd's RuntimeCalibrationPass + observers inside ppq.lib.Pipeline: install_plugins_into_ppq()"}[stack]
+                                    + f'; ResNet-50 {method} {bins} bins, {n} x {batches[0].shape[0]}',
+                        'seam': stack, 'samples': samples, 'value': round(samples / best, 2), 'unit': 'samples/s',
+                        'ms_per_step': round(best / n * 1e3, 3), 'scale_checksum': checksum})
+    except Exception as e:            # a broken stage must not cost the bench line
+        print(f'[bench] seam variants skipped: {type(e).__name__}: {e}', file=sys.stderr)
+    finally:
+        try:
+            import ppq_amd
+            ppq_amd.uninstall_from_ppq()          # the cpu_baseline leg times the reference on ITS OWN torch-CPU path
+        except Exception: pass
+    return out
+
+
+def workload_variants(args):
+    """BASELINE configs 3, 4, 5 as short child runs of this file: each line's value + the roofline entry of its dominant
+    kernel.  Children skip baselines, PMC passes and their own variants; MIOpen immediate mode keeps their warm-up short."""
+    out = []
+    for name, extra in (('resnet50_cfg3', ['--steps', '4', '--batch', '32']), ('vit_b16_fp8', ['--steps', '4', '--batch', '16']),
+                        ('yolov6s_int4_lsq', ['--steps', '8', '--batch', '8'])):
+        cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--warmup', '1', '--repeats', '1', '--variants', '0', '--pmc', '0',
+               '--no-cpu-baseline', '--no-cpu-ops', '--settle-ms', '0', '--miopen-find', '0'] + extra
+        try:
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+            if r.returncode != 0 or not line:
+                out.append({'workload': name, 'error': (r.stderr or r.stdout)[-300:]}); continue
+            j = json.loads(line[-1])
+            roof = j.get('roofline') or {}
+            out.append({'workload': j['config']['workload'], 'name': name, 'metric': j['metric'], 'value': j['value'], 'unit': j['unit'],
+                        'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'child_wall_s': round(time.perf_counter() - t0, 1),
+                        'roofline': {k: roof.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'launches', 'avg_launch_us',
+                                                              'algorithmic_bytes_per_launch')}})
+        except Exception as e:
+            out.append({'workload': name, 'error': f'{type(e).__name__}: {e}'})
+    return out
+
+
+def main_lsq(args, rank, world, dev):
+    """--workload yolov6s_int4_lsq (BASELINE config 5): a *step* is one optimizer step of the block-wise LearnedStepSizePass
+    on one batch (forward through the block with the HIP fake-quant kernels, backward through the LSQ kernels, Adam); the
+    timed region is one LearnedStepSizePass.optimize over all 27 blocks with `--steps` steps each (it includes the pass's own
+    collection of FP32 targets / quantised block inputs).  value = blocks x steps x batch / time, aggregated over ranks
+    (data parallel: each rank its own batches, ONE flat gradient all-reduce per step)."""
+    import ppq_amd  # noqa: F401
+    from ppq_amd import _lib, harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    from ppq_amd.lsq import LearnedStepSizePass
+    size = 320
+    g = torch.Generator(device=dev).manual_seed(4321 + rank)
+    batches = [torch.rand(args.batch, 3, size, size, device=dev, generator=g) for _ in range(4)]
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        group = dist.group.WORLD
+
+    def build():
+        graph = harness.yolov6s_graph(seed=3)
+        harness.quantize_graph(graph, 'minmax')
+        for op in graph.operations.values():                        # weights -> int4 [-8, 7]
+            for cfg, var in op.config_with_variable:
+                if var.is_parameter and cfg.state.value == 1: cfg.num_of_bits, cfg.quant_min, cfg.quant_max = 4, -8, 7
+        ex = harness.TorchExecutor(graph, dev)
+        harness.ParameterQuantizePass().optimize(graph)
+        RuntimeCalibrationPass(check_steps=False).optimize(graph, dataloader=batches, executor=ex, calib_steps=len(batches))
+        return graph, ex
+    if args.warmup > 0:
+        graph, ex = build()
+        LearnedStepSizePass(steps=1, lr=1e-5, block_size=5, process_group=group).optimize(graph, batches[:1], ex)
+        del graph, ex
+    times, p = [], None
+    for rep in range(max(1, args.repeats)):
+        graph, ex = build()
+        p = LearnedStepSizePass(steps=args.steps, lr=1e-5, block_size=5, process_group=group)
+        barrier(world); t0 = time.perf_counter()
+        p.optimize(graph, batches, ex)
+        barrier(world); elapsed = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+        times.append(elapsed)
+        del ex
+    elapsed = sorted(times)[len(times) // 2]
+    blocks = len(p.report)
+    roof, prof_rows = None, []
+    if rank == 0 and world == 1:
+        graph2, ex2 = build()
+        torch.cuda.synchronize(); _lib.lib.ppqhip_prof_enable(1)
+        LearnedStepSizePass(steps=min(args.steps, 4), lr=1e-5, block_size=5).optimize(graph2, batches, ex2)
+        torch.cuda.synchronize(); _lib.lib.ppqhip_prof_enable(0)
+        prof_rows = collect_prof()
+        roof = roofline_entry(prof_rows, prefer=('fq_linear_t_bwd', 'fq_linear_c_bwd'))
+    if rank == 0:
+        total_steps = blocks * args.steps
+        samples = world * total_steps * args.batch
+        print(json.dumps({
+            'metric': 'LSQ finetune samples/sec (block-wise LearnedStepSizePass, YOLOv6-s-like INT4 weights)', 'value': round(samples / elapsed, 2),
+            'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / total_steps * 1e3, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (INT4 / INT8 simulated)', 'data': 'synthetic',
+            'repeats': len(times), 'values': [round(samples / t, 2) for t in times],
+            'config': {'workload': f'{WORKLOADS[WORKLOAD][0]}; {blocks} blocks x {args.steps} Adam steps x batch {args.batch} x 3x{size}x{size} per GPU '
+                                   f'(timed: the whole pass incl. its target / input collection)', 'samples': samples, 'batch': args.batch,
+                       'blocks': blocks, 'optimizer_steps': total_steps, 'kept_blocks': sum(1 for _, a, b in p.report if b <= a),
+                       'parallelism': f'dp{world} (one flat gradient all-reduce per step)', 'rccl_ranks': world},
+            'roofline': roof, 'cpu_baseline': None,
+            'kernels': [{'name': r['name'], 'launches': r['launches'], 'total_ms': round(r['total_ms'], 3),
+                         'GBps': round(r['total_bytes'] / max(r['total_ms'], 1e-9) / 1e6, 1)} for r in prof_rows]}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -323,6 +519,7 @@ def main():
     dev = f'cuda:{local}'
     import ppq_amd  # noqa: F401  (fails loudly without libppq_hip.so)
     from ppq_amd import _lib
+    if WORKLOAD == 'yolov6s_int4_lsq': return main_lsq(args, rank, world, dev)
 
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     batches = [torch.rand(args.batch, 3, 224, 224, device=dev, generator=g) for _ in range(args.steps)]
@@ -388,12 +585,20 @@ def main():
         for _ in range(2):                 # first pass warms MIOpen's batch-1 kernels, second is reported
             graph_v, ex_v = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params, bool(args.channels_last))
             barrier(world); tv = time.perf_counter()
-            pv = run_pass(graph_v, ex_v, vb, 256, args.method, False, 'auto', bool(args.batch_observations))
+            parts = {}
+            pv = run_pass(graph_v, ex_v, vb, 256, args.method, False, 'auto', bool(args.batch_observations), decompose=parts)
             barrier(world); vtimes.append(time.perf_counter() - tv)
             del graph_v, ex_v
+        # where the wall time goes: the two forward loops (256 forwards each; the first steps eager, the rest one HIP-graph
+        # replay per step when 'auto' found the eager step launch-bound: issue_ms = host time to enqueue one eager forward,
+        # total_ms = until the device drained it) and the two renders (range fetch; histogram fold + batched KL search)
         variants.append({'workload': 'batch 1 x 256 steps (SURVEY 8(d) protocol), HIP-graph replay auto', 'samples': 256,
                          'value': round(256 / vtimes[-1], 2), 'unit': 'samples/s', 'ms_per_step': round(vtimes[-1] / 256 * 1e3, 3),
-                         'graph_replays': pv.graph_replays})
+                         'graph_replays': pv.graph_replays,
+                         'decomposition': {'wall_ms': round(vtimes[-1] * 1e3, 1), **parts,
+                                           'ms_per_forward': [round(v / 256, 3) for v in parts.get('forward_loops_ms', [])],
+                                           'eager_step': [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in d.items()}
+                                                          for d in pv.graph_decisions]}})
         del vb, pv
     if args.variants and world == 1 and not args.reuse_activations:
         # MI355X-first variant of the SAME pass (not the headline: the reference's protocol runs every batch twice):
@@ -411,6 +616,11 @@ def main():
                          'replayed_batches': pv.replayed_batches, 'resident_MiB': round(pv.replay_peak_bytes / 2 ** 20),
                          'scale_checksum': check_v})
         del graph_v, ex_v, pv
+
+    if args.variants and world == 1 and WORKLOAD == 'resnet50':
+        variants += seam_variants(dev, batches, args.steps, args.bins, args.method)
+        torch.cuda.empty_cache()
+        variants += workload_variants(args)
 
     # roofline leg: the identical pass once more with hipEvent pairs around every library launch
     roof = None
@@ -431,24 +641,7 @@ def main():
         _lib.lib.ppqhip_prof_enable(0)
         prof_rows = collect_prof()
         del graph2, ex2
-        if prof_rows:
-            # An event pair reports kernel duration + the command processor's timestamp / dispatch
-            # overhead; the library measures that overhead with EMPTY pairs on the same stream and it is
-            # subtracted, so avg_launch_us is comparable with rocprofv3's begin->end kernel duration
-            # (profiles/r02_bench_kernel_stats.csv).  The raw pair time is reported next to it.
-            _lib.lib.ppqhip_prof_event_overhead_us(torch.cuda.current_stream().cuda_stream, 16)      # warm
-            overhead_us = max(0.0, float(_lib.lib.ppqhip_prof_event_overhead_us(torch.cuda.current_stream().cuda_stream, 256)))
-            dom = max(prof_rows, key=lambda r: r['total_ms'])
-            raw_s = dom['total_ms'] * 1e-3 / dom['launches']
-            avg_s = max(raw_s - overhead_us * 1e-6, 0.25 * raw_s)
-            avg_b = dom['total_bytes'] / dom['launches']
-            ach = avg_b / avg_s / 1e9
-            roof = {'kernel': dom['name'], 'bound': 'hbm', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBPS,
-                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBPS, 4), 'traffic': None, 'traffic_source': None,
-                    'launches': dom['launches'], 'avg_launch_us': round(avg_s * 1e6, 2),
-                    'avg_event_pair_us': round(raw_s * 1e6, 2), 'event_overhead_us': round(overhead_us, 2),
-                    'algorithmic_bytes_per_launch': round(avg_b),
-                    'frac_of_measured_copy_ceiling': round(ach / 6290.0, 4)}      # MI355X_MICROARCH.md: 6.29 TB/s float4 copy
+        roof = roofline_entry(prof_rows, prefer={'vit_b16_fp8': ('fq_float',), 'resnet50_cfg3': ('hist_asym_t',)}.get(WORKLOAD))
     if world > 1:
         barrier(world)
     torch.cuda.empty_cache()

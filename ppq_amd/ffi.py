@@ -744,6 +744,14 @@ def install_into_ppq() -> None:
     REF_CONFIG.USING_CUDA_KERNEL = True
 
 
+def uninstall_from_ppq() -> None:
+    """Undo :func:`install_into_ppq`: PPQ is back on its own torch path (USING_CUDA_KERNEL False, no extension)."""
+    from ppq.core import PPQ_CONFIG as REF_CONFIG
+    from ppq.core.ffi import CUDA_COMPLIER as REF_COMPLIER
+    REF_COMPLIER.__CUDA_EXTENTION__ = None
+    REF_CONFIG.USING_CUDA_KERNEL = False
+
+
 def install_plugins_into_ppq(observers: bool = True) -> None:
     """The higher seams (last row), on top of :func:`install_into_ppq`: make this package's observers and
     passes first-class citizens of an importable, UNMODIFIED PPQ -- nothing of PPQ is edited, only its own registration
