@@ -183,25 +183,38 @@ int ppqhip_hist_asym_c_ranges(const float* x, int64_t n, int64_t num_channel, in
 
 /* order statistics ---------------------------------------------------------------------------- */
 /* replaces Quantile_T, sort.cu:42-59 (CUDA.Quantile ffi.py:171-176): dest[0] = sorted[rn(n*q)],
- * dest[1] = sorted[rn(n*(1-q))], indices clamped to [0, n-1].  Implemented as a sample-guided radix
- * select that reads the tensor once in the usual case (never a sort, never a copy of the data).
+ * dest[1] = sorted[rn(n*(1-q))], indices clamped to [0, n-1].  Never a sort, never a copy of the data: one
+ * streaming pass FILTERS the keys beyond two thresholds into short lists and the order statistics are selected
+ * inside them; sides the filter cannot settle go through an exact 3-pass radix select.  The result is exact
+ * in every case (quantile.hip).
+ * `hint`: NULL, or 8 uint32 words of caller-owned device memory, zero-initialised, that belong to ONE
+ * stream of similar tensors (an observer: the same activation, batch after batch).  The library keeps the
+ * thresholds that worked in it, and the next call with the same n and q skips the sampling launch that
+ * otherwise estimates them (words: [0] hi valid, [1] T_hi key, [2] lo valid, [3] T_lo key, [4] n, [5] k_hi,
+ * [6] k_lo, [7] calls settled from the hint).  A stale or foreign hint costs time, never correctness.
  * `workspace` is device scratch of ppqhip_quantile_workspace_bytes(n) bytes. */
 int64_t ppqhip_quantile_workspace_bytes(int64_t n);
-int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, void* workspace,
+int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, uint32_t* hint, void* workspace,
                       void* stream);
 
-/* many tensors, one launch per pass: dest_k[0..1] = (q, 1-q) order statistics of job k exactly as
- * ppqhip_quantile_t.  `jobs` is a HOST array (copied into the kernel arguments); workspace holds
- * ppqhip_quantile_multi_workspace_bytes(num_jobs, total_elems) bytes, total_elems = the sum of the
- * jobs' n (the speculative key lists are sized n / 128 per job and side, 4096 keys at least). */
+/* many tensors, ONE launch sequence (7 launches, any number of jobs: the job table is device
+ * resident): dest_k[0..1] = (q, 1-q) order statistics of job k exactly as ppqhip_quantile_t.  `jobs` is a
+ * HOST array; workspace holds ppqhip_quantile_multi_workspace_bytes(num_jobs, total_elems) bytes,
+ * total_elems = the sum of the jobs' n (the filter lists are sized n / 128 per job and side, 16384 keys at
+ * least). */
 typedef struct ppqhip_quantile_job {
     const float* x;   /* device, n floats */
     float* dest;      /* device, 2 floats */
+    uint32_t* hint;   /* device, 8 words, or NULL (see ppqhip_quantile_t) */
     int64_t n;
 } ppqhip_quantile_job;
 int64_t ppqhip_quantile_multi_workspace_bytes(int num_jobs, int64_t total_elems);
 int ppqhip_quantile_t_multi(const ppqhip_quantile_job* jobs, int num_jobs, float q, void* workspace,
                             void* stream);
+/* developer aid (tools/quantile_diag.py): where a finished call left its per-job state inside `workspace` --
+ * out[0] bytes before job 0's state, [1] words per job, [2] side records, [3] filter record, [4] tickets,
+ * [5] byte offset of the job table, [6] / [7] word offsets of the list / tie counters in the filter record. */
+void ppqhip_quantile_debug_layout(int64_t* out);
 
 /* replaces Isotone_T, sort.cu:61-73: dest = [max, 2nd max, min, 2nd min] (with multiplicity).
  * `workspace`: device scratch of ppqhip_quantile_workspace_bytes(n) bytes (shared sizing). */

@@ -48,7 +48,7 @@ PROTOTYPES = {
     'ppqhip_hist_sym_c_scales': (c_int, [c_f32p, c_i64, c_i64, c_i64, c_f32p, c_int, c_i32p, c_i64, c_vp]),
     'ppqhip_hist_asym_c_ranges': (c_int, [c_f32p, c_i64, c_i64, c_i64, c_f32p, c_f32p, c_int, c_i32p, c_i64, c_vp]),
     'ppqhip_quantile_workspace_bytes': (c_i64, [c_i64]),
-    'ppqhip_quantile_t': (c_int, [c_f32p, c_i64, c_flt, c_f32p, c_vp, c_vp]),
+    'ppqhip_quantile_t': (c_int, [c_f32p, c_i64, c_flt, c_f32p, c_vp, c_vp, c_vp]),
     'ppqhip_isotone_t': (c_int, [c_f32p, c_i64, c_f32p, c_vp, c_vp]),
     'ppqhip_minmax_workspace_bytes': (c_i64, [c_i64]),
     'ppqhip_minmax_t': (c_int, [c_f32p, c_i64, c_f32p, c_vp, c_vp]),
@@ -61,6 +61,7 @@ PROTOTYPES = {
     'ppqhip_fq_float_multi': (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     'ppqhip_quantile_multi_workspace_bytes': (c_i64, [c_int, c_i64]),
     'ppqhip_quantile_t_multi': (c_int, [c_vp, c_int, c_flt, c_vp, c_vp]),
+    'ppqhip_quantile_debug_layout': (None, [c_vp]),
     'ppqhip_minmax_t_slots_multi': (c_int, [c_vp, c_int, c_vp]),
     'ppqhip_hist_t_rows_multi': (c_int, [c_vp, c_int, c_int, c_int, c_i64, c_vp]),
     'ppqhip_channel_sum': (c_int, [c_f32p, c_i64, c_i64, c_i64, c_f64p, c_vp]),

@@ -145,19 +145,20 @@ __device__ __forceinline__ float block_sum(float v, float* lds) {
 }
 
 // per tensor: one contiguous chunk per workgroup, 16-B loads of x and dy, 16-B stores of grad_x;
-// the workgroup's partial d(loss)/d(scale) goes to partial[blockIdx.x] (no same-address atomics),
-// lsq_finish_kernel sums the partials in double and applies grad_factor.
+// the workgroup's partial d(loss)/d(scale) goes to partial[blockIdx.x]; the last workgroup to finish sums
+// the partials in double, in a fixed order, and applies grad_factor (one launch, deterministic).
 #ifndef PPQHIP_LSQ_U
 #define PPQHIP_LSQ_U 4                  // (x, dy) 16-B load pairs in flight per lane (MI355X sweep, Bx32: U=1 152 us, 2 127, 4 116)
 #endif
 #ifndef PPQHIP_LSQ_MAX_WG
 #define PPQHIP_LSQ_MAX_WG 65536         // workgroups per launch (one partial sum each)
 #endif
+constexpr uint32_t kLsqShards = 32;
 template <int R, bool NT>
 __global__ __launch_bounds__(kBlock) void fq_linear_t_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
     const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ partial, uint32_t n, int vec_ok,
-    int qmin, int qmax, int rounding) {
+    int qmin, int qmax, int rounding, uint32_t* __restrict__ tickets, float grad_factor, float* __restrict__ gs) {
     __shared__ float lds[kBlock / kWave];
     const float s = scale[0];
     const float rcp_s = 1.0f / s;
@@ -203,22 +204,40 @@ __global__ __launch_bounds__(kBlock) void fq_linear_t_bwd_kernel(
         gx[i] = g;
     }
     const float tot = block_sum(acc, lds);
-    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
-}
-
-__global__ __launch_bounds__(kBlock) void lsq_finish_kernel(const float* __restrict__ partial, uint32_t count,
-                                                            float grad_factor, float* __restrict__ gs) {
-    __shared__ double lds[kBlock / kWave];
-    double acc = 0.0;
-    for (uint32_t i = threadIdx.x; i < count; i += kBlock) acc += (double)partial[i];
+    // One launch: the workgroup's partial goes out write-through, then the workgroup takes a ticket; the LAST one adds all
+    // partials in the fixed order of the former lsq_finish_kernel (double, 256 strided lanes) -- the same bits whoever is
+    // last.  The arrivals are spread over kLsqShards counters (one same-address device atomic per workgroup would
+    // serialise: 12544 workgroups x ~11 ns exceed the kernel's 100 us), whose last arrivers meet on one more.
+    // No fence: every partial is an sc1 store drained (vmcnt) before its ticket, and the reader uses sc1 loads.
+    __shared__ uint32_t last_flag;
+    const uint32_t G = gridDim.x, b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&partial[b], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t shard = b % kLsqShards;
+        const uint32_t in_shard = (G - shard + kLsqShards - 1) / kLsqShards;
+        bool last = false;
+        if (__hip_atomic_fetch_add(&tickets[shard], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_shard) {
+            const uint32_t shards = G < kLsqShards ? G : kLsqShards;
+            last = __hip_atomic_fetch_add(&tickets[kLsqShards], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == shards;
+        }
+        last_flag = last ? 1u : 0u;
+    }
+    __syncthreads();
+    if (last_flag == 0u) return;
+    __shared__ double dsum[kBlock / kWave];
+    double t = 0.0;
+    for (uint32_t i = threadIdx.x; i < G; i += kBlock)
+        t += (double)__hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    for (int m = 32; m > 0; m >>= 1) t += __shfl_xor(t, m, 64);
+    if ((threadIdx.x & 63) == 0) dsum[threadIdx.x >> 6] = t;
+    if (threadIdx.x <= kLsqShards) tickets[threadIdx.x] = 0u;          // leave the counters as they were found
     __syncthreads();
     if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int w = 0; w < kBlock / kWave; w++) t += lds[w];
-        gs[0] = (float)t * grad_factor;
+        double all = 0.0;
+        for (int w = 0; w < kBlock / kWave; w++) all += dsum[w];
+        gs[0] = (float)all * grad_factor;
     }
 }
 
@@ -548,17 +567,16 @@ int ppqhip_fq_linear_t_bwd(const float* x, const float* scale, const float* offs
     // lsq_bwd_c, which has always been tiled by rows, ran 10 % faster than the persistent form of this kernel)
     const int grid = stream_grid(n, kBlock * 4 * PPQHIP_LSQ_U, PPQHIP_LSQ_MAX_WG);
     float* partial = (float*)scratch(s, sizeof(float) * (size_t)grid);
-    if (partial == nullptr) return PPQHIP_ERR_HIP;
+    uint32_t* tick = tickets(s);
+    if (partial == nullptr || tick == nullptr) return PPQHIP_ERR_HIP;
     const int vec_ok = (aligned16(x) && aligned16(grad_y) && aligned16(grad_x)) ? 1 : 0;
     const bool nt = n >= kStreamElems / 2;       // x and dy together exceed cache residency: streaming loads
 #define PPQ_LAUNCH_LSQ_T(R, NT)                                                                                     \
     hipLaunchKernelGGL((fq_linear_t_bwd_kernel<R, NT>), dim3(grid), dim3(kBlock), 0, s, x, scale, offset, grad_y,   \
-                       grad_x, partial, (uint32_t)n, vec_ok, clip_min, clip_max, rounding)
+                       grad_x, partial, (uint32_t)n, vec_ok, clip_min, clip_max, rounding, tick, grad_factor, grad_s)
     if (rounding == ROUND_HALF_EVEN) { if (nt) PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, true); else PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, false); }
     else { if (nt) PPQ_LAUNCH_LSQ_T(-1, true); else PPQ_LAUNCH_LSQ_T(-1, false); }
 #undef PPQ_LAUNCH_LSQ_T
-    hipLaunchKernelGGL(lsq_finish_kernel, dim3(1), dim3(kBlock), 0, s, (const float*)partial, (uint32_t)grid,
-                       grad_factor, grad_s);
     return finish_launch("fq_linear_t_bwd");
 }
 

@@ -136,7 +136,27 @@ _FQ_FLOAT_JOB = np.dtype([('x', '<u8'), ('scale', '<u8'), ('offset', '<u8'), ('o
                           ('clip_min', '<f4'), ('clip_max', '<f4')])
 _FLOAT_SEARCH_JOB = np.dtype([('x', '<u8'), ('rows', '<i8'), ('row_len', '<i8'), ('exponent', '<i4'), ('mantissa', '<i4'),
                               ('clip_min', '<f4'), ('clip_max', '<f4')])
-_QUANTILE_JOB = np.dtype([('x', '<u8'), ('dest', '<u8'), ('n', '<i8')])
+_QUANTILE_JOB = np.dtype([('x', '<u8'), ('dest', '<u8'), ('hint', '<u8'), ('n', '<i8')])
+
+# Quantile_T(source, q) is stateless in the reference; calibration calls it batch after batch on the same activation, so the
+# drop-in entry point keeps one threshold hint (include/ppq_hip.h: ppqhip_quantile_t) per (device, numel, q).  A hint only
+# ever changes how much the kernels read, never the result.
+_quantile_hints = {}
+_MAX_QUANTILE_HINTS = 4096
+
+
+def quantile_hint(device: torch.device) -> torch.Tensor:
+    """A fresh (zeroed) threshold hint for one stream of similar tensors: int32[8] on ``device``."""
+    return torch.zeros(8, dtype=torch.int32, device=device)
+
+
+def _cached_quantile_hint(device: torch.device, numel: int, q: float) -> torch.Tensor:
+    key = (device.index, int(numel), float(q))
+    h = _quantile_hints.get(key)
+    if h is None:
+        if len(_quantile_hints) >= _MAX_QUANTILE_HINTS: _quantile_hints.clear()
+        h = _quantile_hints[key] = quantile_hint(device)
+    return h
 _HIST_JOB = np.dtype([('x', '<u8'), ('rows', '<u8'), ('n', '<i8'), ('p0', '<f4'), ('p1', '<f4')])
 
 
@@ -420,20 +440,31 @@ class _HipExtension:
                                                  hist.numel() // C, _stream()))
 
     @ staticmethod
-    def Quantile_T(source, q: float) -> torch.Tensor:
+    def Quantile_T(source, q: float, hint='auto') -> torch.Tensor:
+        """``hint``: 'auto' (one cached hint per (device, numel, q)), None (none: every call estimates its thresholds
+        from a sample), or an int32[8] device tensor from ``quantile_hint`` owned by the caller."""
         _f32(source, 'Value')
         v = _dense(source)
         dest = torch.empty(2, dtype=torch.float32, device=v.device)
+        if isinstance(hint, str): hint = _cached_quantile_hint(v.device, v.numel(), q)
         with _DeviceOf(v):
             ws = _workspace(v.device, lib.ppqhip_quantile_workspace_bytes(v.numel()))
-            _raise(lib.ppqhip_quantile_t(v.data_ptr(), v.numel(), float(q), dest.data_ptr(), ws.data_ptr(),
-                                         _stream()))
+            _raise(lib.ppqhip_quantile_t(v.data_ptr(), v.numel(), float(q), dest.data_ptr(),
+                                         _HipExtension._hint_ptr(hint, v.device), ws.data_ptr(), _stream()))
         return dest
 
     @ staticmethod
-    def Quantile_T_Multi(sources, q: float, dests=None) -> list:
-        """One launch per pass for many tensors; each result as Quantile_T.  ``dests``: optional list of
-        preallocated float32[2] device tensors to fill."""
+    def _hint_ptr(hint, device) -> int:
+        if hint is None: return 0
+        if hint.dtype != torch.int32 or hint.numel() != 8 or not hint.is_contiguous() or hint.device != device:
+            raise RuntimeError(_KERNEL_FAILURE + 'a quantile hint is a contiguous int32[8] on the tensor\'s device')
+        return hint.data_ptr()
+
+    @ staticmethod
+    def Quantile_T_Multi(sources, q: float, dests=None, hints=None) -> list:
+        """One launch sequence for many tensors; each result as Quantile_T.  ``dests``: optional list of
+        preallocated float32[2] device tensors to fill; ``hints``: optional list (entries may be None) of
+        ``quantile_hint`` tensors, one per source."""
         if not sources: return []
         vs = []
         for v in sources:
@@ -445,9 +476,12 @@ class _HipExtension:
         for d in dests:
             _f32(d, 'Dest')
             if d.numel() != 2 or not d.is_contiguous(): raise RuntimeError(_KERNEL_FAILURE + 'dest must be a contiguous float32[2]')
+        if hints is None: hints = [None] * len(vs)
+        if len(hints) != len(vs): raise RuntimeError(_KERNEL_FAILURE + 'sources / hints length mismatch')
         jobs = np.empty(len(vs), dtype=_QUANTILE_JOB)
         jobs['x'] = [v.data_ptr() for v in vs]
         jobs['dest'] = [d.data_ptr() for d in dests]
+        jobs['hint'] = [_HipExtension._hint_ptr(h, vs[0].device) for h in hints]
         jobs['n'] = [v.numel() for v in vs]
         with _DeviceOf(vs[0]):
             ws = _workspace(vs[0].device, lib.ppqhip_quantile_multi_workspace_bytes(len(vs), sum(v.numel() for v in vs)))
@@ -833,8 +867,13 @@ class CUDA:
         return HIP_EXTENSION.Quantile_T(tensor, q)
 
     @ staticmethod
-    def Quantile_Multi(tensors, q: float, dests=None):
-        return HIP_EXTENSION.Quantile_T_Multi(tensors, q, dests)
+    def Quantile_Hinted(tensor, q: float, hint):
+        """CUDA.Quantile with the caller's threshold hint (``quantile_hint``), or None for none at all."""
+        return HIP_EXTENSION.Quantile_T(tensor, q, hint)
+
+    @ staticmethod
+    def Quantile_Multi(tensors, q: float, dests=None, hints=None):
+        return HIP_EXTENSION.Quantile_T_Multi(tensors, q, dests, hints)
 
     @ staticmethod
     def Isotone(tensor):

@@ -186,6 +186,7 @@ class TorchExecutor:
         self.fuse_parameter_quantization = True       # all weights of a forward in ONE launch: _fused_parameters
         self._plans: list = []
         self._plan_signature = None
+        self._plan_cache: Dict[tuple, list] = {}
         self._fused: Dict[tuple, torch.Tensor] = {}
         self._delegates: Dict[object, Callable] = {}
         self.channels_last = False                    # see use_channels_last()
@@ -226,13 +227,19 @@ class TorchExecutor:
         return TorchExecutor.forward.__wrapped__(self, inputs, output_names, hooks)
 
     def partial_graph_forward(self, operations: List[Operation], feed_dict: Dict[str, torch.Tensor],
-                              output_names: List[str]) -> List[torch.Tensor]:
+                              output_names: List[str], with_gradient: bool = False) -> List[torch.Tensor]:
         """ppq/executor/torch.py:654-730: run only `operations` (already in execution order) on the
-        given feeds -- the block forward of the training based passes."""
+        given feeds -- the block forward of the training based passes.  Like ``forward`` it records no autograd
+        graph unless ``with_gradient`` (the finetuning passes' training step) asks for one."""
+        if not with_gradient:
+            with torch.no_grad(): return self._partial_graph_forward(operations, feed_dict, output_names)
+        return self._partial_graph_forward(operations, feed_dict, output_names)
+
+    def _partial_graph_forward(self, operations, feed_dict, output_names):
         g = self._graph
         for name, value in feed_dict.items(): g.variables[name].value = self._place(value)
         results = [None] * len(output_names)
-        self._fused_parameters()
+        self._fused_parameters(operations)            # the multi-tensor plan covers the parameters of THESE operations only
         for op in operations:
             raw_in = [v.value for v in op.inputs]
             if any(x is None for x in raw_in):
@@ -252,7 +259,7 @@ class TorchExecutor:
             if not v.is_parameter: v.value = None
         return results
 
-    def _fused_parameters(self) -> None:
+    def _fused_parameters(self, operations=None) -> None:
         """Fake-quantise every parameter whose config is an activated, non-delegated LINEAR one with a
         single multi-tensor launch (ffi.LinearQuantizePlan -> ppqhip_fq_linear_multi) instead of one
         launch per weight; same per-forward work as the reference executor (torch.py:516-518), same
@@ -262,7 +269,7 @@ class TorchExecutor:
         if not self.fuse_parameter_quantization or self._default_quant_fn is not PPQuantFunction: return
         from .ffi import FloatingQuantizePlan, LinearQuantizePlan
         todo, sig = [], []
-        for op in self._graph.operations.values():
+        for op in (self._graph.operations.values() if operations is None else operations):
             if not isinstance(op, QuantableOperation): continue
             for v, c in zip(op.inputs, op.config.input_quantization_config):
                 if not (v.is_parameter and isinstance(v.value, torch.Tensor) and v.value.is_cuda): continue
@@ -282,6 +289,10 @@ class TorchExecutor:
         if not todo:
             self._plans, self._plan_signature = [], None
             return
+        cached = self._plan_cache.get(tuple(sig))
+        if cached is not None:
+            self._plan_cache[tuple(sig)] = self._plan_cache.pop(tuple(sig))          # most recently used last
+            self._plans, self._plan_signature = cached, sig
         if sig != self._plan_signature:
             groups: Dict[tuple, list] = {}
             for item in todo: groups.setdefault((item[3], item[4]), []).append(item)
@@ -295,6 +306,8 @@ class TorchExecutor:
                                                for v, c, axis, _, _ in items], rounding=rnd)
                 self._plans.append((plan, [(v.name, id(c)) for v, c, _, _, _ in items]))
             self._plan_signature = sig
+            if len(self._plan_cache) >= 8: self._plan_cache.pop(next(iter(self._plan_cache)))   # block / whole-graph plans alternate
+            self._plan_cache[tuple(sig)] = self._plans
         for plan, keys in self._plans:
             for key, out in zip(keys, plan.run()): self._fused[key] = out
 

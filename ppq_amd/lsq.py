@@ -227,7 +227,7 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
             qt_input, fp_output = qt_inputs[step % len(qt_inputs)], fp_outputs[step % len(qt_inputs)]
             opt.zero_grad()
             with torch.enable_grad():
-                outs = executor.partial_graph_forward(block.rps, qt_input, names)
+                outs = executor.partial_graph_forward(block.rps, qt_input, names, with_gradient=True)
                 loss = sum(self._loss(y, fp_output[n]) for n, y in zip(names, outs))
                 if self.gamma:
                     for op in block.rps:                                  # training.py:793-798 (the STE gradient passes)

@@ -31,7 +31,7 @@ from .core import (OBSERVER_FLOATING_MSE_FETCHES, OBSERVER_KL_HIST_BINS, OBSERVE
                    OBSERVER_PERCENTILE, OBSERVER_PERCENTILE_MANUL_OVERRIDE, is_initial, set_activated)
 from .core import QuantizationProperty as P
 from .core import RoundingPolicy
-from .ffi import CUDA
+from .ffi import CUDA, quantile_hint
 from .round import ppq_numerical_round, ppq_round_to_power_of_2
 
 
@@ -127,10 +127,11 @@ class ObservationQueue:
         self._hist.setdefault((bool(asymmetric), rows.shape[1], value.device), []).append((value, rows, p0, p1))
         self._grow(value)
 
-    def add_quantile(self, value: torch.Tensor, q: float) -> torch.Tensor:
-        """Returns the float32[2] (max-side, min-side) result tensor; it is filled at the next flush."""
+    def add_quantile(self, value: torch.Tensor, q: float, hint: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Returns the float32[2] (max-side, min-side) result tensor; it is filled at the next flush.
+        ``hint``: the observer's threshold hint (ffi.quantile_hint), see include/ppq_hip.h ppqhip_quantile_t."""
         dest = torch.empty(2, dtype=torch.float32, device=value.device)
-        self._quantile.setdefault((float(q), value.device), []).append((value, dest))
+        self._quantile.setdefault((float(q), value.device), []).append((value, dest, hint))
         self._grow(value)
         return dest
 
@@ -138,7 +139,7 @@ class ObservationQueue:
         if self._quantile:
             pending, self._quantile = self._quantile, {}
             for (q, _), items in pending.items():
-                CUDA.Quantile_Multi([v for v, _ in items], q, [d for _, d in items])
+                CUDA.Quantile_Multi([v for v, _, _ in items], q, [d for _, d, _ in items], [h for _, _, h in items])
                 self.launches += 1
         if self._minmax:
             by_dev = {}
@@ -478,6 +479,7 @@ class TorchPercentileObserver(BaseTensorObserver):
         else: self._percentile = quant_cfg.detail[OBSERVER_PERCENTILE_MANUL_OVERRIDE]
         self._percentile_collector = []
         self._sum: Optional[torch.Tensor] = None     # float32 [3] = (sum of max-quantiles, sum of min-quantiles, count)
+        self._hint: Optional[torch.Tensor] = None    # the filter thresholds that worked for the previous batch (device int32[8])
 
     @ torch.no_grad()
     def observe(self, value: torch.Tensor):
@@ -487,10 +489,12 @@ class TorchPercentileObserver(BaseTensorObserver):
         assert value.numel() > 0, (f'You are observing an empty tensor({getattr(self._watch_on, "name", "")}).')
         assert isinstance(value, torch.Tensor), 'TorchMinMaxObserver can only deal with torch Tensor values'
         if self._quant_cfg.policy.has_property(P.PER_TENSOR):
+            if value.is_cuda and (self._hint is None or self._hint.device != value.device):
+                self._hint = quantile_hint(value.device)
             if self.queue is not None and value.is_cuda:
-                self._percentile_collector.append(self.queue.add_quantile(value, self._percentile).view(1, -1))
+                self._percentile_collector.append(self.queue.add_quantile(value, self._percentile, self._hint).view(1, -1))
             else:
-                self._percentile_collector.append(CUDA.Quantile(value, self._percentile).view(1, -1))
+                self._percentile_collector.append(CUDA.Quantile_Hinted(value, self._percentile, self._hint).view(1, -1))
         elif self._quant_cfg.policy.has_property(P.PER_CHANNEL):
             raise PermissionError('Percentile observer can not deal with per channel quantization.')
         else:

@@ -105,7 +105,8 @@ def main():
             'hist_sym_t (rows)': (4, lambda: lib.ppqhip_hist_sym_t_rows(P(xs[nxt()]), n, hs, 1, P(rowsbuf), args.bins, stream())),
             'minmax_t (slots)': (4, lambda: lib.ppqhip_minmax_t_slots(P(xs[nxt()]), n, P(slots), stream())),
             'minmax_c': (4, lambda: lib.ppqhip_minmax_c(P(xs[nxt()]), n, C, epc, P(mins), P(maxs), stream())),
-            'quantile_t': (4, lambda: CUDA.Quantile(xs[nxt()], 0.9999)),
+            'quantile_t (hinted)': (4, lambda: CUDA.Quantile(xs[nxt()], 0.9999)),          # the drop-in call: thresholds of the previous batch
+            'quantile_t (cold)': (4, lambda: CUDA.Quantile_Hinted(xs[nxt()], 0.9999, None)),      # every call samples its thresholds
             'lsq_bwd_t': (12, bwd_t), 'lsq_bwd_c': (12, bwd_c),
             'torch out.copy_(x) (ref)': (8, copy),
             'torch abs().max() (ref)': (4, lambda: xs[nxt()].abs().max()),

@@ -16,6 +16,8 @@ rows = [torch.zeros(R, 2048, dtype=torch.int32, device=dev) for _ in xs]
 seed = torch.tensor([float('inf'), float('-inf')], device=dev)
 slots = [seed.repeat(S, 1).contiguous() for _ in xs]
 scales = [float(x.max()) / 2048 for x in xs]
+from ppq_amd.ffi import quantile_hint
+qhints = [quantile_hint(x.device) for x in xs]
 
 
 def timed(fn, n=20):
@@ -40,6 +42,8 @@ def per_tensor_quantile():
 print(f'{len(xs)} tensors, {total / 1e6:.0f} MB')
 for name, fn in (('hist multi', lambda: CUDA.Histogram_T_Rows_Multi(xs, rows, scales)), ('hist per-tensor', per_tensor_hist),
                  ('minmax multi', lambda: CUDA.MinMax_T_Slots_Multi(xs, slots)), ('minmax per-tensor', per_tensor_minmax),
-                 ('quantile multi', lambda: CUDA.Quantile_Multi(xs, 0.9999)), ('quantile per-tensor', per_tensor_quantile)):
+                 ('quantile multi (cold)', lambda: CUDA.Quantile_Multi(xs, 0.9999)),
+                 ('quantile multi (hinted)', lambda: CUDA.Quantile_Multi(xs, 0.9999, None, qhints)),
+                 ('quantile per-tensor', per_tensor_quantile)):
     us = timed(fn)
     print(f'{name:18s} {us:9.1f} us  {total / us / 1e6:7.2f} TB/s')
