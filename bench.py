@@ -376,9 +376,13 @@ def workload_variants(args):
     """BASELINE configs 3, 4, 5 as short child runs of this file: each line's value + the roofline entry of its dominant
     kernel.  Children skip baselines, PMC passes and their own variants; MIOpen immediate mode keeps their warm-up short."""
     out = []
-    for name, extra in (('resnet50_cfg3', ['--steps', '4', '--batch', '32']), ('vit_b16_fp8', ['--steps', '4', '--batch', '16']),
-                        ('yolov6s_int4_lsq', ['--steps', '8', '--batch', '8'])):
-        cmd = [sys.executable, os.path.abspath(__file__), '--workload', name, '--warmup', '1', '--repeats', '1', '--variants', '0', '--pmc', '0',
+    for name, extra in (('resnet50_cfg3', ['--workload', 'resnet50_cfg3', '--steps', '4', '--batch', '32']),
+                        ('vit_b16_fp8', ['--workload', 'vit_b16_fp8', '--steps', '4', '--batch', '16']),
+                        ('yolov6s_int4_lsq', ['--workload', 'yolov6s_int4_lsq', '--steps', '8', '--batch', '8']),
+                        # the percentile observer on the headline topology: the in-situ number of the quantile launch
+                        # sequence (quantile.hip; one sequence per forward over 72 tensors, hints from the previous batch)
+                        ('resnet50_percentile', ['--workload', 'resnet50', '--method', 'percentile', '--steps', '16', '--batch', '32'])):
+        cmd = [sys.executable, os.path.abspath(__file__), '--warmup', '1', '--repeats', '1', '--variants', '0', '--pmc', '0',
                '--no-cpu-baseline', '--no-cpu-ops', '--settle-ms', '0', '--miopen-find', '0'] + extra
         try:
             t0 = time.perf_counter()

@@ -56,6 +56,17 @@ int ppqhip_fq_linear_c(const float* x, const float* scale, const float* offset, 
                        int64_t n, int64_t num_channel, int64_t elem_per_channel,
                        int clip_min, int clip_max, int rounding, void* stream);
 
+/* quantise WITHOUT dequantising: PPQLinearQuant_toInt, ppq/quantization/qfunction/linear.py:218-238 (torch ops in the
+ * reference; used when an exporter writes integer weights).  q = clamp(ppq_tensor_round(x / s) + o, qmin, qmax)
+ * evaluated in float32 with the RAW offset and the float32 rounding formulas of ppq/utils/round.py:9-49, then
+ * truncated to out_dtype: 0 = int8, 1 = uint8, 2 = int32 (`out` has n elements of that type).
+ * ROUND_TO_NEAR_INT has no tensor form in the reference (round.py:47-49): invalid value here. */
+int ppqhip_to_int_t(const float* x, const float* scale, const float* offset, void* out, int64_t n,
+                    int clip_min, int clip_max, int rounding, int out_dtype, void* stream);
+int ppqhip_to_int_c(const float* x, const float* scale, const float* offset, void* out, int64_t n,
+                    int64_t num_channel, int64_t elem_per_channel, int clip_min, int clip_max,
+                    int rounding, int out_dtype, void* stream);
+
 /* many tensors, one launch (MI355X-native addition): every job is fake-quantised exactly as
  * ppqhip_fq_linear_c would (a per-tensor job has num_channel = 1, elem_per_channel = n).  Meant for the
  * weights of a graph, which the executor re-quantises on every forward: `jobs` is a HOST array;

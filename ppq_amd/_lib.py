@@ -32,6 +32,8 @@ PROTOTYPES = {
     'ppqhip_device_arch': (c_int, [ctypes.c_char_p, c_int]),
     'ppqhip_fq_linear_t': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int, c_vp]),
     'ppqhip_fq_linear_c': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_vp]),
+    'ppqhip_to_int_t': (c_int, [c_f32p, c_f32p, c_f32p, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp]),
+    'ppqhip_to_int_c': (c_int, [c_f32p, c_f32p, c_f32p, c_vp, c_i64, c_i64, c_i64, c_int, c_int, c_int, c_int, c_vp]),
     'ppqhip_fq_linear_t_bwd': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int,
                                        c_vp]),
     'ppqhip_fq_linear_c_bwd': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_int,

@@ -51,7 +51,6 @@ struct LaunchScope {
 
 int finish_launch(const char* what);   // hipGetLastError -> status
 void* scratch(hipStream_t stream, size_t bytes);   // device scratch private to (device, stream)
-uint32_t* tickets(hipStream_t stream);             // 64 words per (device, stream), zero between launches (arrival counters)
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

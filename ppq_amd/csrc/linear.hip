@@ -112,6 +112,61 @@ __global__ __launch_bounds__(kBlock) void fq_linear_c_scalar_kernel(
     }
 }
 
+// --------------------------------------------------------------------------- quantise to integer
+// PPQLinearQuant_toInt, ppq/quantization/qfunction/linear.py:218-238 (the reference does this with torch ops; it
+// has no kernel for it): q = clamp(ppq_tensor_round(x / s) + o, qmin, qmax) in FLOAT32 -- the RAW offset, not the
+// rounded one the fake-quant kernels use -- then .type(int8 | uint8 | int32), i.e. truncation towards zero.
+// ppq_tensor_round (utils/round.py:9-49) is a float32 formula per policy, not common.cuh's _round2int.
+__device__ __forceinline__ float tensor_round_f32(float v, int rounding) {
+    const float sgn = v > 0.f ? 1.f : (v < 0.f ? -1.f : v);           // torch.sign: 0 -> 0, NaN -> NaN
+    switch (rounding) {
+        case ROUND_HALF_EVEN: return __builtin_rintf(v);
+        case ROUND_UP: return __builtin_ceilf(v);
+        case ROUND_HALF_TOWARDS_ZERO: return sgn * __builtin_ceilf(__builtin_fabsf(v) - 0.5f);
+        case ROUND_HALF_FAR_FORM_ZERO: return sgn * __builtin_floorf(__builtin_fabsf(v) + 0.5f);
+        case ROUND_HALF_DOWN: return __builtin_ceilf(v - 0.5f);
+        default: return __builtin_floorf(v + 0.5f);                    // ROUND_HALF_UP
+    }
+}
+__device__ __forceinline__ int to_int_scalar(float x, float s, float o, float qmin, float qmax, int rounding) {
+    float t = tensor_round_f32(x / s, rounding) + o;
+    t = t < qmin ? qmin : t;            // torch.clamp: NaN stays NaN (both compares false)
+    t = t > qmax ? qmax : t;
+    return f2i_sat(t);                  // truncates; NaN -> 0
+}
+// OUT: int8_t / uint8_t / int32_t.  Workgroup b owns elements [b * kBlock * 4, ..): one 16-B load, one 4- or 16-B store per lane.
+template <typename OUT, bool CHANNEL>
+__global__ __launch_bounds__(kBlock) void to_int_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                        const float* __restrict__ offset, OUT* __restrict__ out, uint32_t n,
+                                                        int vec_ok, FastDiv elem_per_channel, FastDiv num_channel, float qmin,
+                                                        float qmax, int rounding) {
+    const uint32_t i0 = (blockIdx.x * kBlock + threadIdx.x) * 4u;
+    if (i0 >= n) return;
+    auto so = [&](uint32_t i, float& s, float& o) {
+        uint32_t c = 0;
+        if (CHANNEL) { const uint32_t row = fdiv(i, elem_per_channel); c = row - fdiv(row, num_channel) * num_channel.d; }
+        s = scale[c]; o = offset[c];
+    };
+    if (vec_ok && i0 + 4 <= n) {        // elem_per_channel % 4 == 0: the four share a channel
+        const float4 a = *reinterpret_cast<const float4*>(x + i0);
+        float s, o;
+        so(i0, s, o);
+        const int q0 = to_int_scalar(a.x, s, o, qmin, qmax, rounding), q1 = to_int_scalar(a.y, s, o, qmin, qmax, rounding);
+        const int q2 = to_int_scalar(a.z, s, o, qmin, qmax, rounding), q3 = to_int_scalar(a.w, s, o, qmin, qmax, rounding);
+        if (sizeof(OUT) == 1) {
+            *reinterpret_cast<uint32_t*>(out + i0) = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+        } else {
+            *reinterpret_cast<int4*>(out + i0) = make_int4(q0, q1, q2, q3);
+        }
+    } else {
+        for (uint32_t i = i0; i < min(i0 + 4u, n); i++) {
+            float s, o;
+            so(i, s, o);
+            out[i] = (OUT)to_int_scalar(x[i], s, o, qmin, qmax, rounding);
+        }
+    }
+}
+
 // --------------------------------------------------------------------------- LSQ backward
 // One element of QuantizeTensor_LT_B / _LC_B (linear.cu:255-274 / :352-372).  `o` is the rounded
 // offset kept as float, as in the reference; returns the partial d(loss)/d(scale) term.
@@ -145,20 +200,19 @@ __device__ __forceinline__ float block_sum(float v, float* lds) {
 }
 
 // per tensor: one contiguous chunk per workgroup, 16-B loads of x and dy, 16-B stores of grad_x;
-// the workgroup's partial d(loss)/d(scale) goes to partial[blockIdx.x]; the last workgroup to finish sums
-// the partials in double, in a fixed order, and applies grad_factor (one launch, deterministic).
+// the workgroup's partial d(loss)/d(scale) goes to partial[blockIdx.x] (no same-address atomics),
+// lsq_finish_kernel sums the partials in double and applies grad_factor.
 #ifndef PPQHIP_LSQ_U
 #define PPQHIP_LSQ_U 4                  // (x, dy) 16-B load pairs in flight per lane (MI355X sweep, Bx32: U=1 152 us, 2 127, 4 116)
 #endif
 #ifndef PPQHIP_LSQ_MAX_WG
 #define PPQHIP_LSQ_MAX_WG 65536         // workgroups per launch (one partial sum each)
 #endif
-constexpr uint32_t kLsqShards = 32;
 template <int R, bool NT>
 __global__ __launch_bounds__(kBlock) void fq_linear_t_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
     const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ partial, uint32_t n, int vec_ok,
-    int qmin, int qmax, int rounding, uint32_t* __restrict__ tickets, float grad_factor, float* __restrict__ gs) {
+    int qmin, int qmax, int rounding) {
     __shared__ float lds[kBlock / kWave];
     const float s = scale[0];
     const float rcp_s = 1.0f / s;
@@ -204,40 +258,32 @@ __global__ __launch_bounds__(kBlock) void fq_linear_t_bwd_kernel(
         gx[i] = g;
     }
     const float tot = block_sum(acc, lds);
-    // One launch: the workgroup's partial goes out write-through, then the workgroup takes a ticket; the LAST one adds all
-    // partials in the fixed order of the former lsq_finish_kernel (double, 256 strided lanes) -- the same bits whoever is
-    // last.  The arrivals are spread over kLsqShards counters (one same-address device atomic per workgroup would
-    // serialise: 12544 workgroups x ~11 ns exceed the kernel's 100 us), whose last arrivers meet on one more.
-    // No fence: every partial is an sc1 store drained (vmcnt) before its ticket, and the reader uses sc1 loads.
-    __shared__ uint32_t last_flag;
-    const uint32_t G = gridDim.x, b = blockIdx.x;
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&partial[b], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t shard = b % kLsqShards;
-        const uint32_t in_shard = (G - shard + kLsqShards - 1) / kLsqShards;
-        bool last = false;
-        if (__hip_atomic_fetch_add(&tickets[shard], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == in_shard) {
-            const uint32_t shards = G < kLsqShards ? G : kLsqShards;
-            last = __hip_atomic_fetch_add(&tickets[kLsqShards], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == shards;
-        }
-        last_flag = last ? 1u : 0u;
-    }
-    __syncthreads();
-    if (last_flag == 0u) return;
-    __shared__ double dsum[kBlock / kWave];
-    double t = 0.0;
-    for (uint32_t i = threadIdx.x; i < G; i += kBlock)
-        t += (double)__hip_atomic_load(&partial[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+// One workgroup of 1024 lanes, 8 loads in flight per lane, double accumulation in a FIXED order (lane l adds
+// partial[l], partial[l + 1024], ..; then lanes, then waves, in index order): the result does not depend on timing.
+// (256 lanes adding one partial per dependent trip took 13.8 us for the 12544 partials of a [32, 512, 56, 56] tensor.)
+constexpr int kLsqFinishBlock = 1024;
+__global__ __launch_bounds__(kLsqFinishBlock) void lsq_finish_kernel(const float* __restrict__ partial, uint32_t count,
+                                                                     float grad_factor, float* __restrict__ gs) {
+    __shared__ double lds[kLsqFinishBlock / kWave];
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < count; i += 8 * kLsqFinishBlock) {
+        float v[8];
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) t += __shfl_xor(t, m, 64);
-    if ((threadIdx.x & 63) == 0) dsum[threadIdx.x >> 6] = t;
-    if (threadIdx.x <= kLsqShards) tickets[threadIdx.x] = 0u;          // leave the counters as they were found
+        for (int u = 0; u < 8; u++) { const uint32_t at = i + u * kLsqFinishBlock; v[u] = at < count ? partial[at] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += (double)v[u];
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
-        double all = 0.0;
-        for (int w = 0; w < kBlock / kWave; w++) all += dsum[w];
-        gs[0] = (float)all * grad_factor;
+        double t = 0.0;
+        for (int w = 0; w < kLsqFinishBlock / kWave; w++) t += lds[w];
+        gs[0] = (float)t * grad_factor;
     }
 }
 
@@ -554,6 +600,41 @@ int ppqhip_fq_linear_multi(const ppqhip_fq_job* jobs, int num_jobs, int rounding
     return finish_launch("fq_linear_multi");
 }
 
+static int to_int_impl(const float* x, const float* scale, const float* offset, void* out, int64_t n, int64_t C, int64_t epc,
+                       int clip_min, int clip_max, int rounding, int out_dtype, bool channel, void* stream, const char* what) {
+    if (int st = validate_n(n, what)) return st;
+    if (channel) { if (int st = validate_channels(n, C, epc, what)) return st; }
+    if (out_dtype < 0 || out_dtype > 2) { set_error("%s: out_dtype must be 0 (int8), 1 (uint8) or 2 (int32)", what); return PPQHIP_ERR_INVALID_VALUE; }
+    if (rounding == ROUND_TO_NEAR_INT || rounding < 0 || rounding > ROUND_UP) {
+        // utils/round.py:47-49: the tensor form of this policy does not exist in the reference either
+        set_error("%s: rounding policy %d has no tensor form (ppq_tensor_round)", what, rounding); return PPQHIP_ERR_INVALID_VALUE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const int elem = out_dtype == 2 ? 4 : 1;
+    const int vec_ok = (aligned16(x) && (reinterpret_cast<uintptr_t>(out) % (size_t)(4 * elem) == 0) && (!channel || epc % 4 == 0)) ? 1 : 0;
+    const FastDiv e = make_fastdiv((uint32_t)(channel ? epc : 1)), nc = make_fastdiv((uint32_t)(channel ? C : 1));
+    const dim3 grid((uint32_t)((n + kBlock * 4 - 1) / (kBlock * 4)));
+    const float qmin = (float)clip_min, qmax = (float)clip_max;
+#define PPQ_LAUNCH_TOINT(T, CH) hipLaunchKernelGGL((to_int_kernel<T, CH>), grid, dim3(kBlock), 0, s, x, scale, offset, (T*)out, \
+                                                   (uint32_t)n, vec_ok, e, nc, qmin, qmax, rounding)
+    if (out_dtype == 0) { if (channel) PPQ_LAUNCH_TOINT(int8_t, true); else PPQ_LAUNCH_TOINT(int8_t, false); }
+    else if (out_dtype == 1) { if (channel) PPQ_LAUNCH_TOINT(uint8_t, true); else PPQ_LAUNCH_TOINT(uint8_t, false); }
+    else { if (channel) PPQ_LAUNCH_TOINT(int32_t, true); else PPQ_LAUNCH_TOINT(int32_t, false); }
+#undef PPQ_LAUNCH_TOINT
+    return finish_launch(what);
+}
+
+int ppqhip_to_int_t(const float* x, const float* scale, const float* offset, void* out, int64_t n, int clip_min, int clip_max,
+                    int rounding, int out_dtype, void* stream) {
+    return to_int_impl(x, scale, offset, out, n, 1, n, clip_min, clip_max, rounding, out_dtype, false, stream, "to_int_t");
+}
+
+int ppqhip_to_int_c(const float* x, const float* scale, const float* offset, void* out, int64_t n, int64_t num_channel,
+                    int64_t elem_per_channel, int clip_min, int clip_max, int rounding, int out_dtype, void* stream) {
+    return to_int_impl(x, scale, offset, out, n, num_channel, elem_per_channel, clip_min, clip_max, rounding, out_dtype, true, stream,
+                       "to_int_c");
+}
+
 int ppqhip_fq_linear_t_bwd(const float* x, const float* scale, const float* offset, const float* grad_y,
                            float* grad_x, float* grad_s, int64_t n, int clip_min, int clip_max,
                            int rounding, void* stream) {
@@ -567,16 +648,17 @@ int ppqhip_fq_linear_t_bwd(const float* x, const float* scale, const float* offs
     // lsq_bwd_c, which has always been tiled by rows, ran 10 % faster than the persistent form of this kernel)
     const int grid = stream_grid(n, kBlock * 4 * PPQHIP_LSQ_U, PPQHIP_LSQ_MAX_WG);
     float* partial = (float*)scratch(s, sizeof(float) * (size_t)grid);
-    uint32_t* tick = tickets(s);
-    if (partial == nullptr || tick == nullptr) return PPQHIP_ERR_HIP;
+    if (partial == nullptr) return PPQHIP_ERR_HIP;
     const int vec_ok = (aligned16(x) && aligned16(grad_y) && aligned16(grad_x)) ? 1 : 0;
     const bool nt = n >= kStreamElems / 2;       // x and dy together exceed cache residency: streaming loads
 #define PPQ_LAUNCH_LSQ_T(R, NT)                                                                                     \
     hipLaunchKernelGGL((fq_linear_t_bwd_kernel<R, NT>), dim3(grid), dim3(kBlock), 0, s, x, scale, offset, grad_y,   \
-                       grad_x, partial, (uint32_t)n, vec_ok, clip_min, clip_max, rounding, tick, grad_factor, grad_s)
+                       grad_x, partial, (uint32_t)n, vec_ok, clip_min, clip_max, rounding)
     if (rounding == ROUND_HALF_EVEN) { if (nt) PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, true); else PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, false); }
     else { if (nt) PPQ_LAUNCH_LSQ_T(-1, true); else PPQ_LAUNCH_LSQ_T(-1, false); }
 #undef PPQ_LAUNCH_LSQ_T
+    hipLaunchKernelGGL(lsq_finish_kernel, dim3(1), dim3(kLsqFinishBlock), 0, s, (const float*)partial, (uint32_t)grid,
+                       grad_factor, grad_s);
     return finish_launch("fq_linear_t_bwd");
 }
 

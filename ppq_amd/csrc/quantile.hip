@@ -91,7 +91,6 @@ constexpr int kOffTick = kOffSpec + 48;     // tick[8]: tiles finished per F pas
 constexpr int kQZeroWords = kOffTick + 8;
 constexpr int kOffCand = kQZeroWords;       // cand[2][kQCap]: full keys of the bucket's elements (F2, COMPACT)
 constexpr int kQWords = kOffCand + 2 * (int)kQCap;
-static_assert(kQCap <= 16384, "list_select keeps <= kQLdsKeys keys in LDS");
 static_assert(kQZeroWords % 4 == 0 && kQWords % 4 == 0, "16-B granularity");
 
 // the hint of a job (8 words of caller-owned device memory, zero = no knowledge): see ppq_hip.h
@@ -211,27 +210,31 @@ __device__ __forceinline__ void block_scan_excl(uint32_t v, uint32_t* scratch, u
     total = tot;
 }
 
-// find the bin of `hist[0..nbins)` that holds rank k (0-based) and the rank inside it; nbins in {256, 4096}, 256 threads:
-// thread t owns `per` consecutive bins.  Result: sel[0], sel[1] (LDS), valid after the call for every thread.
+// find the bin of `hist[0..nbins)` that holds rank k (0-based) and the rank inside it; nbins in {256, 4096}, THREADS threads:
+// thread t owns `per` consecutive bins (threads past the last bin own none).  Result: sel[0], sel[1] (LDS), valid after
+// the call for every thread.  scratch: THREADS / 64 words.
+template <int THREADS>
 __device__ void select_bin(const uint32_t* __restrict__ hist, int nbins, uint32_t k, uint32_t* scratch, uint32_t* sel) {
-    const int per = nbins / kBlock;   // 1 or 16
+    constexpr int kMaxPer = kQ1 / THREADS;                          // 16 (256 threads) or 4 (1024)
+    const int per = nbins >= THREADS ? nbins / THREADS : 1;
     const int t = threadIdx.x;
-    uint32_t mine[16];
+    const bool owner = t * per < nbins;
+    uint32_t mine[kMaxPer];
     uint32_t local = 0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        mine[j] = j < per ? hist[t * per + j] : 0u;
+    for (int j = 0; j < kMaxPer; j++) {
+        mine[j] = (owner && j < per) ? hist[t * per + j] : 0u;
         local += mine[j];
     }
     uint32_t excl, total;
-    block_scan_excl<kBlock>(local, scratch, excl, total);
+    block_scan_excl<THREADS>(local, scratch, excl, total);
     const uint32_t kk = k < total ? k : (total ? total - 1 : 0u);   // k < n always; guard anyway
     if (total == 0u && t == 0) { sel[0] = 0u; sel[1] = 0u; }
     if (kk >= excl && kk < excl + local) {
         uint32_t run = excl;
         int j = 0;
 #pragma unroll
-        for (int jj = 0; jj < 15; jj++) {
+        for (int jj = 0; jj < kMaxPer - 1; jj++) {
             if (jj < per - 1 && j == jj && run + mine[jj] <= kk) { run += mine[jj]; j = jj + 1; }
         }
         sel[0] = (uint32_t)(t * per + j);
@@ -306,6 +309,7 @@ __device__ __forceinline__ bool job_ticket(uint32_t* tick, uint32_t mine, uint32
 }
 
 // ---- init ------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kQInitSplit = 4;        // workgroups per job
 constexpr int kQInitMax = 96;              // jobs per init launch (3.8 KB of kernel arguments)
 struct QUpload {                           // 40 B
     const float* x;
@@ -323,7 +327,13 @@ struct QInitArgs {
 
 __global__ __launch_bounds__(kBlock) void quantile_init_kernel(const QInitArgs a) {
     __shared__ uint32_t red[4][kBlock / kWave];
-    const uint32_t b = blockIdx.x, t = threadIdx.x;
+    const uint32_t b = blockIdx.x / kQInitSplit, part = blockIdx.x % kQInitSplit, t = threadIdx.x;
+    {   // every workgroup zeroes its quarter of the job's record; the first of the four also writes the table entry
+        uint4* z = reinterpret_cast<uint4*>(a.fixed + (size_t)b * kQWords);
+        constexpr uint32_t nz = (uint32_t)kQZeroWords / 4, per = (nz + kQInitSplit - 1) / kQInitSplit;
+        for (uint32_t i = part * per + t; i < umin(nz, (part + 1) * per); i += kBlock) z[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (part != 0) return;
+    }
     // prefix sums of (tiles, units, list words) over the jobs before this one; cold jobs of the whole chunk
     uint32_t tiles = 0, units = 0, words = 0, cold = 0;
     if (t < a.count) {
@@ -356,8 +366,6 @@ __global__ __launch_bounds__(kBlock) void quantile_init_kernel(const QInitArgs a
             else header[kGCold] += cold;            // stream-ordered behind the previous chunk's launch
         }
     }
-    uint4* z = reinterpret_cast<uint4*>(ws);
-    for (uint32_t i = t; i < (uint32_t)kQZeroWords / 4; i += kBlock) z[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // ---- sample (cold jobs only) -----------------------------------------------------------------------------------------
@@ -688,25 +696,25 @@ void quantile_filter_kernel(const QSeq s) {
 // The rank-th smallest (0-based) of the keys of <= 8 list segments (count >= 1 in total, rank < count, every segment 16-B
 // aligned); 256 threads, all call.  Radix select on (key - min) over the bits the keys' RANGE actually has (the most
 // extreme keys of a tensor share their high bits: the top 12 bits of the full key would pile them into two or three LDS
-// counters), <= 3 rounds of <= 12 bits.  Up to kQLdsKeys keys are read from global memory ONCE and kept in LDS.
-constexpr uint32_t kQLdsKeys = 16384;
+// counters), <= 3 rounds of <= 12 bits.  Up to `lds_keys` keys are read from global memory ONCE and kept in LDS.
 struct KeyLists {
     const uint32_t* base;       // segment i starts at base + i * seg
     uint32_t seg, segments, count;
     uint32_t cnt[kQShards];
 };
-template <typename F>
-__device__ __forceinline__ void list_sweep(const uint32_t* __restrict__ list, uint32_t count, uint32_t at0, F&& f) {
+template <int THREADS, typename F>
+__device__ __forceinline__ void list_sweep(const uint32_t* __restrict__ list, uint32_t count, uint32_t at0, uint32_t lt, F&& f) {
+    // `lt` = this thread's index among the THREADS threads that sweep this list
     const uint4* lv = reinterpret_cast<const uint4*>(list);
     const uint32_t nv = (count + 3) >> 2;
-    for (uint32_t i = threadIdx.x; i < nv; i += 8 * kBlock) {
+    for (uint32_t i = lt; i < nv; i += 8 * THREADS) {
         uint4 k[8];
 #pragma unroll
-        for (int u = 0; u < 8; u++) k[u] = lv[umin(i + u * kBlock, nv - 1)];
+        for (int u = 0; u < 8; u++) k[u] = lv[umin(i + u * THREADS, nv - 1)];
 #pragma unroll
         for (int u = 0; u < 8; u++) {
-            const uint32_t at = (i + u * kBlock) << 2;
-            if (i + u * kBlock < nv) {
+            const uint32_t at = (i + u * THREADS) << 2;
+            if (i + u * THREADS < nv) {
                 if (at + 0 < count) f(k[u].x, at0 + at + 0);
                 if (at + 1 < count) f(k[u].y, at0 + at + 1);
                 if (at + 2 < count) f(k[u].z, at0 + at + 2);
@@ -715,43 +723,30 @@ __device__ __forceinline__ void list_sweep(const uint32_t* __restrict__ list, ui
         }
     }
 }
-// all segments at once: 256 / segments threads per segment (8 dependent sweeps in a row cost select A 6 us)
-template <typename F>
+// all segments at once: THREADS / 8 threads per segment (8 dependent sweeps in a row cost select A 6 us)
+template <int THREADS, typename F>
 __device__ __forceinline__ void lists_sweep(const KeyLists& L, F&& f) {
-    if (L.segments == 1) { list_sweep(L.base, L.cnt[0], 0u, f); return; }
-    const uint32_t tpg = kBlock / kQShards, grp = threadIdx.x / tpg, lt = threadIdx.x % tpg;      // segments == kQShards
+    if (L.segments == 1) { list_sweep<THREADS>(L.base, L.cnt[0], 0u, threadIdx.x, f); return; }
+    constexpr uint32_t tpg = THREADS / kQShards;                        // segments == kQShards
+    const uint32_t grp = threadIdx.x / tpg, lt = threadIdx.x % tpg;
     uint32_t at0 = 0, count = 0;
 #pragma unroll
     for (int i = 0; i < kQShards; i++) { if ((uint32_t)i < grp) at0 += L.cnt[i]; if ((uint32_t)i == grp) count = L.cnt[i]; }
-    const uint4* lv = reinterpret_cast<const uint4*>(L.base + (size_t)grp * L.seg);
-    const uint32_t nv = (count + 3) >> 2;
-    for (uint32_t i = lt; i < nv; i += 8 * tpg) {
-        uint4 k[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) k[u] = lv[umin(i + u * tpg, nv - 1)];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const uint32_t at = (i + u * tpg) << 2;
-            if (i + u * tpg < nv) {
-                if (at + 0 < count) f(k[u].x, at0 + at + 0);
-                if (at + 1 < count) f(k[u].y, at0 + at + 1);
-                if (at + 2 < count) f(k[u].z, at0 + at + 2);
-                if (at + 3 < count) f(k[u].w, at0 + at + 3);
-            }
-        }
-    }
+    list_sweep<tpg>(L.base + (size_t)grp * L.seg, count, at0, lt, f);
 }
-__device__ uint32_t list_select(const KeyLists& L, uint32_t rank, uint32_t* keys, uint32_t* h, uint32_t* scratch, uint32_t* sel) {
+template <int THREADS>
+__device__ uint32_t list_select(const KeyLists& L, uint32_t rank, uint32_t* keys, uint32_t lds_keys, uint32_t* h, uint32_t* scratch,
+                                uint32_t* sel) {
     const uint32_t count = L.count;
-    const bool in_lds = count <= kQLdsKeys;
+    const bool in_lds = count <= lds_keys;
     uint32_t mn = 0xFFFFFFFFu, mx = 0u;
-    lists_sweep(L, [&](uint32_t key, uint32_t at) { mn = umin(mn, key); mx = umax(mx, key); if (in_lds) keys[at] = key; });
+    lists_sweep<THREADS>(L, [&](uint32_t key, uint32_t at) { mn = umin(mn, key); mx = umax(mx, key); if (in_lds) keys[at] = key; });
     mn = wave_min_u32(mn); mx = wave_max_u32(mx);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) { scratch[threadIdx.x >> 6] = mn; scratch[4 + (threadIdx.x >> 6)] = mx; }
+    if ((threadIdx.x & 63) == 0) { scratch[threadIdx.x >> 6] = mn; scratch[16 + (threadIdx.x >> 6)] = mx; }
     __syncthreads();
 #pragma unroll
-    for (int w = 0; w < kBlock / kWave; w++) { mn = umin(mn, scratch[w]); mx = umax(mx, scratch[4 + w]); }
+    for (int w = 0; w < THREADS / kWave; w++) { mn = umin(mn, scratch[w]); mx = umax(mx, scratch[16 + w]); }
     __syncthreads();
     if (mn == mx) return mn;
     int pos = 32 - __builtin_clz(mx - mn);                  // bits of the range, 1..32
@@ -759,17 +754,17 @@ __device__ uint32_t list_select(const KeyLists& L, uint32_t rank, uint32_t* keys
     while (pos > 0) {
         const int w = pos > 12 ? 12 : pos;
         const int shift = pos - w;
-        for (int i = threadIdx.x; i < kQ1; i += kBlock) h[i] = 0;
+        for (int i = threadIdx.x; i < kQ1; i += THREADS) h[i] = 0;
         __syncthreads();
         auto digit = [&](uint32_t key) {
             const uint32_t d = key - mn;
             const uint32_t head = pos >= 32 ? 0u : d >> pos;
             if (head == prefix) atomicAdd(&h[(d >> shift) & ((1u << w) - 1u)], 1u);
         };
-        if (in_lds) { for (uint32_t i = threadIdx.x; i < count; i += kBlock) digit(keys[i]); }
-        else lists_sweep(L, [&](uint32_t key, uint32_t) { digit(key); });
+        if (in_lds) { for (uint32_t i = threadIdx.x; i < count; i += THREADS) digit(keys[i]); }
+        else lists_sweep<THREADS>(L, [&](uint32_t key, uint32_t) { digit(key); });
         __syncthreads();
-        select_bin(h, w > 8 ? kQ1 : kQ3, rank, scratch, sel);
+        select_bin<THREADS>(h, w > 8 ? kQ1 : kQ3, rank, scratch, sel);
         prefix = (prefix << w) | sel[0];
         rank = sel[1];
         pos = shift;
@@ -789,10 +784,12 @@ __device__ __forceinline__ uint32_t q_list_limit(uint32_t wanted, uint32_t cap) 
 //   lo:  keys < T are S[0 .. count):      k < count -> the k-th smallest listed key;  else away = k - count + 1 <= tie -> T
 // Anything else (unlucky sample, overflow, a tie on a value the thresholds do not sit on) is left OPEN for F1..F3.
 // The hint of the side is kept when the list was comfortably long, dropped when it was short, overflowing or useless.
-__global__ __launch_bounds__(kBlock) void quantile_select_a_kernel(const QSeq s) {
-    __shared__ uint32_t keys[kQLdsKeys];
+constexpr int kQSABlock = 1024;                 // 16 waves: the list sweeps and the LDS rounds are latency chains, 4x the lanes = 1/4 the trips
+constexpr uint32_t kQSALdsKeys = 32768;
+__global__ __launch_bounds__(kQSABlock) void quantile_select_a_kernel(const QSeq s) {
+    __shared__ uint32_t keys[kQSALdsKeys];
     __shared__ uint32_t h[kQ1];
-    __shared__ uint32_t scratch[16];
+    __shared__ uint32_t scratch[32];
     __shared__ uint32_t sel[2];
     const QJob job = s.job[blockIdx.x >> 1];
     const int w = (int)(blockIdx.x & 1u);
@@ -815,7 +812,7 @@ __global__ __launch_bounds__(kBlock) void quantile_select_a_kernel(const QSeq s)
         if (complete) {
             const uint32_t wanted = w ? k + 1u : n - k;             // listed keys the answer needs
             if (count >= wanted) {
-                const uint32_t key = list_select(L, w ? k : k - (n - count), keys, h, scratch, sel);
+                const uint32_t key = list_select<kQSABlock>(L, w ? k : k - (n - count), keys, kQSALdsKeys, h, scratch, sel);
                 if (threadIdx.x == 0) job.dest[w] = key2f(key);
                 done = true;
                 // next batch: the same threshold while the list is neither nearly too short nor needlessly long (a list of
@@ -844,46 +841,61 @@ __global__ __launch_bounds__(kBlock) void quantile_select_a_kernel(const QSeq s)
     }
 }
 
+// ---- how the exact passes spread their work ------------------------------------------------------------------------
+// Which jobs are open is not known at launch, so F1..F3 cannot lay the work out as one concatenated tile list the way
+// the filter does (a contiguous range per workgroup would land the two or three open jobs of a forward on two or three
+// percent of the grid: 180 us for 50 MB).  Instead every workgroup looks at every job (the modes of all sides are
+// fetched into LDS once) and takes, of each open job, the slices g', g' + G, .. of 8 tiles, g' = g rotated by a
+// per-job offset so that different open jobs start on different workgroups.
+constexpr uint32_t kQFSliceTiles = 8;              // 32768 elements (128 KB) per slice
+__device__ __forceinline__ void load_modes(uint32_t* modes, const QSeq& s) {
+    for (uint32_t i = threadIdx.x; i < 2u * s.count; i += blockDim.x)
+        modes[i] = s.job[i >> 1].ws[kOffSel + 8 * (i & 1u) + kSMode];
+    __syncthreads();
+}
+__device__ __forceinline__ uint32_t first_slice(uint32_t g, uint32_t G, uint32_t j) { return (g + G - (j * 61u) % G) % G; }
+
 // ---- F1: exact histogram of the top 12 key bits of every job with an open side; tail: bucket + rank per open side ---
 constexpr int kQTrash = 64;
 __global__ __launch_bounds__(kBlock) void quantile_f1_kernel(const QSeq s) {
-    __shared__ uint32_t ft[kQMaxJobs];
+    __shared__ uint32_t modes[2 * kQMaxJobs];
     __shared__ int h[kQ1];
-    __shared__ uint32_t scratch[16];
+    __shared__ uint32_t scratch[32];
     __shared__ uint32_t sel[2];
     __shared__ uint32_t flag;
     if (!s.all_open && s.header[kGOpen] == 0u) return;
     const uint32_t G = gridDim.x, g = blockIdx.x;
-    uint32_t t = (uint32_t)(((uint64_t)g * s.total_tiles) / G);
-    const uint32_t t_end = (uint32_t)(((uint64_t)(g + 1) * s.total_tiles) / G);
-    if (t >= t_end) return;
-    load_prefix(ft, s.first_tile, s.count);
+    load_modes(modes, s);
     for (int i = threadIdx.x; i < kQ1; i += kBlock) h[i] = 0;
     __syncthreads();
     WaveBinCounter<false, true, true> acc;
-    for (uint32_t j = find_job(ft, s.count, t); t < t_end; j++) {
+    for (uint32_t j = 0; j < s.count; j++) {
+        if (modes[2 * j] == kModeDone && modes[2 * j + 1] == kModeDone) continue;
         const QJob job = s.job[j];
-        const uint32_t j_end = (j + 1 < s.count) ? ft[j + 1] : s.total_tiles;
-        const uint32_t k0 = t - ft[j], k1 = umin(t_end, j_end) - ft[j];
-        t = umin(t_end, j_end);
+        const uint32_t nsl = (job.tiles + kQFSliceTiles - 1) / kQFSliceTiles;
+        uint32_t sl = first_slice(g, G, j), mine = 0;
+        if (sl >= nsl) continue;
         uint32_t* S_hi = job.ws + kOffSel;
         uint32_t* S_lo = job.ws + kOffSel + 8;
-        if (S_hi[kSMode] == kModeDone && S_lo[kSMode] == kModeDone) continue;
         acc.init(h, kQ1);
-        walk_job_tiles(job.x, job.n, k0, k1,
-                       [&](float v, bool in) { acc.elect((int)(f2key(v) >> 20), in); },
-                       [&](float v, bool in) { acc.template commit<false>((int)(f2key(v) >> 20), in); });
+        for (; sl < nsl; sl += G) {
+            const uint32_t k0 = sl * kQFSliceTiles, k1 = umin(k0 + kQFSliceTiles, job.tiles);
+            mine += k1 - k0;
+            walk_job_tiles(job.x, job.n, k0, k1,
+                           [&](float v, bool in) { acc.elect((int)(f2key(v) >> 20), in); },
+                           [&](float v, bool in) { acc.template commit<false>((int)(f2key(v) >> 20), in); });
+        }
         acc.flush_hot();
         __syncthreads();
         for (int i = threadIdx.x; i < kQ1; i += kBlock) {
             const int v = h[i];
             if (v) { atomicAdd(&job.ws[kOffH1 + i], (uint32_t)v); h[i] = 0; }
         }
-        if (job_ticket(job.ws + kOffTick + 0, k1 - k0, job.tiles, &flag)) {
+        if (job_ticket(job.ws + kOffTick + 0, mine, job.tiles, &flag)) {
             for (int w = 0; w < 2; w++) {
                 uint32_t* S = w ? S_lo : S_hi;
                 if (S[kSMode] != kModeDone) {                                    // block-uniform
-                    select_bin(job.ws + kOffH1, kQ1, w ? job.k_lo : job.k_hi, scratch, sel);
+                    select_bin<kBlock>(job.ws + kOffH1, kQ1, w ? job.k_lo : job.k_hi, scratch, sel);
                     if (threadIdx.x == 0) {
                         const uint32_t top = sel[0];
                         S[kSTop] = top; S[kSRank] = sel[1];
@@ -903,34 +915,31 @@ __global__ __launch_bounds__(kBlock) void quantile_f1_kernel(const QSeq s) {
 // tail: COMPACT -> finish on the candidate list; all keys of the bucket equal (saturated values) -> done; else the
 // 24-bit prefix for F3.
 __global__ __launch_bounds__(kBlock) void quantile_f2_kernel(const QSeq s) {
-    __shared__ uint32_t ft[kQMaxJobs];
+    __shared__ uint32_t modes[2 * kQMaxJobs];
     __shared__ uint32_t h[2 * (kQ2 + kQTrash)];
     __shared__ uint32_t red[4][kBlock / kWave];
     constexpr uint32_t kLocalCap = 512;
     __shared__ uint32_t staged[2][kLocalCap];
     __shared__ uint32_t staged_n[2], staged_base[2];
     __shared__ uint32_t tail_keys[kQCap];          // the tail's LDS copy of a candidate list
-    __shared__ uint32_t scratch[16];
+    __shared__ uint32_t scratch[32];
     __shared__ uint32_t sel[2];
     __shared__ uint32_t flag;
     if (!s.all_open && s.header[kGOpen] == 0u) return;
     const uint32_t G = gridDim.x, g = blockIdx.x;
-    uint32_t t = (uint32_t)(((uint64_t)g * s.total_tiles) / G);
-    const uint32_t t_end = (uint32_t)(((uint64_t)(g + 1) * s.total_tiles) / G);
-    if (t >= t_end) return;
-    load_prefix(ft, s.first_tile, s.count);
+    load_modes(modes, s);
     for (int i = threadIdx.x; i < 2 * (kQ2 + kQTrash); i += kBlock) h[i] = 0;
     if (threadIdx.x < 2) staged_n[threadIdx.x] = 0;
     __syncthreads();
-    for (uint32_t j = find_job(ft, s.count, t); t < t_end; j++) {
+    for (uint32_t j = 0; j < s.count; j++) {
+        const uint32_t m_hi = modes[2 * j], m_lo = modes[2 * j + 1];
+        if (m_hi == kModeDone && m_lo == kModeDone) continue;
         const QJob job = s.job[j];
-        const uint32_t j_end = (j + 1 < s.count) ? ft[j + 1] : s.total_tiles;
-        const uint32_t k0 = t - ft[j], k1 = umin(t_end, j_end) - ft[j];
-        t = umin(t_end, j_end);
+        const uint32_t nsl = (job.tiles + kQFSliceTiles - 1) / kQFSliceTiles;
+        uint32_t sl = first_slice(g, G, j), mine = 0;
+        if (sl >= nsl) continue;
         uint32_t* S_hi = job.ws + kOffSel;
         uint32_t* S_lo = job.ws + kOffSel + 8;
-        const uint32_t m_hi = S_hi[kSMode], m_lo = S_lo[kSMode];
-        if (m_hi == kModeDone && m_lo == kModeDone) continue;
         // a finished side must match nothing: 0xFFFFFFFF is no 12-bit prefix
         const uint32_t p_hi = m_hi == kModeDone ? 0xFFFFFFFFu : S_hi[kSTop];
         const uint32_t p_lo = m_lo == kModeDone ? 0xFFFFFFFFu : S_lo[kSTop];
@@ -941,7 +950,10 @@ __global__ __launch_bounds__(kBlock) void quantile_f2_kernel(const QSeq s) {
         hi_c.init(h, kQ2);
         lo_c.init(h + kQ2 + kQTrash, kQ2);
         uint32_t mn_hi = 0xFFFFFFFFu, mx_hi = 0u, mn_lo = 0xFFFFFFFFu, mx_lo = 0u;
-        walk_job_tiles(job.x, job.n, k0, k1,
+        for (; sl < nsl; sl += G) {
+          const uint32_t k0 = sl * kQFSliceTiles, k1 = umin(k0 + kQFSliceTiles, job.tiles);
+          mine += k1 - k0;
+          walk_job_tiles(job.x, job.n, k0, k1,
                        [&](float v, bool in) {
                            const uint32_t key = f2key(v);
                            hi_c.elect((int)((key >> 8) & 0xFFFu), in && !compact_hi && (key >> 20) == p_hi);
@@ -966,6 +978,7 @@ __global__ __launch_bounds__(kBlock) void quantile_f2_kernel(const QSeq s) {
                                } else { lo_c.add(mid); mn_lo = umin(mn_lo, key); mx_lo = umax(mx_lo, key); }
                            }
                        });
+        }
         hi_c.flush(); lo_c.flush();
         // workgroup min / max of the bucket keys -> one atomic pair per side
         mn_hi = wave_min_u32(mn_hi); mx_hi = wave_max_u32(mx_hi); mn_lo = wave_min_u32(mn_lo); mx_lo = wave_max_u32(mx_lo);
@@ -999,7 +1012,7 @@ __global__ __launch_bounds__(kBlock) void quantile_f2_kernel(const QSeq s) {
         if (threadIdx.x < kQTrash) { h[kQ2 + threadIdx.x] = 0; h[2 * kQ2 + kQTrash + threadIdx.x] = 0; }
         __syncthreads();
         if (threadIdx.x < 2) staged_n[threadIdx.x] = 0;
-        if (job_ticket(job.ws + kOffTick + 1, k1 - k0, job.tiles, &flag)) {
+        if (job_ticket(job.ws + kOffTick + 1, mine, job.tiles, &flag)) {
             // the tail: h doubles as the selection's scratch (its counters are flushed and zero)
             for (int w = 0; w < 2; w++) {
                 uint32_t* S = w ? S_lo : S_hi;
@@ -1027,7 +1040,7 @@ __global__ __launch_bounds__(kBlock) void quantile_f2_kernel(const QSeq s) {
                     } else {
                         const uint32_t need_in = target > outer ? target - outer : 1u;     // >= the bucket's share of `wanted`
                         const uint32_t r = w ? umin(inb, need_in) - 1u : (inb > need_in ? inb - need_in : 0u);
-                        select_bin(job.ws + kOffH2 + w * kQ2, kQ2, r, scratch, sel);
+                        select_bin<kBlock>(job.ws + kOffH2 + w * kQ2, kQ2, r, scratch, sel);
                         const uint32_t m = sel[0], p24 = (top << 12) | m;
                         if (w) { listed = outer + (r - sel[1]) + job.ws[kOffH2 + kQ2 + m]; ok = p24 < 0xFFFFFFu; T = (p24 + 1u) << 8; }
                         else { listed = outer + inb - (r - sel[1]); ok = p24 > 0u; T = (p24 << 8) - 1u; }
@@ -1046,13 +1059,13 @@ __global__ __launch_bounds__(kBlock) void quantile_f2_kernel(const QSeq s) {
                     // every candidate shares `top`: the rank inside the bucket is the rank inside the list
                     KeyLists L;
                     L.base = job.ws + kOffCand + w * kQCap; L.seg = kQCap; L.segments = 1; L.count = count; L.cnt[0] = count;
-                    const uint32_t key = list_select(L, rank, tail_keys, h, scratch, sel);
+                    const uint32_t key = list_select<kBlock>(L, rank, tail_keys, kQCap, h, scratch, sel);
                     if (threadIdx.x == 0) { job.dest[w] = key2f(key); S[kSMode] = kModeDone; }
                 } else if (mode == kModeHist) {
                     if (S[kSMin] == S[kSMax]) {                             // every element of the bucket is the same value
                         if (threadIdx.x == 0) { job.dest[w] = key2f(S[kSMin]); S[kSMode] = kModeDone; }
                     } else {
-                        select_bin(job.ws + kOffH2 + w * kQ2, kQ2, rank, scratch, sel);
+                        select_bin<kBlock>(job.ws + kOffH2 + w * kQ2, kQ2, rank, scratch, sel);
                         if (threadIdx.x == 0) {
                             S[kSP24] = (top << 12) | sel[0]; S[kSR24] = sel[1];
                             atomicAdd(&s.header[kGOpen3], 1u);
@@ -1069,33 +1082,33 @@ __global__ __launch_bounds__(kBlock) void quantile_f2_kernel(const QSeq s) {
 
 // ---- F3: last 8 bits of the sides still open; tail: pick ----------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void quantile_f3_kernel(const QSeq s) {
-    __shared__ uint32_t ft[kQMaxJobs];
+    __shared__ uint32_t modes[2 * kQMaxJobs];
     __shared__ uint32_t h[2 * (kQ3 + kQTrash)];
-    __shared__ uint32_t scratch[16];
+    __shared__ uint32_t scratch[32];
     __shared__ uint32_t sel[2];
     __shared__ uint32_t flag;
     if (s.header[kGOpen3] == 0u) return;
     const uint32_t G = gridDim.x, g = blockIdx.x;
-    uint32_t t = (uint32_t)(((uint64_t)g * s.total_tiles) / G);
-    const uint32_t t_end = (uint32_t)(((uint64_t)(g + 1) * s.total_tiles) / G);
-    if (t >= t_end) return;
-    load_prefix(ft, s.first_tile, s.count);
+    load_modes(modes, s);
     for (int i = threadIdx.x; i < 2 * (kQ3 + kQTrash); i += kBlock) h[i] = 0;
     __syncthreads();
-    for (uint32_t j = find_job(ft, s.count, t); t < t_end; j++) {
+    for (uint32_t j = 0; j < s.count; j++) {
+        const bool need_hi = modes[2 * j] == kModeHist, need_lo = modes[2 * j + 1] == kModeHist;
+        if (!need_hi && !need_lo) continue;
         const QJob job = s.job[j];
-        const uint32_t j_end = (j + 1 < s.count) ? ft[j + 1] : s.total_tiles;
-        const uint32_t k0 = t - ft[j], k1 = umin(t_end, j_end) - ft[j];
-        t = umin(t_end, j_end);
+        const uint32_t nsl = (job.tiles + kQFSliceTiles - 1) / kQFSliceTiles;
+        uint32_t sl = first_slice(g, G, j), mine = 0;
+        if (sl >= nsl) continue;
         const uint32_t* S_hi = job.ws + kOffSel;
         const uint32_t* S_lo = job.ws + kOffSel + 8;
-        const bool need_hi = S_hi[kSMode] == kModeHist, need_lo = S_lo[kSMode] == kModeHist;
-        if (!need_hi && !need_lo) continue;
         const uint32_t p_hi = S_hi[kSP24], p_lo = S_lo[kSP24];
         HotCounter hi_c, lo_c;
         hi_c.init(h, kQ3);
         lo_c.init(h + kQ3 + kQTrash, kQ3);
-        walk_job_tiles(job.x, job.n, k0, k1,
+        for (; sl < nsl; sl += G) {
+          const uint32_t k0 = sl * kQFSliceTiles, k1 = umin(k0 + kQFSliceTiles, job.tiles);
+          mine += k1 - k0;
+          walk_job_tiles(job.x, job.n, k0, k1,
                        [&](float v, bool in) {
                            const uint32_t key = f2key(v);
                            hi_c.elect((int)(key & 0xFFu), in && need_hi && (key >> 8) == p_hi);
@@ -1107,6 +1120,7 @@ __global__ __launch_bounds__(kBlock) void quantile_f3_kernel(const QSeq s) {
                            if (in && need_hi && (key >> 8) == p_hi) hi_c.add(low);
                            if (in && need_lo && (key >> 8) == p_lo) lo_c.add(low);
                        });
+        }
         hi_c.flush(); lo_c.flush();
         __syncthreads();
         for (int i = threadIdx.x; i < 2 * (kQ3 + kQTrash); i += kBlock) {
@@ -1115,11 +1129,11 @@ __global__ __launch_bounds__(kBlock) void quantile_f3_kernel(const QSeq s) {
             if (v && bin < kQ3) atomicAdd(&job.ws[kOffH3 + side * kQ3 + bin], v);
             h[i] = 0;
         }
-        if (job_ticket(job.ws + kOffTick + 2, k1 - k0, job.tiles, &flag)) {
+        if (job_ticket(job.ws + kOffTick + 2, mine, job.tiles, &flag)) {
             for (int w = 0; w < 2; w++) {
                 const uint32_t* S = w ? S_lo : S_hi;
                 if (S[kSMode] == kModeHist) {
-                    select_bin(job.ws + kOffH3 + w * kQ3, kQ3, S[kSR24], scratch, sel);
+                    select_bin<kBlock>(job.ws + kOffH3 + w * kQ3, kQ3, S[kSR24], scratch, sel);
                     if (threadIdx.x == 0) job.dest[w] = key2f((S[kSP24] << 8) | sel[0]);
                 }
                 __syncthreads();
@@ -1166,7 +1180,7 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
                 units += q_job_units(e.n);
                 spec_at += 2 * (size_t)quantile_spec_cap((uint64_t)n);
             }
-            hipLaunchKernelGGL(quantile_init_kernel, dim3(a.count), dim3(kBlock), 0, s, a);
+            hipLaunchKernelGGL(quantile_init_kernel, dim3(a.count * kQInitSplit), dim3(kBlock), 0, s, a);
         }
         QSeq seq;
         seq.job = (const QJob*)(prefix + kQPrefTable);
@@ -1182,7 +1196,7 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
             if (gf < 1) gf = 1;
             if (gf > (uint32_t)(kNumCU * kQFWgPerCu)) gf = kNumCU * kQFWgPerCu;
             hipLaunchKernelGGL(quantile_filter_kernel, dim3(gf), dim3(kQFBlock), 0, s, seq);
-            hipLaunchKernelGGL(quantile_select_a_kernel, dim3(2 * (uint32_t)count), dim3(kBlock), 0, s, seq);
+            hipLaunchKernelGGL(quantile_select_a_kernel, dim3(2 * (uint32_t)count), dim3(kQSABlock), 0, s, seq);
         }
         uint32_t gF = tiles < (uint32_t)(kNumCU * 4) ? tiles : (uint32_t)(kNumCU * 4);
         if (gF < 1) gF = 1;

@@ -223,6 +223,9 @@ __global__ __launch_bounds__(kBlock) void minmax_c_row_kernel(const float* __res
 #ifndef PPQHIP_MMC_U
 #define PPQHIP_MMC_U 8
 #endif
+#ifndef PPQHIP_MMC_PRED
+#define PPQHIP_MMC_PRED 0
+#endif
 constexpr int kMMCU = PPQHIP_MMC_U;
 constexpr uint32_t kMMCChunk = 8192;            // elements per chunk of a long row
 __global__ __launch_bounds__(kBlock) void minmax_c_wave_kernel(const float* __restrict__ x, uint32_t epc, int vec_ok, uint32_t C,
@@ -243,8 +246,17 @@ __global__ __launch_bounds__(kBlock) void minmax_c_wave_kernel(const float* __re
             const uint32_t v1 = hi >> 2;
             for (uint32_t v0 = (lo >> 2) + lane; v0 < v1; v0 += 64 * kMMCU) {
                 float4 a[kMMCU];
+#if PPQHIP_MMC_PRED
+                const float qnan = __builtin_nanf("");                                      // fminf / fmaxf ignore it
+#pragma unroll
+                for (int u = 0; u < kMMCU; u++) {
+                    a[u] = make_float4(qnan, qnan, qnan, qnan);
+                    if (v0 + 64 * u < v1) a[u] = xv[v0 + 64 * u];                           // predicated: no load past the row's end
+                }
+#else
 #pragma unroll
                 for (int u = 0; u < kMMCU; u++) a[u] = xv[min(v0 + 64 * u, v1 - 1)];       // clamped: loads stay unconditional
+#endif
 #pragma unroll
                 for (int u = 0; u < kMMCU; u++) {
                     mn = fminf(fminf(mn, a[u].x), fminf(a[u].y, fminf(a[u].z, a[u].w)));

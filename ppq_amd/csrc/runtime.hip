@@ -57,23 +57,6 @@ void* scratch(hipStream_t stream, size_t bytes) {
     return slot.first;
 }
 
-// 64 zero-initialised words per (device, stream) for kernels that count workgroup arrivals ("last workgroup done"):
-// the kernel that uses them leaves them zero again, so the one memset at allocation is the only one.
-static std::map<std::pair<int, hipStream_t>, uint32_t*> g_tickets;
-
-uint32_t* tickets(hipStream_t stream) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
-    uint32_t*& p = g_tickets[{dev, stream}];
-    if (p == nullptr) {
-        void* q = nullptr;
-        if (hipMalloc(&q, 256) != hipSuccess || hipMemset(q, 0, 256) != hipSuccess) { set_error("tickets: allocation failed"); return nullptr; }
-        p = (uint32_t*)q;
-    }
-    return p;
-}
-
 // ---- profiling aid ------------------------------------------------------------------------
 struct ProfRecord {
     int id;

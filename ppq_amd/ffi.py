@@ -299,6 +299,29 @@ class _HipExtension:
         return out
 
     @ staticmethod
+    def QuantizeTensor_ToInt(value, scale, offset, clip_min: int, clip_max: int, rounding: int, channel_axis,
+                             dtype: torch.dtype) -> torch.Tensor:
+        """PPQLinearQuant_toInt's arithmetic (qfunction/linear.py:218-238) as one kernel: quantise only, integer output
+        (``dtype``: torch.int8 / torch.uint8 / torch.int32), element order of ``value.contiguous()``."""
+        _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset')
+        code = {torch.int8: 0, torch.uint8: 1, torch.int32: 2}.get(dtype)
+        if code is None: raise RuntimeError(_KERNEL_FAILURE + f'unsupported integer dtype {dtype}')
+        v = value.contiguous()
+        out = torch.empty(v.shape, dtype=dtype, device=v.device)
+        sc, of = scale.contiguous(), offset.contiguous()
+        with _DeviceOf(v):
+            if channel_axis is None:
+                _raise(lib.ppqhip_to_int_t(v.data_ptr(), sc.data_ptr(), of.data_ptr(), out.data_ptr(), v.numel(), int(clip_min),
+                                           int(clip_max), int(rounding), code, _stream()))
+            else:
+                C, epc = _geometry(v.shape, channel_axis)
+                if sc.numel() < C or of.numel() < C:
+                    raise RuntimeError(_KERNEL_FAILURE + f'scale/offset need {C} elements for channel axis {channel_axis}')
+                _raise(lib.ppqhip_to_int_c(v.data_ptr(), sc.data_ptr(), of.data_ptr(), out.data_ptr(), v.numel(), C, epc,
+                                           int(clip_min), int(clip_max), int(rounding), code, _stream()))
+        return out
+
+    @ staticmethod
     def QuantizeTensor_LT_B(value, scale, offset, grad_y, clip_min: int, clip_max: int,
                             rounding: int) -> List[torch.Tensor]:
         _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset'); _f32(grad_y, 'Gard')
@@ -828,6 +851,11 @@ class CUDA:
     def LinearQuantize_C(tensor, scales, offsets, channel_axis: int, minimum: int = -128, maximum: int = 127,
                          rounding: int = 0):
         return HIP_EXTENSION.QuantizeTensor_LC(tensor, scales, offsets, minimum, maximum, channel_axis, rounding)
+
+    @ staticmethod
+    def LinearQuantize_ToInt(tensor, scales, offsets, minimum: int, maximum: int, rounding: int, channel_axis, dtype):
+        """MI355X-native addition (the reference does this step with torch ops): see HIP_EXTENSION.QuantizeTensor_ToInt."""
+        return HIP_EXTENSION.QuantizeTensor_ToInt(tensor, scales, offsets, minimum, maximum, rounding, channel_axis, dtype)
 
     @ staticmethod
     def LinearQuantize_T_B(tensor, scales, offsets, dy, minimum: int, maximum: int, rounding: int):

@@ -163,25 +163,22 @@ def PPQuantFunction(tensor: torch.Tensor, config) -> torch.Tensor:
 
 
 def PPQLinearQuant_toInt(tensor: torch.Tensor, config) -> torch.Tensor:
-    """qfunction/linear.py:218-238 (quantise only, integer output; torch ops -- used at export
-    time, not on the calibration hot path)."""
-    from .round import ppq_tensor_round
+    """qfunction/linear.py:218-238: quantise only, integer output (int8 / uint8 for 8 bits, int32 above).  The
+    reference evaluates clamp(ppq_tensor_round(x / s) + o, qmin, qmax) with torch ops in float32 and casts; here the same
+    float32 arithmetic is one HIP kernel (ppqhip_to_int_t / _c), no intermediate tensors."""
     if not config.policy.has_property(P.LINEAR):
         raise ValueError('Critical Quantization Error! Non-linear config detected.')
-    if config.policy.has_property(P.PER_CHANNEL):
-        shape = [1 if axis != config.channel_axis else -1 for axis in range(tensor.ndim)]
-        scale, offset = config.scale.view(shape), config.offset.view(shape)
-        tensor = ppq_tensor_round((tensor / scale), config.rounding) + offset
-        tensor = torch.clamp(tensor, config.quant_min, config.quant_max)
-    elif config.policy.has_property(P.PER_TENSOR):
-        tensor = ppq_tensor_round((tensor / config.scale), config.rounding) + config.offset
-        tensor = torch.clamp(tensor, config.quant_min, config.quant_max)
     if config.num_of_bits == 8:
-        if config.policy.has_property(P.SYMMETRICAL): return tensor.type(dtype=torch.int8)
-        if config.policy.has_property(P.ASYMMETRICAL): return tensor.type(dtype=torch.uint8)
-    elif config.num_of_bits > 8:
-        return tensor.type(dtype=torch.int32)
+        if config.policy.has_property(P.SYMMETRICAL): dtype = torch.int8
+        elif config.policy.has_property(P.ASYMMETRICAL): dtype = torch.uint8
+        else: return None                                   # (the reference falls off its if-chain here too)
+    elif config.num_of_bits > 8: dtype = torch.int32
     else: raise Exception('Do not konw how to convert value into int. num of bits is unexpected.')
+    if config.policy.has_property(P.PER_CHANNEL): axis = config.channel_axis
+    elif config.policy.has_property(P.PER_TENSOR): axis = None
+    else: return tensor.type(dtype=dtype)                   # neither granularity: the reference casts the tensor as it is
+    return CUDA.LinearQuantize_ToInt(tensor, config.scale, config.offset, config.quant_min, config.quant_max,
+                                     rounding_value(config.rounding), axis, dtype)
 
 
 def PPQuantFunction_toInt(tensor: torch.Tensor, config) -> torch.Tensor:

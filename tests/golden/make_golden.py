@@ -11,6 +11,7 @@ kernels.  Outputs (committed, all small):
     tests/golden/linear_fq.npz        per-tensor / per-channel linear fake-quant
     tests/golden/rounding.npz         ppq_tensor_round / ppq_numerical_round tables
     tests/golden/observers.npz        minmax / percentile / kl / mse observer results
+    tests/golden/to_int.npz           PPQLinearQuant_toInt (quantise only, integer output; --to-int-only regenerates just this file)
     tests/golden/fp8_ref.npz          FP8 fake-quant + the 8 rounding modes, from the reference's common.cuh compiled on the host
                                       (--fp8-only regenerates just this file)
 
@@ -50,6 +51,7 @@ _orig_round = ref_range.ppq_numerical_round
 ref_range.ppq_numerical_round = lambda v, *a, **k: _orig_round(float(v), *a, **k)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
 P = QuantizationProperty
 
 
@@ -350,8 +352,26 @@ def gen_fp8_ref():
     print('fp8_ref.npz', len(out), 'arrays,', os.path.getsize(os.path.join(HERE, 'fp8_ref.npz')), 'bytes')
 
 
+from to_int_cases import to_int_cases, to_int_inputs  # noqa: E402  (shared with the tests; imports nothing of the reference)
+
+
+def gen_to_int():
+    from ppq.quantization.qfunction.linear import PPQLinearQuant_toInt
+    out = {}
+    for key, shape, axis, sym, bits, qmin, qmax, r in to_int_cases():
+        x, scale, offset = to_int_inputs(key, shape, axis)
+        cfg = tqc(per_channel=axis is not None, sym=sym, qmin=qmin, qmax=qmax, bits=bits, axis=axis, rounding=RoundingPolicy(r))
+        cfg.scale, cfg.offset, cfg.state = scale, offset, QuantizationStates.ACTIVATED
+        y = PPQLinearQuant_toInt(x, cfg)
+        out[key] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, 'to_int.npz'), **out)
+    print('to_int.npz', len(out), 'arrays,', os.path.getsize(os.path.join(HERE, 'to_int.npz')), 'bytes')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
+    if '--to-int-only' in sys.argv:
+        gen_to_int(); sys.exit(0)
     if '--fp8-only' in sys.argv:
         gen_fp8_ref(); sys.exit(0)
     if '--cuda-rule-only' not in sys.argv:
@@ -360,3 +380,4 @@ if __name__ == '__main__':
         gen_observers()
     gen_observers_cuda_rule()
     gen_fp8_ref()
+    gen_to_int()

@@ -449,3 +449,18 @@ def test_fp8_and_rounding_restatement_equals_reference_goldens(golden_dir):
         ok = got == want[rounding]
         if not ok.all():       # host conversion of |v| >= 2^31 is undefined in the golden's producer; the oracle saturates
             assert all(abs(float(v[i])) >= 2.0 ** 31 for i in np.nonzero(~ok)[0]), (rounding, v[~ok], got[~ok], want[rounding][~ok])
+
+
+def test_to_int_oracle_matches_reference_outputs(golden_dir):
+    """oracle.to_int (PPQLinearQuant_toInt restated, qfunction/linear.py:218-238 + utils/round.py:9-49) against what the
+    reference's own function returned on the seeded cases of tests/golden/to_int_cases.py (make_golden.py --to-int-only):
+    6 tensor-rounding policies x {per-tensor int8, per-channel uint8}, axis 0 / last axis, int32 containers, a 4-bit range,
+    ties at +-0.5 and fractional offsets."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from to_int_cases import to_int_cases, to_int_inputs
+    z = np.load(os.path.join(golden_dir, 'to_int.npz'))
+    for key, shape, axis, sym, bits, qmin, qmax, r in to_int_cases():
+        x, s, o = to_int_inputs(key, shape, axis)
+        got = O.to_int(x.numpy(), s.numpy(), o.numpy(), qmin, qmax, r, axis, z[key].dtype)
+        assert got.dtype == z[key].dtype and np.array_equal(got, z[key]), key

@@ -8,7 +8,7 @@ rm -rf $O; mkdir -p $O
 (time timeout 900 python -m pytest tests -q -m gpu -k "quantile or minmax or lsq or percentile" -x) > $O/pytest.log 2>&1
 echo "rc=$?" >> $O/pytest.log
 timeout 300 python tools/quantile_diag.py 4 > $O/diag.txt 2>&1
-for v in $(ls variants/lib_qf*.so); do
+for v in $(ls variants/lib_qf*.so 2>/dev/null); do
   n=$(basename $v .so); echo "== $n" >> $O/variants.txt
   PPQHIP_LIBRARY=$R/$v timeout 200 python tools/microbench.py --tensors Bx32 --only quantile 2>&1 | grep quantile >> $O/variants.txt
 done
