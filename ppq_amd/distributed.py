@@ -30,17 +30,20 @@ def is_distributed(group=None) -> bool:
 last_merge_stats: dict = {}     # what the most recent merge_observers() moved (bench.py reports it)
 
 
-def _check_layout(dist, lengths: List[int], device, group) -> None:
+def _check_layout(dist, lengths: List[int], device, group, largest_count: int = 0) -> int:
     """Every rank must bring the same flat layout: an observer that saw no batch on one rank (fewer
     batches than ranks, uneven shards) declares nothing, and all-reducing buffers of different length
-    hangs or corrupts.  ONE tiny MAX all-reduce over [len, -len, ...] detects it on every rank."""
-    probe = torch.tensor([v for n in lengths for v in (n, -n)], dtype=torch.int64, device=device)
+    hangs or corrupts.  ONE tiny MAX all-reduce over [len, -len, ...] detects it on every rank.  The same
+    collective carries the largest int32 count any rank holds (returned: the maximum over ranks), which
+    decides whether the int32 SUM can overflow."""
+    probe = torch.tensor([v for n in lengths for v in (n, -n)] + [int(largest_count)], dtype=torch.int64, device=device)
     dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
     got = probe.tolist()
     if any(got[2 * i] != -got[2 * i + 1] for i in range(len(lengths))):
         raise RuntimeError('merge_observers: the ranks declare different statistics layouts '
                            f'(this rank: {lengths}, max over ranks: {got[0::2]}); every rank must observe at '
                            'least one batch with every observer before a merge (calib_steps >= world_size)')
+    return int(got[-1])
 
 
 def merge_observers(observers: Sequence, group=None, even_if_single_rank: bool = False) -> int:
@@ -75,7 +78,13 @@ def merge_observers(observers: Sequence, group=None, even_if_single_rank: bool =
     some = mins + maxs + [b for v in sums.values() for b in v]
     backend = dist.get_backend(group)
     device = some[0].device if some else torch.device('cuda' if backend == 'nccl' else 'cpu')
-    _check_layout(dist, lengths, device, group)
+    # int32 histograms (the reference's counter type, sort.cu:91-165): world_size ranks x the largest count any of them
+    # holds bounds every merged bin -- below 2^31 the int32 SUM cannot wrap; otherwise the buffers are summed in int64 and
+    # a bin that really passes 2^31 raises instead of wrapping silently (the reference wraps in one process, too)
+    i32 = sums.get(torch.int32) or []
+    largest = max((int(b.max()) for b in i32 if b.numel()), default=0)
+    largest = _check_layout(dist, lengths, device, group, largest)
+    widen_i32 = largest * dist.get_world_size(group) >= 2 ** 31
     issued = 0
     moved = {}
     if mins or maxs:
@@ -92,7 +101,16 @@ def merge_observers(observers: Sequence, group=None, even_if_single_rank: bool =
         bufs = sums.get(dtype)
         if not bufs: continue
         flat = torch.cat([b.reshape(-1) for b in bufs])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        if dtype == torch.int32 and widen_i32:
+            wide = flat.to(torch.int64)
+            dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=group)
+            if int(wide.max()) >= 2 ** 31:
+                raise OverflowError('merge_observers: a merged histogram bin reaches 2^31 counts; int32 histograms cannot hold '
+                                    f'it (largest bin {int(wide.max())}).  Calibrate with fewer samples per observer or more bins.')
+            flat = wide.to(torch.int32)
+            moved['sum_int32_widened'] = 1
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
         issued += 1
         moved[f'sum_{str(dtype).split(".")[-1]}_bytes'] = flat.numel() * flat.element_size()
         pos = 0

@@ -266,6 +266,43 @@ def test_merge_observers_gloo_world2():
         assert shard == list(range(rank, 10, 2))
 
 
+def _overflow_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ppq_amd import distributed as D
+
+    class FakeObserver:
+        def __init__(self, bufs): self.bufs = bufs
+        def reducible(self): return self.bufs
+    big = torch.tensor([1_200_000_000, 5, 7 + rank], dtype=torch.int32)     # 2 x 1.2e9 = 2.4e9 > 2^31 - 1 in bin 0
+    try:
+        D.merge_observers([FakeObserver([(big, 'sum')])]); first = 'no error'
+    except OverflowError as e:
+        first = str(e)
+    fits = torch.tensor([1_500_000_000 if rank == 0 else 500_000_000, 5, 7 + rank], dtype=torch.int32)    # 2 x 1.5e9 could wrap: widened; the real sum 2e9 fits
+    D.merge_observers([FakeObserver([(fits, 'sum')])])
+    q.put((rank, first, fits.tolist(), D.last_merge_stats.get('sum_int32_widened', 0)))
+    dist.destroy_process_group()
+
+
+def test_merge_guards_the_int32_histogram_limit():
+    """The reference's histograms are int32 (sort.cu:91-165); summed over ranks a bin can pass 2^31.  The layout probe carries
+    the largest per-rank count, so the common case stays one int32 SUM; when world_size x that count could wrap, the merge sums
+    in int64 and raises on a real overflow instead of wrapping silently."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_overflow_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)])
+    for p in procs: p.join(timeout=60)
+    for rank, first, fits, widened in res:
+        assert 'reaches 2^31' in first, first
+        assert fits == [2_000_000_000, 10, 15] and widened == 1
+
+
 def test_merge_is_noop_without_process_group():
     from ppq_amd.distributed import merge_observers, shard_batches
 
