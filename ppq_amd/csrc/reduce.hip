@@ -183,48 +183,14 @@ __global__ __launch_bounds__(kBlock) void minmax_finish_kernel(const float* __re
     }
 }
 
-#ifndef PPQHIP_MMC_WAVE
-#define PPQHIP_MMC_WAVE 1
-#endif
-// rows of `epc` contiguous elements, workgroup = (row, chunk)
-__global__ __launch_bounds__(kBlock) void minmax_c_row_kernel(const float* __restrict__ x, uint32_t epc, int vec_ok,
-                                                              FastDiv chunks, FastDiv num_channel,
-                                                              uint32_t chunk_elems, float* __restrict__ mins,
-                                                              float* __restrict__ maxs) {
-    __shared__ float lds[16];
-    const uint32_t row = fdiv(blockIdx.x, chunks);
-    const uint32_t chunk = blockIdx.x - row * chunks.d;
-    const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
-    const uint32_t lo = chunk * chunk_elems;
-    const uint32_t hi = min(lo + chunk_elems, epc);
-    const float* xr = x + (size_t)row * epc;
-    float mn = INFINITY, mx = -INFINITY;
-    if (vec_ok) {   // epc % 4 == 0, chunk_elems % 4 == 0, base 16-B aligned
-        const float4* xv = reinterpret_cast<const float4*>(xr);
-        for (uint32_t v = (lo >> 2) + threadIdx.x; v < (hi >> 2); v += kBlock) {
-            const float4 a = xv[v];
-            mn = fminf(fminf(mn, a.x), fminf(a.y, fminf(a.z, a.w)));
-            mx = fmaxf(fmaxf(mx, a.x), fmaxf(a.y, fmaxf(a.z, a.w)));
-        }
-    } else {
-        for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
-            const float a = xr[j];
-            mn = fminf(mn, a); mx = fmaxf(mx, a);
-        }
-    }
-    block_minmax_commit(mn, mx, &mins[c], &maxs[c], lds);
-}
-
 // rows of `epc` contiguous elements, ONE WAVE per work item, no workgroup barrier anywhere: item i = (channel c = i % C,
 // row group g = i / C, chunk) -> the wave reduces `K` rows of its channel (rows g*K .. of stride C) or one 8192-element
 // chunk of one row, with U 16-B loads in flight per lane, folds across its 64 lanes with shuffles and commits ONE pair of
-// atomics.  (The workgroup-per-row kernel above spends a barrier, an LDS round trip and two atomics on every 12.5 KB row
-// of a [32, 512, 56, 56] activation and keeps one load per lane in flight: 0.68 of the roofline where minmax_t has 0.79.)
+// atomics.  (Round 2's workgroup-per-row kernel spent a barrier, an LDS round trip and two atomics on every 12.5 KB row
+// of a [32, 512, 56, 56] activation and kept one load per lane in flight: 0.68 of the roofline, this one 0.72; predicated
+// instead of clamped loads, U = 4 / 16: within 1 us of each other, profiles/r03_minmax_c_variants.txt.)
 #ifndef PPQHIP_MMC_U
 #define PPQHIP_MMC_U 8
-#endif
-#ifndef PPQHIP_MMC_PRED
-#define PPQHIP_MMC_PRED 0
 #endif
 constexpr int kMMCU = PPQHIP_MMC_U;
 constexpr uint32_t kMMCChunk = 8192;            // elements per chunk of a long row
@@ -246,17 +212,8 @@ __global__ __launch_bounds__(kBlock) void minmax_c_wave_kernel(const float* __re
             const uint32_t v1 = hi >> 2;
             for (uint32_t v0 = (lo >> 2) + lane; v0 < v1; v0 += 64 * kMMCU) {
                 float4 a[kMMCU];
-#if PPQHIP_MMC_PRED
-                const float qnan = __builtin_nanf("");                                      // fminf / fmaxf ignore it
-#pragma unroll
-                for (int u = 0; u < kMMCU; u++) {
-                    a[u] = make_float4(qnan, qnan, qnan, qnan);
-                    if (v0 + 64 * u < v1) a[u] = xv[v0 + 64 * u];                           // predicated: no load past the row's end
-                }
-#else
 #pragma unroll
                 for (int u = 0; u < kMMCU; u++) a[u] = xv[min(v0 + 64 * u, v1 - 1)];       // clamped: loads stay unconditional
-#endif
 #pragma unroll
                 for (int u = 0; u < kMMCU; u++) {
                     mn = fminf(fminf(mn, a[u].x), fminf(a[u].y, fminf(a[u].z, a[u].w)));
@@ -539,7 +496,6 @@ int ppqhip_minmax_c(const float* x, int64_t n, int64_t num_channel, int64_t elem
     if (elem_per_channel >= 64) {
         const int64_t rows = n / elem_per_channel;
         const int vec_ok = (aligned16(x) && elem_per_channel % 4 == 0) ? 1 : 0;
-#if PPQHIP_MMC_WAVE
         const uint32_t C = (uint32_t)num_channel, outer = (uint32_t)(rows / num_channel);
         const uint32_t chunks = (uint32_t)((elem_per_channel + kMMCChunk - 1) / kMMCChunk);
         // short rows: K rows of a channel per wave while that leaves the chip >= 32 waves per CU
@@ -555,12 +511,6 @@ int ppqhip_minmax_c(const float* x, int64_t n, int64_t num_channel, int64_t elem
         const uint32_t items = groups * C * chunks;
         hipLaunchKernelGGL(minmax_c_wave_kernel, dim3((items + kBlock / kWave - 1) / (kBlock / kWave)), dim3(kBlock), 0, s, x,
                            (uint32_t)elem_per_channel, vec_ok, C, outer, K, chunks, items, mins, maxs);
-#else
-        const uint32_t chunk_elems = 8192;
-        const uint32_t chunks = (uint32_t)((elem_per_channel + chunk_elems - 1) / chunk_elems);
-        hipLaunchKernelGGL(minmax_c_row_kernel, dim3((uint32_t)(rows * chunks)), dim3(kBlock), 0, s, x,
-                           (uint32_t)elem_per_channel, vec_ok, make_fastdiv(chunks), nc, chunk_elems, mins, maxs);
-#endif
     } else {
         const int use_lds = num_channel <= 4096;
         const size_t lds = use_lds ? 2 * sizeof(float) * (size_t)num_channel : 0;

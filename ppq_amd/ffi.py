@@ -16,6 +16,8 @@ All tensor arguments must live on the GPU.  There is no CPU path: a CPU tensor r
 Errors follow the reference's convention as seen from Python: the C++ ``ValueTypeException`` /
 ``InvalidValueException`` (common.cuh:32-48) surface as ``RuntimeError``.
 """
+import sys
+import weakref
 from typing import List
 
 import numpy as np
@@ -138,11 +140,13 @@ _FLOAT_SEARCH_JOB = np.dtype([('x', '<u8'), ('rows', '<i8'), ('row_len', '<i8'),
                               ('clip_min', '<f4'), ('clip_max', '<f4')])
 _QUANTILE_JOB = np.dtype([('x', '<u8'), ('dest', '<u8'), ('hint', '<u8'), ('n', '<i8')])
 
-# Quantile_T(source, q) is stateless in the reference; calibration calls it batch after batch on the same activation, so the
-# drop-in entry point keeps one threshold hint (include/ppq_hip.h: ppqhip_quantile_t) per (device, numel, q).  A hint only
-# ever changes how much the kernels read, never the result.
-_quantile_hints = {}
-_MAX_QUANTILE_HINTS = 4096
+# Quantile_T(source, q) is stateless in the reference, but calibration calls it batch after batch from the same observer on
+# the same activation.  The drop-in entry point therefore keeps one threshold hint (include/ppq_hip.h: ppqhip_quantile_t)
+# per CALLING OBJECT -- the `self` of the nearest caller frame, i.e. the reference's TorchPercentileObserver instance, held
+# weakly -- and (device, numel, q).  Keying on the shape alone would hand the thresholds of one layer to every other layer
+# of the same size (a CNN repeats its shapes), and a misplaced hint costs the exact passes.  No calling object -> no hint
+# (every call samples its thresholds).  A hint only ever changes how much the kernels read, never the result.
+_owner_hints = weakref.WeakKeyDictionary()
 
 
 def quantile_hint(device: torch.device) -> torch.Tensor:
@@ -150,13 +154,20 @@ def quantile_hint(device: torch.device) -> torch.Tensor:
     return torch.zeros(8, dtype=torch.int32, device=device)
 
 
-def _cached_quantile_hint(device: torch.device, numel: int, q: float) -> torch.Tensor:
-    key = (device.index, int(numel), float(q))
-    h = _quantile_hints.get(key)
-    if h is None:
-        if len(_quantile_hints) >= _MAX_QUANTILE_HINTS: _quantile_hints.clear()
-        h = _quantile_hints[key] = quantile_hint(device)
-    return h
+def _caller_quantile_hint(device: torch.device, numel: int, q: float, depth: int = 2):
+    f = sys._getframe(depth)
+    for _ in range(3):
+        if f is None: return None
+        owner = f.f_locals.get('self')
+        if owner is not None:
+            try: per = _owner_hints.setdefault(owner, {})
+            except TypeError: return None                       # not weakly referenceable
+            key = (device.index, int(numel), float(q))
+            h = per.get(key)
+            if h is None: h = per[key] = quantile_hint(device)
+            return h
+        f = f.f_back
+    return None
 _HIST_JOB = np.dtype([('x', '<u8'), ('rows', '<u8'), ('n', '<i8'), ('p0', '<f4'), ('p1', '<f4')])
 
 
@@ -464,12 +475,12 @@ class _HipExtension:
 
     @ staticmethod
     def Quantile_T(source, q: float, hint='auto') -> torch.Tensor:
-        """``hint``: 'auto' (one cached hint per (device, numel, q)), None (none: every call estimates its thresholds
-        from a sample), or an int32[8] device tensor from ``quantile_hint`` owned by the caller."""
+        """``hint``: 'auto' (one hint per calling object, see ``_caller_quantile_hint``), None (none: every call estimates its
+        thresholds from a sample), or an int32[8] device tensor from ``quantile_hint`` owned by the caller."""
         _f32(source, 'Value')
         v = _dense(source)
         dest = torch.empty(2, dtype=torch.float32, device=v.device)
-        if isinstance(hint, str): hint = _cached_quantile_hint(v.device, v.numel(), q)
+        if isinstance(hint, str): hint = _caller_quantile_hint(v.device, v.numel(), q)
         with _DeviceOf(v):
             ws = _workspace(v.device, lib.ppqhip_quantile_workspace_bytes(v.numel()))
             _raise(lib.ppqhip_quantile_t(v.data_ptr(), v.numel(), float(q), dest.data_ptr(),

@@ -76,6 +76,8 @@ def main():
         ws = torch.empty(int(lib.ppqhip_hist_workspace_bytes(n, args.bins)) + 64, dtype=torch.uint8, device=dev)
 
         def P(t): return t.data_ptr()
+        from ppq_amd.ffi import quantile_hint
+        qhint = quantile_hint(torch.device(dev))
 
         def fq_t():
             i = nxt(); lib.ppqhip_fq_linear_t(P(xs[i]), P(s1), P(o1), P(outs[i]), n, -128, 127, 0, stream())
@@ -105,7 +107,7 @@ def main():
             'hist_sym_t (rows)': (4, lambda: lib.ppqhip_hist_sym_t_rows(P(xs[nxt()]), n, hs, 1, P(rowsbuf), args.bins, stream())),
             'minmax_t (slots)': (4, lambda: lib.ppqhip_minmax_t_slots(P(xs[nxt()]), n, P(slots), stream())),
             'minmax_c': (4, lambda: lib.ppqhip_minmax_c(P(xs[nxt()]), n, C, epc, P(mins), P(maxs), stream())),
-            'quantile_t (hinted)': (4, lambda: CUDA.Quantile(xs[nxt()], 0.9999)),          # the drop-in call: thresholds of the previous batch
+            'quantile_t (hinted)': (4, lambda: CUDA.Quantile_Hinted(xs[nxt()], 0.9999, qhint)),   # an observer's call: thresholds of the previous batch
             'quantile_t (cold)': (4, lambda: CUDA.Quantile_Hinted(xs[nxt()], 0.9999, None)),      # every call samples its thresholds
             'lsq_bwd_t': (12, bwd_t), 'lsq_bwd_c': (12, bwd_c),
             'torch out.copy_(x) (ref)': (8, copy),
