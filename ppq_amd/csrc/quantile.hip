@@ -155,6 +155,7 @@ struct QSeq {                 // what every kernel of a sequence receives
     const uint32_t* first_tile;   // [count] prefix of QJob::tiles
     const uint32_t* first_unit;   // [count] prefix of QJob::units
     uint32_t* header;
+    uint32_t* fixed;              // record of the sequence's job 0 (record j: fixed + j * kQWords == job[j].ws)
     uint32_t count, total_tiles, total_units, all_open;
 };
 // layout of the sequence prefix inside the workspace (bytes)
@@ -791,9 +792,10 @@ __global__ __launch_bounds__(kQSABlock) void quantile_select_a_kernel(const QSeq
     __shared__ uint32_t h[kQ1];
     __shared__ uint32_t scratch[32];
     __shared__ uint32_t sel[2];
+    // (the counters are addressed from the sequence's base, not through the job record: both loads leave together)
+    const uint32_t* P = s.fixed + (size_t)(blockIdx.x >> 1) * kQWords + kOffSpec;
     const QJob job = s.job[blockIdx.x >> 1];
     const int w = (int)(blockIdx.x & 1u);
-    const uint32_t* P = job.ws + kOffSpec;
     const uint32_t n = job.n, k = w ? job.k_lo : job.k_hi;
     bool done = false, keep = false;
     const uint32_t T = P[w ? kPTLo : kPTHi];
@@ -850,7 +852,7 @@ __global__ __launch_bounds__(kQSABlock) void quantile_select_a_kernel(const QSeq
 constexpr uint32_t kQFSliceTiles = 8;              // 32768 elements (128 KB) per slice
 __device__ __forceinline__ void load_modes(uint32_t* modes, const QSeq& s) {
     for (uint32_t i = threadIdx.x; i < 2u * s.count; i += blockDim.x)
-        modes[i] = s.job[i >> 1].ws[kOffSel + 8 * (i & 1u) + kSMode];
+        modes[i] = s.fixed[(size_t)(i >> 1) * kQWords + kOffSel + 8 * (i & 1u) + kSMode];      // == job[i >> 1].ws[..], one load
     __syncthreads();
 }
 __device__ __forceinline__ uint32_t first_slice(uint32_t g, uint32_t G, uint32_t j) { return (g + G - (j * 61u) % G) % G; }
@@ -1187,6 +1189,7 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
         seq.first_tile = (const uint32_t*)(prefix + kQPrefTile);
         seq.first_unit = (const uint32_t*)(prefix + kQPrefUnit);
         seq.header = (uint32_t*)(prefix + kQPrefHeader);
+        seq.fixed = fixed + (size_t)seq_base * kQWords;
         seq.count = (uint32_t)count; seq.total_tiles = tiles; seq.total_units = units;
         seq.all_open = elems >= kQSpeculateMinElems ? 0u : 1u;
         if (!seq.all_open) {

@@ -1,5 +1,7 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: parity tests of the touched kernels, per-tensor diagnosis, geometry variants, timings
+# Runs ON THE GPU BOX (gpurun -- bash tools/quantile_profile.sh <tag>): parity tests of quantile / minmax / lsq, the per-tensor
+# diagnosis of a real calibration (tools/quantile_diag.py), variants/lib_*.so built by tools/variants.sh, micro-benchmarks,
+# rocprofv3 kernel traces of the micro-benchmark and of bench.py --method percentile (profiles/r03_quantile_*)
 set -u
 export TMPDIR=/tmp
 R=$PWD
