@@ -1136,7 +1136,20 @@ __global__ __launch_bounds__(kBlock) void quantile_f3_kernel(const QSeq s) {
                 const uint32_t* S = w ? S_lo : S_hi;
                 if (S[kSMode] == kModeHist) {
                     select_bin<kBlock>(job.ws + kOffH3 + w * kQ3, kQ3, S[kSR24], scratch, sel);
-                    if (threadIdx.x == 0) job.dest[w] = key2f((S[kSP24] << 8) | sel[0]);
+                    if (threadIdx.x == 0) {
+                        const uint32_t V = (S[kSP24] << 8) | sel[0];
+                        job.dest[w] = key2f(V);
+                        // hist3 counts single keys: the answer's exact multiplicity.  A heavy tie on a value no threshold rule
+                        // looks at (a clip at 5.3, say) would list itself into an overflow batch after batch; with the threshold
+                        // ON the value select A settles it from the tie count (one element in eight is counted: 16x margin).
+                        const uint32_t mult = job.ws[kOffH3 + w * kQ3 + sel[0]];
+                        const uint32_t wanted = w ? job.k_lo + 1u : job.n - job.k_hi;
+                        if (job.hint != nullptr && mult / 16u >= wanted + 16u) {
+                            uint32_t* H = job.hint;
+                            H[w ? kHTLo : kHTHi] = V;
+                            H[w ? kHValidLo : kHValidHi] = 1u;
+                        }
+                    }
                 }
                 __syncthreads();
             }

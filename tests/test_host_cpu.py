@@ -623,3 +623,32 @@ def test_block_builder_on_random_dags_vs_the_reference_walk():
                     differs += 1
                     assert not satisfies_definition(hg, *theirs), (seed, limit, mine, theirs)
     assert builds > 500 and 0 < differs < builds // 5
+
+
+def test_drop_in_quantile_hint_is_per_calling_object():
+    """CUDA.Quantile(tensor, q) is stateless in the reference; the facade finds the calling observer on the frame stack and keeps
+    one threshold hint per (caller, device, numel, q), weakly: two observers of equal shape never share thresholds, a plain
+    function gets none (every call samples), and a collected observer releases its hints."""
+    import gc
+    from ppq_amd import ffi
+    dev = torch.device('cpu')                      # the bookkeeping is device agnostic; kernels are not involved
+
+    def facade(numel, q):                          # stands for CUDA.Quantile -> HIP_EXTENSION.Quantile_T (two frames, no `self`)
+        def quantile_t(): return ffi._caller_quantile_hint(dev, numel, q)
+        return quantile_t()
+
+    class Observer:
+        def observe(self, numel, q=0.9999): return facade(numel, q)
+    a, b = Observer(), Observer()
+    ha, hb = a.observe(1000), b.observe(1000)
+    assert ha is not None and hb is not None and ha is not hb
+    assert a.observe(1000) is ha and a.observe(1001) is not ha and a.observe(1000, 0.999) is not ha
+    assert ha.dtype == torch.int32 and ha.numel() == 8 and int(ha.abs().sum()) == 0
+    assert facade(1000, 0.9999) is None            # called from a function: no owner, no hint
+
+    def short_lived():
+        o = Observer(); o.observe(5)
+        return len(ffi._owner_hints)
+    inside = short_lived()
+    gc.collect()
+    assert len(ffi._owner_hints) == inside - 1     # the collected observer took its hints with it
