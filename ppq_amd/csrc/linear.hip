@@ -205,6 +205,9 @@ __device__ __forceinline__ float block_sum(float v, float* lds) {
 #ifndef PPQHIP_LSQ_U
 #define PPQHIP_LSQ_U 4                  // (x, dy) 16-B load pairs in flight per lane (MI355X sweep, Bx32: U=1 152 us, 2 127, 4 116)
 #endif
+#ifndef PPQHIP_LSQ_C_U
+#define PPQHIP_LSQ_C_U 4
+#endif
 #ifndef PPQHIP_LSQ_MAX_WG
 #define PPQHIP_LSQ_MAX_WG 65536         // workgroups per launch (one partial sum each)
 #endif
@@ -311,14 +314,27 @@ __global__ __launch_bounds__(kBlock) void fq_linear_c_bwd_row_kernel(
         const float4* xv = reinterpret_cast<const float4*>(x + base);
         const float4* dv = reinterpret_cast<const float4*>(dy + base);
         float4* gv = reinterpret_cast<float4*>(gx + base);
-        for (uint32_t v = (lo >> 2) + threadIdx.x; v < (hi >> 2); v += kBlock) {
-            const float4 a = xv[v], d = dv[v];
-            float4 g;
-            acc += lsq_bwd_elem<true, R>(a.x, d.x, s, rcp_s, o, oi, qmin, qmax, rounding, &g.x);
-            acc += lsq_bwd_elem<true, R>(a.y, d.y, s, rcp_s, o, oi, qmin, qmax, rounding, &g.y);
-            acc += lsq_bwd_elem<true, R>(a.z, d.z, s, rcp_s, o, oi, qmin, qmax, rounding, &g.z);
-            acc += lsq_bwd_elem<true, R>(a.w, d.w, s, rcp_s, o, oi, qmin, qmax, rounding, &g.w);
-            gv[v] = g;
+        // U (x, dy) load pairs in flight per lane: a 56 x 56 row (784 float4) is ONE trip of 4, all 8 loads issued up front
+        // (one pair per dependent trip kept this kernel at 0.68 of the roofline on [32, 512, 56, 56])
+        constexpr int U = PPQHIP_LSQ_C_U;
+        const uint32_t v1 = hi >> 2;
+        for (uint32_t v = (lo >> 2) + threadIdx.x; v < v1; v += kBlock * U) {
+            float4 a[U], d[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                const uint32_t at = min(v + u * kBlock, v1 - 1);          // clamped: loads stay unconditional
+                a[u] = xv[at]; d[u] = dv[at];
+            }
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                if (v + u * kBlock >= v1) break;
+                float4 g;
+                acc += lsq_bwd_elem<true, R>(a[u].x, d[u].x, s, rcp_s, o, oi, qmin, qmax, rounding, &g.x);
+                acc += lsq_bwd_elem<true, R>(a[u].y, d[u].y, s, rcp_s, o, oi, qmin, qmax, rounding, &g.y);
+                acc += lsq_bwd_elem<true, R>(a[u].z, d[u].z, s, rcp_s, o, oi, qmin, qmax, rounding, &g.z);
+                acc += lsq_bwd_elem<true, R>(a[u].w, d[u].w, s, rcp_s, o, oi, qmin, qmax, rounding, &g.w);
+                gv[v + u * kBlock] = g;
+            }
         }
     } else {
         for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
@@ -644,8 +660,10 @@ int ppqhip_fq_linear_t_bwd(const float* x, const float* scale, const float* offs
     // rsqrtf(((double)n * (clip_max - clip_min))): linear.cu:299
     const float grad_factor = (float)(1.0 / sqrt((double)n * (double)(clip_max - clip_min)));
     // one tile per workgroup while that keeps the grid below PPQHIP_LSQ_MAX_WG: tens of thousands of short
-    // workgroups stream better than a chip-sized persistent grid here (same finding as the forward tile kernels;
-    // lsq_bwd_c, which has always been tiled by rows, ran 10 % faster than the persistent form of this kernel)
+    // workgroups stream better than a chip-sized persistent grid for this 2-reads + 1-write pattern (same finding as
+    // the forward tile kernels).  Measured again in round 3 with ping-pong register tiles and the partial sum folded into
+    // the launch (last workgroup, sharded tickets): 512 x 2 / CU 120 us, 512 x 4 122, 256 x 8 125, U = 4 124 -- against
+    // 107 us for this kernel + its finish launch (profiles/r03_lsq_variants.txt)
     const int grid = stream_grid(n, kBlock * 4 * PPQHIP_LSQ_U, PPQHIP_LSQ_MAX_WG);
     float* partial = (float*)scratch(s, sizeof(float) * (size_t)grid);
     if (partial == nullptr) return PPQHIP_ERR_HIP;
