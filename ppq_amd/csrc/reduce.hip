@@ -187,10 +187,14 @@ __global__ __launch_bounds__(kBlock) void minmax_finish_kernel(const float* __re
 // row group g = i / C, chunk) -> the wave reduces `K` rows of its channel (rows g*K .. of stride C) or one 8192-element
 // chunk of one row, with U 16-B loads in flight per lane, folds across its 64 lanes with shuffles and commits ONE pair of
 // atomics.  (Round 2's workgroup-per-row kernel spent a barrier, an LDS round trip and two atomics on every 12.5 KB row
-// of a [32, 512, 56, 56] activation and kept one load per lane in flight: 0.68 of the roofline, this one 0.72; predicated
-// instead of clamped loads, U = 4 / 16: within 1 us of each other, profiles/r03_minmax_c_variants.txt.)
+// of a [32, 512, 56, 56] activation and kept one load per lane in flight: 0.68 of the roofline, this one 0.73.  Sweep in
+// profiles/r03_minmax_c_variants.txt: U = 4 / 8 / 16, 8 .. 64 waves per CU, predicated instead of clamped loads -- all within
+// 35.1 .. 37.2 us; shipped: U = 16 (a 56 x 56 row is one trip) and >= 16 waves per CU.)
 #ifndef PPQHIP_MMC_U
-#define PPQHIP_MMC_U 8
+#define PPQHIP_MMC_U 16
+#endif
+#ifndef PPQHIP_MMC_WPC
+#define PPQHIP_MMC_WPC 16            // waves per CU a launch should at least have before a wave takes several rows
 #endif
 constexpr int kMMCU = PPQHIP_MMC_U;
 constexpr uint32_t kMMCChunk = 8192;            // elements per chunk of a long row
@@ -501,7 +505,7 @@ int ppqhip_minmax_c(const float* x, int64_t n, int64_t num_channel, int64_t elem
         // short rows: K rows of a channel per wave while that leaves the chip >= 32 waves per CU
         uint32_t K = 1;
         if (chunks == 1) {
-            K = (uint32_t)(rows / (kNumCU * 32));
+            K = (uint32_t)(rows / (kNumCU * PPQHIP_MMC_WPC));
             const uint32_t k_bytes = (uint32_t)(65536 / (elem_per_channel * 4));       // <= 64 KB per wave
             if (K > k_bytes) K = k_bytes;
             if (K > outer) K = outer;
