@@ -214,7 +214,11 @@ def collect_prof():
 DEVICE_KERNELS = {'hist_sym_t': ('ppqhip::hist_persistent_kernel<false',), 'hist_asym_t': ('ppqhip::hist_persistent_kernel<true',),
                   'minmax_t': ('ppqhip::minmax_persistent_kernel', 'ppqhip::minmax_t_kernel'),
                   'fq_linear_c': ('ppqhip::fq_linear_multi_kernel', 'ppqhip::fq_linear_c_tile_kernel'),
-                  'fq_linear_t': ('ppqhip::fq_linear_t_tile_kernel',)}
+                  'fq_linear_t': ('ppqhip::fq_linear_t_tile_kernel',),
+                  # a quantile_t "launch" is one 7-kernel sequence: bytes of ALL its kernels (init zeroes 84 KB per job, the
+                  # filter reads the tensors, select A reads the lists ..) per filter launch (one per sequence)
+                  'quantile_t': ('ppqhip::quantile_',)}
+LAUNCHES_COUNTED_ON = {'quantile_t': 'ppqhip::quantile_filter_kernel'}
 
 
 def pmc_traffic(kernel_name: str, child_args: list, timeout_s: float = 240.0):
@@ -242,9 +246,12 @@ def pmc_traffic(kernel_name: str, child_args: list, timeout_s: float = 240.0):
             files = glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True)
             if not files: return None, f'{counter} pass wrote no counter_collection.csv'
             tot = n = 0
+            counted_on = LAUNCHES_COUNTED_ON.get(kernel_name)
             for r in csv.DictReader(open(files[0])):
-                if r['Counter_Name'] == counter and r['Kernel_Name'].replace('void ', '').startswith(prefixes):
-                    tot += float(r['Counter_Value']); n += 1
+                name = r['Kernel_Name'].replace('void ', '')
+                if r['Counter_Name'] == counter and name.startswith(prefixes):
+                    tot += float(r['Counter_Value'])
+                    if counted_on is None or name.startswith(counted_on): n += 1
             if n == 0: return None, f'{counter}: kernel not found in the trace'
             per_launch[counter] = tot / n * 1024.0        # the counters report KB
     finally:
