@@ -81,8 +81,8 @@ def merge_observers(observers: Sequence, group=None, even_if_single_rank: bool =
     # int32 histograms (the reference's counter type, sort.cu:91-165): world_size ranks x the largest count any of them
     # holds bounds every merged bin -- below 2^31 the int32 SUM cannot wrap; otherwise the buffers are summed in int64 and
     # a bin that really passes 2^31 raises instead of wrapping silently (the reference wraps in one process, too)
-    i32 = sums.get(torch.int32) or []
-    largest = max((int(b.max()) for b in i32 if b.numel()), default=0)
+    i32 = [b for b in (sums.get(torch.int32) or []) if b.numel()]
+    largest = int(torch.stack([b.max() for b in i32]).max()) if i32 else 0          # one device -> host copy
     largest = _check_layout(dist, lengths, device, group, largest)
     widen_i32 = largest * dist.get_world_size(group) >= 2 ** 31
     issued = 0
