@@ -403,6 +403,10 @@ def workload_variants(args):
                         'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'child_wall_s': round(time.perf_counter() - t0, 1),
                         'roofline': {k: roof.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'launches', 'avg_launch_us',
                                                               'algorithmic_bytes_per_launch')}})
+            if name == 'yolov6s_int4_lsq':      # per-block tensors of 0.05 .. 6 MB: every launch is latency-, not bandwidth-bound
+                out[-1]['roofline']['note'] = ('block-wise finetuning launches the LSQ backward on one small weight / activation at a time '
+                                               '(average 7 us per launch); the same kernels on [32,512,56,56]: 0.69-0.72 of 8 TB/s '
+                                               '(profiles/r03_microbench_randn.txt)')
         except Exception as e:
             out.append({'workload': name, 'error': f'{type(e).__name__}: {e}'})
     return out
