@@ -1247,7 +1247,9 @@ int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, uint32_t*
 int64_t ppqhip_quantile_multi_workspace_bytes(int num_jobs, int64_t total_elems) {
     // sequence prefix + fixed part per job + the filter lists: sum over jobs of 2 * clamp(n / 128, 16384, 2^20) keys (+ rounding)
     if (num_jobs <= 0) return 0;
-    return (int64_t)kQPrefBytes + ((int64_t)num_jobs * (kQWords + 2 * 16384 + 64) + 2 * ((total_elems > 0 ? total_elems : 0) / 128)) * 4;
+    int64_t lists = (total_elems > 0 ? total_elems : 0) / 128;            // sum of n / 128 <= total / 128 ..
+    if (lists > (int64_t)num_jobs << 20) lists = (int64_t)num_jobs << 20;       // .. and every list is capped at 2^20 keys
+    return (int64_t)kQPrefBytes + ((int64_t)num_jobs * (kQWords + 2 * 16384 + 64) + 2 * lists) * 4;
 }
 
 void ppqhip_quantile_debug_layout(int64_t* out) {

@@ -652,3 +652,25 @@ def test_drop_in_quantile_hint_is_per_calling_object():
     inside = short_lived()
     gc.collect()
     assert len(ffi._owner_hints) == inside - 1     # the collected observer took its hints with it
+
+
+def test_quantile_workspace_sizing_covers_the_layout():
+    """ppqhip_quantile_multi_workspace_bytes (a host function) must cover what a launch sequence lays out: the prefix (header,
+    prefix arrays, device job table), one record per job and two filter lists per job of clamp(n / 128, 16384, 2^20) keys
+    rounded up to 32 -- for any mix of sizes, including > 1024 jobs (several sequences share the prefix)."""
+    import ctypes
+    from ppq_amd import _lib
+    lay = (ctypes.c_int64 * 8)()
+    _lib.lib.ppqhip_quantile_debug_layout(lay)
+    prefix, words = int(lay[0]), int(lay[1])
+
+    def cap(n): return (min(max(n // 128, 16384), 1 << 20) + 31) // 32 * 32
+    rng = np.random.default_rng(0)
+    for jobs in ([1], [4096], [1605632], [51380224], [2 ** 31 - 1], list(rng.integers(1, 3_000_000, 72)), [300] * 1100 + [10 ** 6],
+                 list(rng.integers(1, 200_000_000, 5))):
+        need = prefix + sum(words + 2 * cap(int(n)) for n in jobs) * 4
+        got = int(_lib.lib.ppqhip_quantile_multi_workspace_bytes(len(jobs), int(sum(int(n) for n in jobs))))
+        assert got >= need, (len(jobs), got, need)
+        assert got <= 2 * need + (1 << 20)                                                     # and is not wildly larger
+    for n in (1, 1605632, 2 ** 31 - 1):
+        assert int(_lib.lib.ppqhip_quantile_workspace_bytes(n)) >= prefix + (words + 2 * cap(n)) * 4 >= 65536   # (isotone's partials fit too)
