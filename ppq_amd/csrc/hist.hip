@@ -363,6 +363,84 @@ __global__ __launch_bounds__(kBlock) void hist_c_row_kernel(const float* __restr
     }
 }
 
+// per channel, round 3: ONE workgroup per (channel, row split) instead of one per row.  hist_c_row_kernel above zeroes,
+// fills and flushes an LDS histogram for every 12.5 KB row of a [32, 512, 56, 56] activation -- 16384 workgroups, 13 M
+// device atomics, 4-B loads: 98.9 us = 0.26 of the roofline.  Here a workgroup owns its channel: it streams the channel's
+// rows (stride C * epc) as one virtual float4 range with the persistent kernel's machinery (two ping-pong register tiles,
+// packed-f32 binning, EXEC-mask LDS commits, hot bin) and adds its histogram to the channel's row of `hist` ONCE -- with
+// plain read-modify-writes when it is the channel's only workgroup (splits == 1: no atomics at all).
+#ifndef PPQHIP_HIST_C_WGPC
+#define PPQHIP_HIST_C_WGPC 1             // workgroups per CU a launch should have before channels stop being split
+#endif
+template <bool ASYM, bool CLIP>
+__global__ __launch_bounds__(kHistBlock, (kHistBlock * kHistWgPerCu + 255) / 256)
+void hist_c_channel_kernel(const float* __restrict__ x, FastDiv vec_per_row, uint32_t C, uint32_t outer, uint32_t splits,
+                           BinRule rule, int copies, int* __restrict__ hist, const float* __restrict__ scales,
+                           const float* __restrict__ mins, const float* __restrict__ maxs) {
+    extern __shared__ int lds[];
+    const int bins = rule.bins;
+    for (int i = threadIdx.x; i < copies * bins; i += kHistBlock) lds[i] = 0;
+    __syncthreads();
+    const uint32_t c = blockIdx.x % C, sp = blockIdx.x / C;
+    const uint32_t vpr = vec_per_row.d;
+    // the channel's rows as ONE virtual float4 range [0, outer * vpr); split `sp` owns [v0, v0 + V) of it
+    const uint32_t all = outer * vpr;
+    const uint32_t v0 = (uint32_t)(((uint64_t)sp * all) / splits);
+    const uint32_t V = (uint32_t)(((uint64_t)(sp + 1) * all) / splits) - v0;
+    Binner<ASYM, CLIP, true> acc;
+    acc.init(lds + ((threadIdx.x >> 6) % copies) * bins, bins);
+    if (ASYM) acc.set_rule(mins[c], (maxs[c] - mins[c]) / (float)bins);      // per-channel range (hist_scale as in sort.cu:123)
+    else acc.set_rule(0.f, scales != nullptr ? scales[c] : rule.hs);        // per-channel hist_scale
+    const float4* xc = reinterpret_cast<const float4*>(x) + (size_t)c * vpr;
+    const size_t row_stride = (size_t)C * vpr;
+    auto at = [&](uint32_t v) -> const float4* {                           // index inside this split -> address (v < V)
+        const uint32_t r = fdiv(v0 + v, vec_per_row);
+        return xc + (size_t)r * row_stride + (v0 + v - r * vpr);
+    };
+    const uint32_t tiles = V / kTileVec;                                   // full tiles: every lane has a float4
+    if (tiles > 0) {
+        float4 bufa[kHistU], bufb[kHistU];
+        auto fetch = [&](float4 (&buf)[kHistU], uint32_t tile) {
+#pragma unroll
+            for (int u = 0; u < kHistU; u++) buf[u] = *at(tile * kTileVec + u * kHistBlock + threadIdx.x);
+        };
+        auto consume = [&](const float4 (&buf)[kHistU]) {
+#pragma unroll
+            for (int u = 0; u < kHistU; u++) {
+                int b[4];
+                acc.bins4(buf[u], b);
+                if (u == 0) acc.elect(b[0], true);
+                if (CLIP) acc.commit4_exec(b);
+                else {
+                    acc.template commit<true>(b[0], true); acc.template commit<true>(b[1], true);
+                    acc.template commit<true>(b[2], true); acc.template commit<true>(b[3], true);
+                }
+            }
+        };
+        uint32_t k = 0;
+        fetch(bufa, k);
+        for (;;) {
+            fetch(bufb, min(k + 1, tiles - 1));
+            consume(bufa);
+            if (++k >= tiles) break;
+            fetch(bufa, min(k + 1, tiles - 1));
+            consume(bufb);
+            if (++k >= tiles) break;
+        }
+    }
+    for (uint32_t v = tiles * kTileVec + threadIdx.x, t = 0; t < kHistU; t++, v += kHistBlock) {   // the ragged rest (< one tile)
+        const bool in = v < V;                                             // wave-uniform trip count, masked lanes
+        const float4 a = in ? *at(v) : make_float4(0.f, 0.f, 0.f, 0.f);
+        int b[4];
+        acc.bins4(a, b);
+        acc.elect(b[0], in);
+        acc.template commit<false>(b[0], in); acc.template commit<false>(b[1], in);
+        acc.template commit<false>(b[2], in); acc.template commit<false>(b[3], in);
+    }
+    acc.flush_hot();
+    lds_hist_flush(lds, bins, copies, hist + (size_t)c * bins, splits == 1 ? FLUSH_ROWS_ADD : FLUSH_ATOMIC);
+}
+
 __global__ __launch_bounds__(kBlock) void hist_c_global_kernel(const float* __restrict__ x, uint32_t n,
                                                                FastDiv elem_per_channel, FastDiv num_channel,
                                                                BinRule rule, int* __restrict__ hist,
@@ -589,7 +667,25 @@ static int hist_c_impl(const float* x, int64_t n, int64_t num_channel, int64_t e
     LaunchScope scope(K_HIST_SYM_C, 4.0 * (double)n, s);
     BinRule rule = make_rule(0.f, hist_scale, (int)num_bins, clip_outliers ? 1 : 0, asym);
     const FastDiv nc = make_fastdiv((uint32_t)num_channel);
-    if (elem_per_channel >= 1024 && num_bins <= kMaxLdsBins) {
+    if (elem_per_channel % 4 == 0 && elem_per_channel >= 64 && aligned16(x) && num_bins <= kMaxLdsBins) {
+        const uint32_t C = (uint32_t)num_channel, outer = (uint32_t)(n / (num_channel * elem_per_channel));
+        // one workgroup per channel; channels are split over row ranges only while that is what fills the chip
+        const uint32_t want_wgs = (uint32_t)kNumCU * PPQHIP_HIST_C_WGPC;
+        uint32_t splits = C >= want_wgs ? 1u : (want_wgs + C - 1) / C;
+        const uint64_t tiles_per_channel = ((uint64_t)outer * (uint64_t)(elem_per_channel / 4)) / kTileVec;      // a split should have >= 1 full tile
+        if (splits > tiles_per_channel) splits = tiles_per_channel > 0 ? (uint32_t)tiles_per_channel : 1u;
+        const int copies = pick_copies(rule.bins, kHistBlock);
+#define PPQ_LAUNCH_HIST_CC(A, CL)                                                                                     \
+        hipLaunchKernelGGL((hist_c_channel_kernel<A, CL>), dim3(C * splits), dim3(kHistBlock), lds_bytes(rule.bins, copies), s, x, \
+                           make_fastdiv((uint32_t)(elem_per_channel / 4)), C, outer, splits, rule, copies, hist, scales, mins, maxs)
+        switch ((asym ? 2 : 0) | (rule.clip ? 1 : 0)) {
+            case 0: PPQ_LAUNCH_HIST_CC(false, false); break;
+            case 1: PPQ_LAUNCH_HIST_CC(false, true); break;
+            case 2: PPQ_LAUNCH_HIST_CC(true, false); break;
+            default: PPQ_LAUNCH_HIST_CC(true, true); break;
+        }
+#undef PPQ_LAUNCH_HIST_CC
+    } else if (elem_per_channel >= 1024 && num_bins <= kMaxLdsBins) {
         const int copies = pick_copies(rule.bins, kBlock);
         const uint32_t chunk_elems = 16384;
         const uint32_t chunks = (uint32_t)((elem_per_channel + chunk_elems - 1) / chunk_elems);

@@ -70,6 +70,7 @@ def main():
         gs1 = torch.zeros(1, device=dev); gsc = torch.zeros(C, device=dev)
         hist = torch.zeros(args.bins, dtype=torch.int32, device=dev)
         rowsbuf = torch.zeros(CUDA.hist_rows(), args.bins, dtype=torch.int32, device=dev)
+        hist_c = torch.zeros(C, args.bins, dtype=torch.int32, device=dev)
         slots = torch.tensor([float('inf'), float('-inf')], device=dev).repeat(CUDA.minmax_slots(), 1).contiguous()
         mins = torch.full([C], float('inf'), device=dev); maxs = torch.full([C], float('-inf'), device=dev)
         hs = float(xs[0].abs().max()) / args.bins
@@ -105,6 +106,7 @@ def main():
             'fq_linear_t': (8, fq_t), 'fq_linear_c': (8, fq_c), 'fq_float_t (E4M3, s=2^-5)': (8, fq_f), 'fq_float_t (generic s)': (8, fq_f_generic),
             'hist_sym_t (one-shot)': (4, lambda: lib.ppqhip_hist_sym_t(P(xs[nxt()]), n, hs, 1, P(hist), args.bins, P(ws), stream())),
             'hist_sym_t (rows)': (4, lambda: lib.ppqhip_hist_sym_t_rows(P(xs[nxt()]), n, hs, 1, P(rowsbuf), args.bins, stream())),
+            'hist_sym_c (per channel)': (4, lambda: lib.ppqhip_hist_sym_c(P(xs[nxt()]), n, C, epc, hs, 1, P(hist_c), args.bins, stream())),
             'minmax_t (slots)': (4, lambda: lib.ppqhip_minmax_t_slots(P(xs[nxt()]), n, P(slots), stream())),
             'minmax_c': (4, lambda: lib.ppqhip_minmax_c(P(xs[nxt()]), n, C, epc, P(mins), P(maxs), stream())),
             'quantile_t (hinted)': (4, lambda: CUDA.Quantile_Hinted(xs[nxt()], 0.9999, qhint)),   # an observer's call: thresholds of the previous batch
