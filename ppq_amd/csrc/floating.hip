@@ -210,27 +210,131 @@ __global__ __launch_bounds__(kBlock) void fq_float_c_tile_kernel(
 }
 
 // QuantizeTensor_FT_B / _FC_B, floating.cu:133-331: STE + scale gradient with +-1 sentinel clip.
-// The reference adds every block-partial divided by sqrtf((float)(n * clip_max)).
-__global__ __launch_bounds__(kBlock) void fq_float_bwd_kernel(
+// The reference adds every block-partial divided by sqrtf((float)(n * clip_max)) with one atomic per block; here the
+// tensor is cut into (row, chunk) workgroups of one channel each -- rows of elem_per_channel contiguous elements, chunks of
+// 4096 -- that leave ONE partial sum per workgroup, and a second launch adds a channel's partials in a fixed order and
+// divides once (deterministic; the first version issued one device atomic PER ELEMENT: 44 ms for [32, 512, 56, 56]).
+__device__ __forceinline__ float fq_float_bwd_elem(float v, float d, float s, float inv_s, float o, float cmin, float cmax,
+                                                   const FloatFmt& fmt_wide, float clip_min, float clip_max, int rounding,
+                                                   float* gx) {
+    const float qt = quant_float_scalar<-1>(v, s, fmt_wide, rounding);
+    const float q = (qt - o) * s;
+    if (qt == clip_max + 1) { *gx = 0.f; return cmax * d * inv_s; }
+    if (qt == clip_min - 1) { *gx = 0.f; return cmin * d * inv_s; }
+    *gx = d;
+    return (q - v) * inv_s * d;
+}
+
+constexpr uint32_t kFloatBwdChunk = 4096;      // elements per workgroup
+__global__ __launch_bounds__(kBlock) void fq_float_bwd_row_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
-    const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ gs, uint32_t n,
-    FastDiv elem_per_channel, FastDiv num_channel, FloatFmt fmt_wide, float clip_min, float clip_max,
-    float denom, int rounding) {
+    const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ partial, uint32_t epc, int vec_ok,
+    FastDiv chunks, FastDiv num_channel, FloatFmt fmt_wide, float clip_min, float clip_max, int rounding) {
+    __shared__ float lds[kBlock / kWave];
+    const uint32_t row = fdiv(blockIdx.x, chunks);
+    const uint32_t chunk = blockIdx.x - row * chunks.d;
+    const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
+    const float s = scale[c], inv_s = 1 / s, o = offset[c];
+    const float cmin = s * (clip_min - o), cmax = s * (clip_max - o);
+    const uint32_t lo = chunk * kFloatBwdChunk, hi = min(lo + kFloatBwdChunk, epc);
+    const size_t base = (size_t)row * epc;
+    float acc = 0.f;
+    if (vec_ok) {                                  // epc % 4 == 0, 16-B aligned bases: 4 (x, dy) load pairs in flight per lane
+        const float4* xv = reinterpret_cast<const float4*>(x + base);
+        const float4* dv = reinterpret_cast<const float4*>(dy + base);
+        float4* gv = reinterpret_cast<float4*>(gx + base);
+        const uint32_t v1 = hi >> 2;
+        for (uint32_t v = (lo >> 2) + threadIdx.x; v < v1; v += kBlock * 4) {
+            float4 a[4], d[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t at = min(v + u * kBlock, v1 - 1); a[u] = xv[at]; d[u] = dv[at]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (v + u * kBlock >= v1) break;
+                float4 g;
+                acc += fq_float_bwd_elem(a[u].x, d[u].x, s, inv_s, o, cmin, cmax, fmt_wide, clip_min, clip_max, rounding, &g.x);
+                acc += fq_float_bwd_elem(a[u].y, d[u].y, s, inv_s, o, cmin, cmax, fmt_wide, clip_min, clip_max, rounding, &g.y);
+                acc += fq_float_bwd_elem(a[u].z, d[u].z, s, inv_s, o, cmin, cmax, fmt_wide, clip_min, clip_max, rounding, &g.z);
+                acc += fq_float_bwd_elem(a[u].w, d[u].w, s, inv_s, o, cmin, cmax, fmt_wide, clip_min, clip_max, rounding, &g.w);
+                gv[v + u * kBlock] = g;
+            }
+        }
+    } else {
+        for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
+            float g;
+            acc += fq_float_bwd_elem(x[base + j], dy[base + j], s, inv_s, o, cmin, cmax, fmt_wide, clip_min, clip_max, rounding, &g);
+            gx[base + j] = g;
+        }
+    }
+    acc = wave_sum(acc);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) lds[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < kBlock / kWave; w++) t += lds[w];
+        partial[blockIdx.x] = t;
+    }
+}
+
+// short rows (elem_per_channel < 64: [N, C] matrices, channel-last views): grid-stride over elements, per-channel sums in
+// LDS (num_channel <= 8192) or straight global atomics, one flush per workgroup
+__global__ __launch_bounds__(kBlock) void fq_float_bwd_generic_kernel(
+    const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
+    const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ gs, uint32_t n, FastDiv elem_per_channel,
+    FastDiv num_channel, int use_lds, FloatFmt fmt_wide, float clip_min, float clip_max, float denom, int rounding) {
+    extern __shared__ float acc_lds[];
+    const uint32_t C = num_channel.d;
+    if (use_lds) {
+        for (uint32_t c = threadIdx.x; c < C; c += kBlock) acc_lds[c] = 0.f;
+        __syncthreads();
+    }
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += stride) {
         const uint32_t row = fdiv(i, elem_per_channel);
-        const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
+        const uint32_t c = row - fdiv(row, num_channel) * C;
         const float s = scale[c], inv_s = 1 / s, o = offset[c];
-        const float cmin = s * (clip_min - o), cmax = s * (clip_max - o);
-        const float v = x[i], d = dy[i];
-        const float qt = quant_float_scalar<-1>(v, s, fmt_wide, rounding);
-        const float q = (qt - o) * s;
-        float p;
-        if (qt == clip_max + 1) { p = cmax * d * inv_s; gx[i] = 0.f; }
-        else if (qt == clip_min - 1) { p = cmin * d * inv_s; gx[i] = 0.f; }
-        else { p = (q - v) * inv_s * d; gx[i] = d; }
-        // no caller in ppq: one global atomic per element is acceptable here
-        atomicAdd(&gs[c], p / denom);
+        float g;
+        const float p = fq_float_bwd_elem(x[i], dy[i], s, inv_s, o, s * (clip_min - o), s * (clip_max - o), fmt_wide, clip_min,
+                                          clip_max, rounding, &g);
+        gx[i] = g;
+        if (use_lds) atomicAdd(&acc_lds[c], p);
+        else atomicAdd(&gs[c], p / denom);
+    }
+    if (use_lds) {
+        __syncthreads();
+        for (uint32_t c = threadIdx.x; c < C; c += kBlock) {
+            const float v = acc_lds[c];
+            if (v != 0.f) atomicAdd(&gs[c], v / denom);
+        }
+    }
+}
+
+// grad_s[c] = (sum of the partials of channel c: rows c, c + C, .. x their chunks, in index order) / denom
+__global__ __launch_bounds__(kBlock) void fq_float_bwd_finish_kernel(const float* __restrict__ partial, uint32_t rows, uint32_t chunks,
+                                                                     uint32_t C, float denom, float* __restrict__ gs) {
+    __shared__ double lds[kBlock / kWave];
+    const uint32_t c = blockIdx.x;
+    const uint32_t per_channel = (rows / C) * chunks;                 // partials of this channel
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < per_channel; i += 8 * kBlock) {          // 8 loads in flight per lane
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const uint32_t at = i + u * kBlock, r = at / chunks, k = at - r * chunks;
+            v[u] = at < per_channel ? partial[(size_t)(r * C + c) * chunks + k] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += (double)v[u];
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kBlock / kWave; w++) t += lds[w];
+        gs[c] = (float)t / denom;
     }
 }
 
@@ -599,12 +703,27 @@ int ppqhip_fq_float_c_bwd(const float* x, const float* scale, const float* offse
     if (int st = make_fmt(exponent, mantissa, clip_min - 1, clip_max + 1, &fmt, "fq_float_c_bwd")) return st;
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_FQ_FLOAT_BWD, 12.0 * (double)n, s);
-    if (int st = check_hip(hipMemsetAsync(grad_s, 0, sizeof(float) * (size_t)num_channel, s), "memset grad_s"))
-        return st;
     const float denom = sqrtf((float)((float)n * clip_max));
-    hipLaunchKernelGGL(fq_float_bwd_kernel, dim3(stream_grid(n, kBlock * 4, kNumCU * 4)), dim3(kBlock), 0, s, x,
-                       scale, offset, grad_y, grad_x, grad_s, (uint32_t)n, make_fastdiv((uint32_t)elem_per_channel),
-                       make_fastdiv((uint32_t)num_channel), fmt, clip_min, clip_max, denom, rounding);
+    if (elem_per_channel < 64) {
+        if (int st = check_hip(hipMemsetAsync(grad_s, 0, sizeof(float) * (size_t)num_channel, s), "memset grad_s")) return st;
+        const int use_lds = num_channel <= 8192;
+        hipLaunchKernelGGL(fq_float_bwd_generic_kernel, dim3(stream_grid(n, kBlock * 8, kNumCU * 2)), dim3(kBlock),
+                           use_lds ? sizeof(float) * (size_t)num_channel : 0, s, x, scale, offset, grad_y, grad_x, grad_s, (uint32_t)n,
+                           make_fastdiv((uint32_t)elem_per_channel), make_fastdiv((uint32_t)num_channel), use_lds, fmt, clip_min,
+                           clip_max, denom, rounding);
+        return finish_launch("fq_float_c_bwd");
+    }
+    const uint32_t chunks = (uint32_t)((elem_per_channel + kFloatBwdChunk - 1) / kFloatBwdChunk);
+    const int64_t rows = n / elem_per_channel;
+    if (rows * chunks > 0x7fffffffLL) { set_error("fq_float_c_bwd: too many rows"); return PPQHIP_ERR_INVALID_VALUE; }
+    float* partial = (float*)scratch(s, sizeof(float) * (size_t)(rows * chunks));
+    if (partial == nullptr) return PPQHIP_ERR_HIP;
+    const int vec_ok = (elem_per_channel % 4 == 0 && aligned16(x) && aligned16(grad_y) && aligned16(grad_x)) ? 1 : 0;
+    hipLaunchKernelGGL(fq_float_bwd_row_kernel, dim3((uint32_t)(rows * chunks)), dim3(kBlock), 0, s, x, scale, offset, grad_y,
+                       grad_x, partial, (uint32_t)elem_per_channel, vec_ok, make_fastdiv(chunks),
+                       make_fastdiv((uint32_t)num_channel), fmt, clip_min, clip_max, rounding);
+    hipLaunchKernelGGL(fq_float_bwd_finish_kernel, dim3((uint32_t)num_channel), dim3(kBlock), 0, s, (const float*)partial,
+                       (uint32_t)rows, chunks, (uint32_t)num_channel, denom, grad_s);
     return finish_launch("fq_float_c_bwd");
 }
 

@@ -285,9 +285,14 @@ __global__ __launch_bounds__(kBlock) void channel_sum_row_kernel(const float* __
         const float* xr = x + ((size_t)n * C + c) * epc;
         if (vec_ok) {
             const float4* xv = reinterpret_cast<const float4*>(xr);
-            for (uint32_t v = threadIdx.x; v < (epc >> 2); v += kBlock) {
-                const float4 a = xv[v];
-                acc += ((double)a.x + (double)a.y) + ((double)a.z + (double)a.w);
+            const uint32_t v1 = epc >> 2;
+            for (uint32_t v = threadIdx.x; v < v1; v += 4 * kBlock) {          // 4 loads in flight per lane (a 56 x 56 row: one trip)
+                float4 a[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) a[u] = xv[min(v + u * kBlock, v1 - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (v + u * kBlock < v1) acc += ((double)a[u].x + (double)a[u].y) + ((double)a[u].z + (double)a[u].w);
             }
         } else {
             for (uint32_t j = threadIdx.x; j < epc; j += kBlock) acc += (double)xr[j];

@@ -77,6 +77,9 @@ def main():
         ws = torch.empty(int(lib.ppqhip_hist_workspace_bytes(n, args.bins)) + 64, dtype=torch.uint8, device=dev)
 
         def P(t): return t.data_ptr()
+        scp2 = torch.full([C], 2.0 ** -5, device=dev); ocz = torch.zeros(C, device=dev)
+        iso4 = torch.zeros(4, device=dev); csum = torch.zeros(C, dtype=torch.float64, device=dev)
+        qws = torch.empty(int(lib.ppqhip_quantile_workspace_bytes(n)) + 64, dtype=torch.uint8, device=dev)
         from ppq_amd.ffi import quantile_hint
         qhint = quantile_hint(torch.device(dev))
 
@@ -112,6 +115,12 @@ def main():
             'quantile_t (hinted)': (4, lambda: CUDA.Quantile_Hinted(xs[nxt()], 0.9999, qhint)),   # an observer's call: thresholds of the previous batch
             'quantile_t (cold)': (4, lambda: CUDA.Quantile_Hinted(xs[nxt()], 0.9999, None)),      # every call samples its thresholds
             'lsq_bwd_t': (12, bwd_t), 'lsq_bwd_c': (12, bwd_c),
+            'fq_float_c (E4M3, per channel)': (8, lambda: lib.ppqhip_fq_float_c(P(xs[nxt()]), P(scp2), P(ocz), P(outs[nxt()]), n, C, epc, 4, 3, -448.0, 448.0, 0, stream())),
+            'fq_float_c_bwd': (12, lambda: lib.ppqhip_fq_float_c_bwd(P(xs[nxt()]), P(scp2), P(ocz), P(dys[nxt()]), P(outs[nxt()]), P(gsc), n, C, epc, 4, 3, -448.0, 448.0, 0, stream())),
+            'to_int_t (int8 out)': (5, lambda: lib.ppqhip_to_int_t(P(xs[nxt()]), P(s1), P(o1), P(outs[nxt()]), n, -128, 127, 0, 0, stream())),
+            'to_int_c (int32 out)': (8, lambda: lib.ppqhip_to_int_c(P(xs[nxt()]), P(sc), P(oc), P(outs[nxt()]), n, C, epc, -32768, 32767, 0, 2, stream())),
+            'isotone_t': (4, lambda: lib.ppqhip_isotone_t(P(xs[nxt()]), n, P(iso4), P(qws), stream())),
+            'channel_sum': (4, lambda: lib.ppqhip_channel_sum(P(xs[nxt()]), n, C, epc, P(csum), stream())),
             'torch out.copy_(x) (ref)': (8, copy),
             'torch abs().max() (ref)': (4, lambda: xs[nxt()].abs().max()),
         }
