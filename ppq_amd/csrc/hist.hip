@@ -322,50 +322,10 @@ __global__ __launch_bounds__(kBlock) void hist_t_global_kernel(const float* __re
     }
 }
 
-// per channel, long rows: workgroup = (row, chunk); one channel per workgroup -> LDS histogram
-// (scales: one hist_scale per channel; mins / maxs: one asymmetric range per channel, hist_scale =
-//  (max - min) / bins as in sort.cu:123)
-template <bool ASYM, bool CLIP>
-__global__ __launch_bounds__(kBlock) void hist_c_row_kernel(const float* __restrict__ x, uint32_t epc, FastDiv chunks,
-                                                            FastDiv num_channel, uint32_t chunk_elems, BinRule rule,
-                                                            int copies, int* __restrict__ hist,
-                                                            const float* __restrict__ scales,
-                                                            const float* __restrict__ mins,
-                                                            const float* __restrict__ maxs) {
-    extern __shared__ int lds[];
-    for (int i = threadIdx.x; i < copies * rule.bins; i += kBlock) lds[i] = 0;
-    __syncthreads();
-    const uint32_t row = fdiv(blockIdx.x, chunks);
-    const uint32_t chunk = blockIdx.x - row * chunks.d;
-    const uint32_t c = row - fdiv(row, num_channel) * num_channel.d;
-    Binner<ASYM, CLIP, true> acc;
-    acc.init(lds + ((threadIdx.x >> 6) % copies) * rule.bins, rule.bins);
-    if (ASYM) acc.set_rule(mins[c], (maxs[c] - mins[c]) / (float)rule.bins);      // per-channel range
-    else acc.set_rule(0.f, scales != nullptr ? scales[c] : rule.hs);              // per-channel hist_scale
-    const uint32_t lo = chunk * chunk_elems;
-    const uint32_t hi = min(lo + chunk_elems, epc);
-    const float* xr = x + (size_t)row * epc;
-    const uint32_t trips = (hi - lo + kBlock - 1) / kBlock;
-    uint32_t j = lo + threadIdx.x;
-    for (uint32_t t = 0; t < trips; t++, j += kBlock) {
-        const bool in = j < hi;
-        const int b = acc.bin1(in ? xr[j] : 0.f);
-        if ((t & 15u) == 0) acc.elect(b, in);
-        acc.template commit<false>(b, in);
-    }
-    acc.flush_hot();
-    __syncthreads();
-    int* dst = hist + (size_t)c * rule.bins;
-    for (int b = threadIdx.x; b < rule.bins; b += kBlock) {
-        int sum = 0;
-        for (int k = 0; k < copies; k++) sum += lds[k * rule.bins + b];
-        if (sum) atomicAdd(&dst[b], sum);
-    }
-}
-
-// per channel, round 3: ONE workgroup per (channel, row split) instead of one per row.  hist_c_row_kernel above zeroes,
-// fills and flushes an LDS histogram for every 12.5 KB row of a [32, 512, 56, 56] activation -- 16384 workgroups, 13 M
-// device atomics, 4-B loads: 98.9 us = 0.26 of the roofline.  Here a workgroup owns its channel: it streams the channel's
+// per channel (scales: one hist_scale per channel; mins / maxs: one asymmetric range per channel, hist_scale =
+// (max - min) / bins as in sort.cu:123): ONE workgroup per (channel, split).  Round 2's kernel took one workgroup per ROW: it
+// zeroed, filled and flushed an LDS histogram for every 12.5 KB row of a [32, 512, 56, 56] activation -- 16384 workgroups,
+// 13 M device atomics, 4-B loads: 98.9 us = 0.26 of the roofline.  Here a workgroup owns its channel: it streams the channel's
 // rows (stride C * epc) as one virtual float4 range with the persistent kernel's machinery (two ping-pong register tiles,
 // packed-f32 binning, EXEC-mask LDS commits, hot bin) and adds its histogram to the channel's row of `hist` ONCE -- with
 // plain read-modify-writes when it is the channel's only workgroup (splits == 1: no atomics at all).
@@ -436,6 +396,42 @@ void hist_c_channel_kernel(const float* __restrict__ x, FastDiv vec_per_row, uin
         acc.elect(b[0], in);
         acc.template commit<false>(b[0], in); acc.template commit<false>(b[1], in);
         acc.template commit<false>(b[2], in); acc.template commit<false>(b[3], in);
+    }
+    acc.flush_hot();
+    lds_hist_flush(lds, bins, copies, hist + (size_t)c * bins, splits == 1 ? FLUSH_ROWS_ADD : FLUSH_ATOMIC);
+}
+
+// the same ownership for rows that are not float4-addressable (elem_per_channel % 4 != 0: the 7 x 7 planes of a CNN's last
+// stage; unaligned views): 4-B loads over the channel's virtual ELEMENT range -- still one LDS histogram and one flush per
+// channel split instead of one device atomic per element (hist_c_global_kernel)
+template <bool ASYM, bool CLIP>
+__global__ __launch_bounds__(kHistBlock) void hist_c_channel_scalar_kernel(
+    const float* __restrict__ x, FastDiv elem_per_row, uint32_t C, uint32_t outer, uint32_t splits, BinRule rule, int copies,
+    int* __restrict__ hist, const float* __restrict__ scales, const float* __restrict__ mins, const float* __restrict__ maxs) {
+    extern __shared__ int lds[];
+    const int bins = rule.bins;
+    for (int i = threadIdx.x; i < copies * bins; i += kHistBlock) lds[i] = 0;
+    __syncthreads();
+    const uint32_t c = blockIdx.x % C, sp = blockIdx.x / C;
+    const uint32_t epc = elem_per_row.d;
+    const uint32_t all = outer * epc;
+    const uint32_t v0 = (uint32_t)(((uint64_t)sp * all) / splits);
+    const uint32_t V = (uint32_t)(((uint64_t)(sp + 1) * all) / splits) - v0;
+    Binner<ASYM, CLIP, true> acc;
+    acc.init(lds + ((threadIdx.x >> 6) % copies) * bins, bins);
+    if (ASYM) acc.set_rule(mins[c], (maxs[c] - mins[c]) / (float)bins);
+    else acc.set_rule(0.f, scales != nullptr ? scales[c] : rule.hs);
+    const float* xc = x + (size_t)c * epc;
+    const size_t row_stride = (size_t)C * epc;
+    const uint32_t trips = (V + kHistBlock - 1) / kHistBlock;              // block-uniform: the commits use wave ballots
+    uint32_t v = threadIdx.x;
+    for (uint32_t t = 0; t < trips; t++, v += kHistBlock) {
+        const bool in = v < V;
+        float a = 0.f;
+        if (in) { const uint32_t r = fdiv(v0 + v, elem_per_row); a = xc[(size_t)r * row_stride + (v0 + v - r * epc)]; }
+        const int b = acc.bin1(a);
+        if ((t & 15u) == 0) acc.elect(b, in);
+        acc.template commit<false>(b, in);
     }
     acc.flush_hot();
     lds_hist_flush(lds, bins, copies, hist + (size_t)c * bins, splits == 1 ? FLUSH_ROWS_ADD : FLUSH_ATOMIC);
@@ -685,22 +681,23 @@ static int hist_c_impl(const float* x, int64_t n, int64_t num_channel, int64_t e
             default: PPQ_LAUNCH_HIST_CC(true, true); break;
         }
 #undef PPQ_LAUNCH_HIST_CC
-    } else if (elem_per_channel >= 1024 && num_bins <= kMaxLdsBins) {
-        const int copies = pick_copies(rule.bins, kBlock);
-        const uint32_t chunk_elems = 16384;
-        const uint32_t chunks = (uint32_t)((elem_per_channel + chunk_elems - 1) / chunk_elems);
-        const int64_t rows = n / elem_per_channel;
-#define PPQ_LAUNCH_HIST_C(A, C)                                                                                      \
-        hipLaunchKernelGGL((hist_c_row_kernel<A, C>), dim3((uint32_t)(rows * chunks)), dim3(kBlock),                 \
-                           lds_bytes(rule.bins, copies), s, x, (uint32_t)elem_per_channel, make_fastdiv(chunks), nc, \
-                           chunk_elems, rule, copies, hist, scales, mins, maxs)
+    } else if (n / num_channel >= 256 && num_bins <= kMaxLdsBins) {        // >= 256 elements per channel, not float4-addressable
+        const uint32_t C = (uint32_t)num_channel, outer = (uint32_t)(n / (num_channel * elem_per_channel));
+        const uint32_t want_wgs = (uint32_t)kNumCU * PPQHIP_HIST_C_WGPC;
+        uint32_t splits = C >= want_wgs ? 1u : (want_wgs + C - 1) / C;
+        const uint64_t trips_per_channel = ((uint64_t)outer * (uint64_t)elem_per_channel) / (kHistBlock * 8);   // >= 8 trips per split
+        if (splits > trips_per_channel) splits = trips_per_channel > 0 ? (uint32_t)trips_per_channel : 1u;
+        const int copies = pick_copies(rule.bins, kHistBlock);
+#define PPQ_LAUNCH_HIST_CS(A, CL)                                                                                     \
+        hipLaunchKernelGGL((hist_c_channel_scalar_kernel<A, CL>), dim3(C * splits), dim3(kHistBlock), lds_bytes(rule.bins, copies), s, \
+                           x, make_fastdiv((uint32_t)elem_per_channel), C, outer, splits, rule, copies, hist, scales, mins, maxs)
         switch ((asym ? 2 : 0) | (rule.clip ? 1 : 0)) {
-            case 0: PPQ_LAUNCH_HIST_C(false, false); break;
-            case 1: PPQ_LAUNCH_HIST_C(false, true); break;
-            case 2: PPQ_LAUNCH_HIST_C(true, false); break;
-            default: PPQ_LAUNCH_HIST_C(true, true); break;
+            case 0: PPQ_LAUNCH_HIST_CS(false, false); break;
+            case 1: PPQ_LAUNCH_HIST_CS(false, true); break;
+            case 2: PPQ_LAUNCH_HIST_CS(true, false); break;
+            default: PPQ_LAUNCH_HIST_CS(true, true); break;
         }
-#undef PPQ_LAUNCH_HIST_C
+#undef PPQ_LAUNCH_HIST_CS
     } else {
         hipLaunchKernelGGL(hist_c_global_kernel, dim3(stream_grid(n, kBlock * 4)), dim3(kBlock), 0, s, x, (uint32_t)n,
                            make_fastdiv((uint32_t)elem_per_channel), nc, rule, hist, scales, mins, maxs);
