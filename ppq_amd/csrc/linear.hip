@@ -167,6 +167,33 @@ __global__ __launch_bounds__(kBlock) void to_int_kernel(const float* __restrict_
     }
 }
 
+// 1-byte outputs: 16 consecutive elements per lane -- four 16-B loads, ONE 16-B store (a 4-B store per lane writes 256 B per
+// wave instruction: 0.62 of the roofline on [32, 512, 56, 56]; this form 16 x that per instruction).  elem_per_channel % 16 == 0.
+template <typename OUT, bool CHANNEL>
+__global__ __launch_bounds__(kBlock) void to_int8_x16_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ offset, OUT* __restrict__ out, uint32_t n16,
+                                                             FastDiv elem_per_channel, FastDiv num_channel, float qmin, float qmax,
+                                                             int rounding) {
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;           // group of 16 elements
+    if (g >= n16) return;
+    const uint32_t i0 = g * 16u;
+    uint32_t c = 0;
+    if (CHANNEL) { const uint32_t row = fdiv(i0, elem_per_channel); c = row - fdiv(row, num_channel) * num_channel.d; }
+    const float s = scale[c], o = offset[c];
+    const float4* xv = reinterpret_cast<const float4*>(x + i0);
+    float4 a[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) a[u] = xv[u];
+    uint32_t w[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int q0 = to_int_scalar(a[u].x, s, o, qmin, qmax, rounding), q1 = to_int_scalar(a[u].y, s, o, qmin, qmax, rounding);
+        const int q2 = to_int_scalar(a[u].z, s, o, qmin, qmax, rounding), q3 = to_int_scalar(a[u].w, s, o, qmin, qmax, rounding);
+        w[u] = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+    }
+    *reinterpret_cast<uint4*>(out + i0) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // --------------------------------------------------------------------------- LSQ backward
 // One element of QuantizeTensor_LT_B / _LC_B (linear.cu:255-274 / :352-372).  `o` is the rounded
 // offset kept as float, as in the reference; returns the partial d(loss)/d(scale) term.
@@ -631,6 +658,23 @@ static int to_int_impl(const float* x, const float* scale, const float* offset, 
     const FastDiv e = make_fastdiv((uint32_t)(channel ? epc : 1)), nc = make_fastdiv((uint32_t)(channel ? C : 1));
     const dim3 grid((uint32_t)((n + kBlock * 4 - 1) / (kBlock * 4)));
     const float qmin = (float)clip_min, qmax = (float)clip_max;
+    // 1-byte outputs, 16-B aligned both ways, channels in whole groups of 16: the bulk goes through the 16-per-lane kernel,
+    // the (< 16 element) rest through the general one
+    if (out_dtype != 2 && aligned16(x) && aligned16(out) && (!channel || epc % 16 == 0) && n >= 16) {
+        const uint32_t n16 = (uint32_t)(n / 16);
+        const dim3 g16((n16 + kBlock - 1) / kBlock);
+#define PPQ_LAUNCH_TOINT16(T, CH) hipLaunchKernelGGL((to_int8_x16_kernel<T, CH>), g16, dim3(kBlock), 0, s, x, scale, offset, (T*)out, \
+                                                     n16, e, nc, qmin, qmax, rounding)
+        if (out_dtype == 0) { if (channel) PPQ_LAUNCH_TOINT16(int8_t, true); else PPQ_LAUNCH_TOINT16(int8_t, false); }
+        else { if (channel) PPQ_LAUNCH_TOINT16(uint8_t, true); else PPQ_LAUNCH_TOINT16(uint8_t, false); }
+#undef PPQ_LAUNCH_TOINT16
+        const int64_t done = (int64_t)n16 * 16;
+        if (done == n) return finish_launch(what);
+        // the rest: per-tensor (or the tail's own channel: elements [done, n) continue the last row)
+        if (!channel) return to_int_impl(x + done, scale, offset, (uint8_t*)out + done, n - done, 1, n - done, clip_min, clip_max, rounding,
+                                         out_dtype, false, stream, what);
+        set_error("%s: internal: ragged tail with channels", what); return PPQHIP_ERR_INVALID_VALUE;      // n % (C * epc) == 0 and epc % 16 == 0
+    }
 #define PPQ_LAUNCH_TOINT(T, CH) hipLaunchKernelGGL((to_int_kernel<T, CH>), grid, dim3(kBlock), 0, s, x, scale, offset, (T*)out, \
                                                    (uint32_t)n, vec_ok, e, nc, qmin, qmax, rounding)
     if (out_dtype == 0) { if (channel) PPQ_LAUNCH_TOINT(int8_t, true); else PPQ_LAUNCH_TOINT(int8_t, false); }
