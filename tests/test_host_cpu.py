@@ -674,3 +674,20 @@ def test_quantile_workspace_sizing_covers_the_layout():
         assert got <= 2 * need + (1 << 20)                                                     # and is not wildly larger
     for n in (1, 1605632, 2 ** 31 - 1):
         assert int(_lib.lib.ppqhip_quantile_workspace_bytes(n)) >= prefix + (words + 2 * cap(n)) * 4 >= 65536   # (isotone's partials fit too)
+
+
+def test_to_int_dispatch_and_no_cpu_path():
+    """PPQLinearQuant_toInt mirrors the reference's dispatch (qfunction/linear.py:218-238): non-linear configs raise, fewer than
+    8 bits raise, and -- like every kernel-backed function here -- a host tensor is refused instead of silently computed on
+    the CPU; PPQuantFunction_toInt refuses dynamic / non-linear policies (qfunction/__init__.py:47-60)."""
+    from ppq_amd import FloatingQuantizationConfig, LinearQuantizationConfig, QuantizationStates, qfunction
+    t = torch.zeros(4, 6)
+    cfg = LinearQuantizationConfig(symmetrical=True, num_of_bits=8)
+    cfg.scale, cfg.offset, cfg.state = torch.ones(1), torch.zeros(1), QuantizationStates.ACTIVATED
+    with pytest.raises(RuntimeError, match='not on the GPU'): qfunction.PPQLinearQuant_toInt(t, cfg)
+    low = LinearQuantizationConfig(symmetrical=True, num_of_bits=4, quant_min=-8, quant_max=7)
+    low.scale, low.offset = torch.ones(1), torch.zeros(1)
+    with pytest.raises(Exception, match='num of bits is unexpected'): qfunction.PPQLinearQuant_toInt(t, low)
+    with pytest.raises(ValueError, match='Non-linear'): qfunction.PPQLinearQuant_toInt(t, FloatingQuantizationConfig())
+    with pytest.raises(ValueError): qfunction.PPQuantFunction_toInt(t, FloatingQuantizationConfig())
+    with pytest.raises(ValueError): qfunction.PPQuantFunction_toInt(t, LinearQuantizationConfig(dynamic=True))
