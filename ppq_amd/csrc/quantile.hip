@@ -5,7 +5,7 @@
 // asks for extreme ranks (q = 0.9999: the answer is one of the n / 10000 largest / smallest elements), so this file
 // FILTERS instead of sorting:
 //
-//   init      (1 wg / job)    the job table goes to device memory (no 64-job kernel-argument limit: one launch sequence per
+//   init      (4 wg / job)    the job table goes to device memory (no 64-job kernel-argument limit: one launch sequence per
 //                             forward), the per-job counters are zeroed, the jobs whose thresholds must be estimated are counted
 //   sample    (cold jobs)     histogram of the top 12 key bits over ~2 % of the tensor (jittered 64-B granules)
 //   filter    (all data)      ONE streaming pass: every key above T_hi / below T_lo is staged in LDS and appended to the
@@ -15,12 +15,15 @@
 //                             batch after batch) or, cold, from the sample histogram, computed by every workgroup at the
 //                             head of the job's tiles (a separate 1-workgroup launch cost 8 us + a boundary).
 //   select A  (1 wg / side)   the list holds the `count` most extreme keys exactly, so the wanted order statistic is the
-//                             (k - (n - count))-th smallest listed key (radix select on the key range, in LDS), or the
-//                             threshold itself when it lies within the counted ties.  Writes the hint for the next batch.
+//                             (k - (n - count))-th smallest listed key (radix select on the key range, 1024 lanes, the list
+//                             kept in LDS), or the threshold itself when it lies within the counted ties.  Keeps or drops
+//                             the hint for the next batch.
 //   F1 F2 F3  (open sides)    exact radix select over the whole tensor (12 + 12 + 8 key bits) for the sides the filter
 //                             could not settle (unlucky sample, list overflow, tie on an odd value, unaligned or tiny
 //                             tensors): each is an all-data pass whose LAST workgroup (ticket per job) runs the single-
-//                             workgroup step that used to be its own launch.  With nothing open each returns on one load.
+//                             workgroup step that used to be its own launch (and F2 / F3 leave a hint that works: a
+//                             threshold with a known, sufficient number of keys beyond it, or ON a heavily tied answer).
+//                             With nothing open each returns on one load.
 //
 // The result is exact in every case; the hint only decides how much is read.  Hot path: 7 launches, 4 of them empty.
 #include <cmath>
