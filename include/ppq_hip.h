@@ -42,7 +42,7 @@ typedef enum {
 
 /* library / device introspection ------------------------------------------------------------- */
 const char* ppqhip_last_error(void);
-int ppqhip_version(void);                 /* ABI version, bumped on incompatible change */
+int ppqhip_version(void);                 /* ABI version, bumped on incompatible change (2: quantile hints) */
 int ppqhip_device_arch(char* buf, int n); /* gcnArchName of the current device, e.g. "gfx950:..." */
 
 /* linear (integer) fake quant ---------------------------------------------------------------- */
