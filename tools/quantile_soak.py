@@ -2,7 +2,7 @@
 a device sort (the reference's index rule, sort.cu:13-19) -- while a second stream keeps the chip unevenly busy, which is
 where a missing release / acquire in the exact passes' "last workgroup" tails would show (MI355X_MICROARCH.md: test every
 hand-off under uneven load).
-    python tools/quantile_soak.py [rounds] [seed]"""
+    python tools/quantile_soak.py [rounds] [seed] [big]"""
 import os
 import sys
 import time
@@ -17,6 +17,7 @@ from ppq_amd.ffi import quantile_hint  # noqa: E402
 dev = torch.device('cuda')
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+big = len(sys.argv) > 3 and sys.argv[3] == 'big'        # also 25 M / 51 M element tensors (the sharded lists, many slices per job)
 rng = np.random.default_rng(seed)
 g = torch.Generator(device=dev).manual_seed(seed)
 
@@ -64,7 +65,7 @@ for r in range(rounds):
     q = float(rng.choice([0.9999, 0.9999, 0.999, 0.99, 0.5, 1.0, 0.0]))
     xs, hints, keys = [], [], []
     for _ in range(jobs):
-        n = int(rng.choice([1, 7, 300, 5000, 70_001, 262_144, 1_000_003, 3_145_768, 6_422_528]))
+        n = int(rng.choice([1, 7, 300, 5000, 70_001, 262_144, 1_000_003, 3_145_768, 6_422_528] + ([25_690_112, 51_380_224] if big else [])))
         kind = int(rng.integers(0, 8))
         x = make(n, kind)
         if rng.random() < 0.15 and n > 8: x = x[1:]                    # 4-B aligned only
