@@ -626,7 +626,7 @@ def main():
                             for c, v in op.config_with_variable if not v.is_parameter and c.scale is not None
                             and int(getattr(c.state, 'value', c.state)) == 4))
         variants.append({'workload': f'the same {args.steps} x {args.batch} pass with reuse_activations: phase 2 bins the phase-1 activations '
-                                     'kept in HBM, no second forward (identical scales)', 'samples': args.steps * args.batch,
+                                     'kept in HBM, no second forward (scale checksum equal to ~1e-7 relative: the two forwards of the headline are not bitwise repeatable, MIOpen atomics)', 'samples': args.steps * args.batch,
                          'value': round(args.steps * args.batch / tv, 2), 'unit': 'samples/s', 'ms_per_step': round(tv / args.steps * 1e3, 3),
                          'replayed_batches': pv.replayed_batches, 'resident_MiB': round(pv.replay_peak_bytes / 2 ** 20),
                          'scale_checksum': check_v})

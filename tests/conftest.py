@@ -21,7 +21,8 @@ def pytest_configure(config):
 # Collection order (the driver runs `pytest -x`): kernel-level bit-exact parity first, then the unmodified reference
 # on these kernels, then the host layer, and the training-based passes LAST, so that no single test further down the
 # stack can hide the parity suite (round 2: one optimizer-outcome threshold masked 234 tests).
-_ORDER = ['test_oracle_golden.py', 'test_host_cpu.py', 'test_gpu_kernels.py', 'test_gpu_fp8_reference.py', 'test_gpu_reference.py',
+_ORDER = ['test_oracle_golden.py', 'test_oracle_ref_kernels.py', 'test_host_cpu.py', 'test_gpu_kernels.py', 'test_gpu_fp8_reference.py',
+          'test_gpu_kernels_reference.py', 'test_gpu_reference.py',
           'test_gpu_plugin_seam.py', 'test_gpu_calibration.py', 'test_gpu_rccl.py', 'test_gpu_finetune.py']
 
 

@@ -14,6 +14,10 @@ kernels.  Outputs (committed, all small):
     tests/golden/to_int.npz           PPQLinearQuant_toInt (quantise only, integer output; --to-int-only regenerates just this file)
     tests/golden/fp8_ref.npz          FP8 fake-quant + the 8 rounding modes, from the reference's common.cuh compiled on the host
                                       (--fp8-only regenerates just this file)
+    tests/golden/dynamic.npz          PPQDyamicLinearQuantFunction, per tensor and per channel (--dynamic-only)
+    tests/golden/kernels_ref.npz      histograms, quantile positions / picks, LSQ-backward and FP8-backward masks + scale gradients
+                                      from the reference's OWN `__global__` kernel bodies (sort.cu / linear.cu / floating.cu) run on
+                                      the host (oracle/_ref/libref_kernels.so; --kernels-only regenerates just this file)
 
 Import shims (the container has no onnx and a newer protobuf/numpy than ppq expects):
 stub `onnx*` modules, PROTOCOL_BUFFERS_PYTHON_IMPLEMENTATION=python, and a float() cast in
@@ -352,6 +356,43 @@ def gen_fp8_ref():
     print('fp8_ref.npz', len(out), 'arrays,', os.path.getsize(os.path.join(HERE, 'fp8_ref.npz')), 'bytes')
 
 
+def gen_kernels_ref():
+    """Outputs PRODUCED BY THE REFERENCE'S OWN KERNEL BODIES (oracle/ref_kernels.py: the `__global__` functions of sort.cu,
+    linear.cu, floating.cu extracted at build time from where they lie and executed thread by thread on the host), on the
+    seeded inputs of tests/golden/kernel_ref_cases.py.  Only outputs are stored: histograms, the two positions `_Quantile_T`
+    reads per (n, q), its picks on small tensors, and for the backward kernels the bit mask `grad_x != 0`, grad_s, and the
+    double-precision sum of the per-thread terms handed to the block reduction."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import ref_kernels as K
+    import kernel_ref_cases as cases
+    out = {}
+    for key, kind, v, prm in cases.hist_cases():
+        if kind == 'sym':
+            out['hist_' + key] = K.hist_sym_t(v, prm[0], np.zeros(cases.BINS, np.int32), prm[1])
+        elif kind == 'asym':
+            out['hist_' + key] = K.hist_asym_t(v, prm[0], prm[1], np.zeros(cases.BINS, np.int32), prm[2])
+        else:
+            shape, axis, hs, clip = prm
+            out['hist_' + key] = K.hist_sym_c(v, axis, hs, np.zeros(shape[axis] * 128, np.int32), clip)
+    out['qpos'] = np.array([[K.quantile_positions(n, float(np.float32(q))) for q in cases.QUANTILE_QS] for n in cases.QUANTILE_NS], np.int64)
+    for key, v, q in cases.quantile_arrays():
+        out[key] = K.quantile_t(v, q)
+    for key, x, dy, s, o, axis, qmin, qmax, r in cases.lsq_cases():
+        if axis is None: gx, gs, part = K.fq_linear_t_bwd(x, s, o, dy, qmin, qmax, r, with_partials=True)
+        else: gx, gs, part = K.fq_linear_c_bwd(x, s, o, dy, axis, qmin, qmax, r, with_partials=True)
+        assert np.all((gx == 0) | (gx == dy))
+        out[key + '_mask'] = np.packbits(gx.reshape(-1) != 0)
+        out[key + '_gs'] = gs
+        out[key + '_psum'] = part.astype(np.float64).sum(axis=None if axis is None else 1)
+    for key, x, dy, s, o, axis, E, M, c in cases.fp8_bwd_cases():
+        gx, gs = K.fq_float_c_bwd(x, s, o, dy, axis, E, M, -c, c, 0)
+        assert np.all((gx == 0) | (gx == dy))
+        out[key + '_mask'] = np.packbits(gx.reshape(-1) != 0)
+        out[key + '_gs'] = gs
+    np.savez_compressed(os.path.join(HERE, 'kernels_ref.npz'), **out)
+    print('kernels_ref.npz', len(out), 'arrays,', os.path.getsize(os.path.join(HERE, 'kernels_ref.npz')), 'bytes')
+
+
 from to_int_cases import to_int_cases, to_int_inputs  # noqa: E402  (shared with the tests; imports nothing of the reference)
 
 
@@ -368,16 +409,43 @@ def gen_to_int():
     print('to_int.npz', len(out), 'arrays,', os.path.getsize(os.path.join(HERE, 'to_int.npz')), 'bytes')
 
 
+from dynamic_cases import dynamic_cases, dynamic_input  # noqa: E402
+
+
+def gen_dynamic():
+    """PPQDyamicLinearQuantFunction of the reference (qfunction/linear.py:99-198: min / max of THIS tensor, per tensor or per
+    channel -> minmax_to_scale_offset -> torch fake quant) on the seeded cases of dynamic_cases.py."""
+    from ppq.quantization.qfunction.linear import PPQDyamicLinearQuantFunction
+    import io, contextlib
+    out = {}
+    for key, shape, axis, sym, qmin, qmax, pow2 in dynamic_cases():
+        x = dynamic_input(key, shape, axis)
+        cfg = tqc(per_channel=axis is not None, sym=sym, qmin=qmin, qmax=qmax, bits=8, axis=axis, pow2=pow2)
+        cfg._policy = QuantizationPolicy(cfg.policy._policy + P.DYNAMIC.value)
+        cfg.state = QuantizationStates.ACTIVATED
+        with contextlib.redirect_stdout(io.StringIO()):             # the reference prints scale / offset (linear.py:120)
+            y = PPQDyamicLinearQuantFunction(x, cfg)
+        out[key] = y.numpy()
+    np.savez_compressed(os.path.join(HERE, 'dynamic.npz'), **out)
+    print('dynamic.npz', len(out), 'arrays,', os.path.getsize(os.path.join(HERE, 'dynamic.npz')), 'bytes')
+
+
 if __name__ == '__main__':
     torch.set_num_threads(8)
     if '--to-int-only' in sys.argv:
         gen_to_int(); sys.exit(0)
     if '--fp8-only' in sys.argv:
         gen_fp8_ref(); sys.exit(0)
+    if '--dynamic-only' in sys.argv:
+        gen_dynamic(); sys.exit(0)
+    if '--kernels-only' in sys.argv:
+        gen_kernels_ref(); sys.exit(0)
     if '--cuda-rule-only' not in sys.argv:
         gen_linear()
         gen_rounding()
         gen_observers()
     gen_observers_cuda_rule()
     gen_fp8_ref()
+    gen_kernels_ref()
     gen_to_int()
+    gen_dynamic()

@@ -464,3 +464,23 @@ def test_to_int_oracle_matches_reference_outputs(golden_dir):
         x, s, o = to_int_inputs(key, shape, axis)
         got = O.to_int(x.numpy(), s.numpy(), o.numpy(), qmin, qmax, r, axis, z[key].dtype)
         assert got.dtype == z[key].dtype and np.array_equal(got, z[key]), key
+
+
+def test_dynamic_quant_oracle_equals_reference_goldens(golden_dir):
+    """PPQDyamicLinearQuantFunction (qfunction/linear.py:99-198), per tensor AND per channel: min / max of this very tensor ->
+    minmax_to_scale_offset (Python floats) -> fake quant; the oracle's composition vs what the reference returned (dynamic.npz)."""
+    import sys
+    sys.path.insert(0, golden_dir)
+    from dynamic_cases import dynamic_cases, dynamic_input
+    z = np.load(os.path.join(golden_dir, 'dynamic.npz'))
+    for key, shape, axis, sym, qmin, qmax, pow2 in dynamic_cases():
+        x = dynamic_input(key, shape, axis).numpy()
+        if axis is None:
+            mm = O.minmax_t(x)
+            s, o = O.minmax_to_scale_offset(float(mm[0]), float(mm[1]), qmin, qmax, sym, pow2)
+            got = O.fq_linear_t(x, [np.float32(s)], [np.float32(o)], qmin, qmax, 0)
+        else:
+            mins, maxs = O.minmax_c(x, axis)
+            so = [O.minmax_to_scale_offset(float(a), float(b), qmin, qmax, sym, pow2) for a, b in zip(mins, maxs)]
+            got = O.fq_linear_c(x, np.array([v[0] for v in so], np.float32), np.array([v[1] for v in so], np.float32), axis, qmin, qmax, 0)
+        assert np.array_equal(got.view(np.uint32), z[key].view(np.uint32)), key
