@@ -280,3 +280,45 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
             self.calibrate(desc='Calibration Progress(Phase 2)', dataloader=dataloader, executor=executor,
                            hooks=hooks, output_names=None)
             self._render()
+
+
+class IsotoneCalibrationPass(RuntimeCalibrationPass):
+    """optim/calibration.py:325-423.  Marks classification outputs for the order-preserving 'isotone' observer -- by default the
+    output of every Softmax that owns its config, otherwise the variables named in ``variables`` with ``axis`` as the class
+    axis -- and then CALIBRATES them: like the reference's, this pass ends in ``RuntimeCalibrationPass.optimize`` (method None,
+    so the 'Isotone' marks are kept, every other INITIAL config is observed with its own algorithm)."""
+    def __init__(self, variables: List[str] = None, axis: int = -1, verbose: bool = True, calib_steps: int = 32) -> None:
+        super().__init__(calib_steps=calib_steps)
+        self.name = 'Isotone Calibration Pass'
+        self.variables = variables
+        self.axis = axis
+        self.verbose = verbose
+
+    @ staticmethod
+    def _mark(cfg, axis: int) -> None:
+        from .core import OBSERVER_ISOTONE_OBSERVER_AXIS
+        cfg.state = type(cfg.state).INITIAL                               # the graph may carry the reference's own enum
+        cfg.observer_algorithm = 'Isotone'
+        cfg.detail[OBSERVER_ISOTONE_OBSERVER_AXIS] = axis
+
+    def optimize(self, graph, **kwargs) -> None:
+        if self.variables is None:
+            for op in graph.operations.values():
+                if op.type != 'Softmax' or not hasattr(op, 'config'): continue
+                cfg = op.config.output_quantization_config[0]
+                if cfg.dominated_by != cfg: continue                          # a dominated config follows its master
+                axis = op.attributes.get('axis', -1)
+                self._mark(cfg, axis)
+                if self.verbose: print(f'Calibration Method of Op {op.name} has been changed to Isotone[axis={axis}].')
+        else:
+            if not isinstance(self.variables, list) or not all(isinstance(v, str) for v in self.variables):
+                raise TypeError('Isotone Calibration Pass needs a list of variable name as its input.')
+            for name in self.variables:
+                if name not in graph.variables: raise ValueError(f'Variable {name} not in current graph.')
+                var = graph.variables[name]
+                op = var.source_op
+                if op is None or not hasattr(op, 'config'): continue           # not a QuantableVariable
+                self._mark(op.config.output_quantization_config[op.outputs.index(var)], self.axis)
+                if self.verbose: print(f'Calibration Method of Variable {var.name} has been changed to Isotone[axis={self.axis}].')
+        super().optimize(graph, **kwargs)
+

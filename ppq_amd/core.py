@@ -24,6 +24,7 @@ OBSERVER_PERCENTILE_MANUL_OVERRIDE = 'OBSERVER_PERCENTILE_MANUL_OVERRIDE'
 OBSERVER_MSE_HIST_BINS = 2048
 OBSERVER_MSE_COMPUTE_INTERVAL = 8
 OBSERVER_FLOATING_MSE_FETCHES = 4096
+OBSERVER_ISOTONE_OBSERVER_AXIS = 'OBSERVER_ISOTONE_OBSERVER_AXIS'      # ppq/core/common.py:34
 
 
 class _Config:

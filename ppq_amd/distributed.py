@@ -10,6 +10,7 @@ shards embarrassingly over samples and every observer statistic is an associativ
       phase 1  running ranges      MIN over [mins ; -maxs]          (a few KB)
                percentile sums     SUM                              (3 floats per observer)
                FP8 'floating'      SUM of the 7 per-candidate squared errors + a count (doubles)
+               isotone             all-gather of the [rows, 2] top-2 pairs (a set, not a reduction)
       phase 2  histograms          SUM over int32 [n_observers x bins]   (~1 MB for ResNet-50)
   Payloads are latency-bound on xGMI (7 links x ~153 GB/s per GPU), so the number of collectives,
   not their size, is what is minimised -- never one collective per tensor.
@@ -69,13 +70,16 @@ def merge_observers(observers: Sequence, group=None, even_if_single_rank: bool =
             elif kind == 'max': maxs.append(buf)
             elif kind == 'sum': sums.setdefault(buf.dtype, []).append(buf)
             else: raise ValueError(f'unknown reduction {kind}')
+    gathers = [(ob, ob.gatherable()) for ob in observers if hasattr(ob, 'gatherable')]
+    gathers = [(ob, bufs) for ob, bufs in gathers if bufs]
     t0 = time.perf_counter()
     sum_dtypes = (torch.int32, torch.float32, torch.float64, torch.int64)
     for dt in sums:
         if dt not in sum_dtypes: raise ValueError(f'merge_observers: unsupported sum dtype {dt}')
     lengths = [sum(b.numel() for b in mins), sum(b.numel() for b in maxs)] + \
               [sum(b.numel() for b in sums.get(dt, [])) for dt in sum_dtypes]
-    some = mins + maxs + [b for v in sums.values() for b in v]
+    lengths.append(sum(len(bufs) for _, bufs in gathers))
+    some = (mins + maxs + [b for v in sums.values() for b in v] + [b for _, bufs in gathers for b in bufs])
     backend = dist.get_backend(group)
     device = some[0].device if some else torch.device('cuda' if backend == 'nccl' else 'cpu')
     # int32 histograms (the reference's counter type, sort.cu:91-165): world_size ranks x the largest count any of them
@@ -116,6 +120,32 @@ def merge_observers(observers: Sequence, group=None, even_if_single_rank: bool =
         pos = 0
         for b in bufs:
             n = b.numel(); b.copy_(flat[pos: pos + n].reshape(b.shape)); pos += n
+    if gathers:
+        # row sets (isotone top-2 pairs): ONE all-gather of the row counts, ONE of the rows padded to the largest count
+        world = dist.get_world_size(group)
+        flat_bufs = [b for _, bufs in gathers for b in bufs]
+        rows = torch.tensor([b.shape[0] for b in flat_bufs], dtype=torch.int64, device=device)
+        all_rows = [torch.empty_like(rows) for _ in range(world)]
+        dist.all_gather(all_rows, rows, group=group)
+        width = [int(b.shape[1]) for b in flat_bufs]
+        cap = [int(max(int(r[k]) for r in all_rows)) for k in range(len(flat_bufs))]
+        mine = torch.cat([torch.cat([b.reshape(b.shape[0], -1).float(),
+                                     torch.zeros(cap[k] - b.shape[0], width[k], dtype=torch.float32, device=device)]).reshape(-1)
+                          for k, b in enumerate(flat_bufs)])
+        everyone = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(everyone, mine, group=group)
+        issued += 2
+        moved['gather_f32_bytes'] = mine.numel() * 4 * world
+        merged, pos = [[] for _ in flat_bufs], 0
+        for k in range(len(flat_bufs)):
+            n = cap[k] * width[k]
+            for r in range(world):
+                merged[k].append(everyone[r][pos: pos + n].reshape(cap[k], width[k])[: int(all_rows[r][k])])
+            pos += n
+        k = 0
+        for ob, bufs in gathers:
+            ob.take_gathered([torch.cat(merged[k + i]).to(bufs[i].dtype) for i in range(len(bufs))])
+            k += len(bufs)
     if some and some[0].is_cuda: torch.cuda.synchronize(some[0].device)
     last_merge_stats = {'collectives': issued, 'ms': (time.perf_counter() - t0) * 1e3, 'world_size': dist.get_world_size(group),
                         'backend': backend, **moved}

@@ -26,7 +26,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from .core import (OBSERVER_FLOATING_MSE_FETCHES, OBSERVER_KL_HIST_BINS, OBSERVER_KL_HIST_BINS_MANUL_OVERRIDE,
+from .core import (OBSERVER_FLOATING_MSE_FETCHES, OBSERVER_ISOTONE_OBSERVER_AXIS, OBSERVER_KL_HIST_BINS, OBSERVER_KL_HIST_BINS_MANUL_OVERRIDE,
                    OBSERVER_MIN_SCALE, OBSERVER_MIN_SCALE_MANUL_OVERRIDE, OBSERVER_MSE_HIST_BINS,
                    OBSERVER_PERCENTILE, OBSERVER_PERCENTILE_MANUL_OVERRIDE, is_initial, set_activated)
 from .core import QuantizationProperty as P
@@ -198,6 +198,15 @@ class BaseTensorObserver:
         """Device buffers + reduction ('min' | 'max' | 'sum') that merge shards of a data-parallel
         calibration; applied in place before rendering."""
         return []
+
+    def gatherable(self) -> List[torch.Tensor]:
+        """2-D device buffers [rows, k] whose ROWS must be collected from every rank -- statistics that are a set, not a
+        reduction (the isotone observer's top-2 pairs).  ``take_gathered`` receives, per buffer, the concatenation over
+        ranks in rank order, identical on every rank."""
+        return []
+
+    def take_gathered(self, merged: List[torch.Tensor]) -> None:
+        pass
 
 
 _RANGE_SEEDS: Dict[object, tuple] = {}
@@ -811,6 +820,75 @@ class DirectMSEObserver(BaseTensorObserver):
         set_activated(cfg)
 
 
+class TorchIsotoneObserver(BaseTensorObserver):
+    """OBSERVER_TABLE['isotone'] (observer/order.py:12-103): an order-preserving scale for classification outputs.  With L1 > L2
+    the two largest entries of a row, argmax survives quantisation when L2 / (quant_max - .51) < scale < 2 (L1 - max(L2, 0));
+    the scale inside the most rows' intervals wins, smallest such scale first.
+
+    ``observe`` keeps one [rows, 2] device buffer per batch (torch.topk, as the reference -- including its use of the ORIGINAL
+    axis on the already flattened [rows, classes] view, order.py:49-52).  ``render`` is ONE device-to-host copy and a sort-based
+    sweep over all 2 x rows interval end points at once (numpy; the reference walks a Python list of tuples): end points are
+    ordered by (value, closing-before-opening) exactly as its ``sorted()`` orders ``(value, 'max') < (value, 'min')``, the
+    running depth is a cumulative sum and the winner its first maximum.  All arithmetic is float32, like the numpy scalars the
+    reference iterates over, so the rendered scale is bit-identical (tests/golden/isotone.npz).
+    Data parallel: the pairs are a set -- ``merge_observers`` all-gathers them (``gatherable``)."""
+    def __init__(self, watch_on, quant_cfg):
+        super().__init__(watch_on, quant_cfg)
+        self._pairs: List[torch.Tensor] = []
+        self.axis = quant_cfg.detail.get(OBSERVER_ISOTONE_OBSERVER_AXIS, -1)      # order.py:16-19 (implicit axis -1)
+
+    @ torch.no_grad()
+    def observe(self, value: torch.Tensor):
+        if not is_initial(self._quant_cfg): return
+        assert isinstance(value, torch.Tensor), 'IsotoneObserver can only deal with torch Tensor values'
+        assert value.numel() > 0, f'You are observing an empty tensor({getattr(self._watch_on, "name", "?")}).'
+        policy = self._quant_cfg.policy
+        if policy.has_property(P.PER_CHANNEL):
+            raise TypeError('Isotone Observer is not designed for channelwise quantization.')
+        if not policy.has_property(P.PER_TENSOR):
+            raise TypeError('Isotone Observer only work with per-tensor or per-channel quantize policy.')
+        rows = value
+        if rows.ndim > 1: rows = rows.transpose(self.axis, -1).flatten(0, -2)
+        top2 = torch.topk(rows, k=2, dim=self.axis, largest=True, sorted=True).values
+        self._pairs.append(top2.reshape(1, -1) if top2.ndim <= 1 else top2)
+
+    def gatherable(self):
+        if not is_initial(self._quant_cfg) or not self._pairs: return []
+        self._pairs = [torch.cat(self._pairs, dim=0).contiguous()]
+        return [self._pairs[0]]
+
+    def take_gathered(self, merged):
+        self._pairs = [merged[0]]
+
+    def render_quantization_config(self):
+        cfg = self._quant_cfg
+        if not is_initial(cfg): return
+        device = self._pairs[-1].device
+        pairs = torch.cat(self._pairs, dim=0).cpu().numpy().astype(np.float32, copy=False)
+        l1, l2 = pairs[:, 0], pairs[:, 1]
+        if cfg.policy.has_property(P.SYMMETRICAL): l1, l2 = np.abs(l1), np.abs(l2)
+        f32 = np.float32
+        lower = np.maximum(l2 / f32(cfg.quant_max - .51), f32(0))               # L2 must not be clipped
+        upper = f32(2) * (l1 - np.maximum(l2, f32(0)))                          # L1 and L2 must land in different levels
+        usable = (upper > lower) & (l1 > 0)
+
+        def _tensor(v): return torch.tensor([v], dtype=torch.float32, device=device).squeeze(0)
+        if not usable.any():
+            # no row can be separated: min-max on [0, L1 of the LAST row] (order.py:81-91)
+            scale, offset = minmax_to_scale_offset(min_val=0, max_val=l1[-1], config=cfg)
+            cfg.scale, cfg.offset = _tensor(scale), _tensor(offset)
+            set_activated(cfg)
+            return
+        ends = np.concatenate([upper[usable], lower[usable]])
+        opens = np.concatenate([np.zeros(int(usable.sum()), np.int8), np.ones(int(usable.sum()), np.int8)])
+        order = np.lexsort((opens, ends))                                       # by value; an interval closes before another opens
+        depth = np.cumsum(np.where(opens[order] == 1, 1, -1))
+        best = int(np.argmax(depth))                                            # first maximum = the smallest best scale
+        cfg.scale, cfg.offset = _tensor(ends[order][best]), _tensor(0)
+        set_activated(cfg)
+        self.s_candidates = [(v, 'min' if o else 'max') for v, o in zip(ends[order].tolist(), opens[order].tolist())]
+
+
 # observer/__init__.py:15-23
 OBSERVER_TABLE = {
     'minmax': TorchMinMaxObserver,
@@ -819,6 +897,7 @@ OBSERVER_TABLE = {
     'percentile': TorchPercentileObserver,
     'mse': TorchMSEObserver,
     'mse_channel': ChannelwiseMSEObserver,     # extension, not in the reference's table
+    'isotone': TorchIsotoneObserver,
     'constant': ConstantObserver,
     'floating': DirectMSEObserver,
 }

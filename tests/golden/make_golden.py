@@ -18,6 +18,7 @@ kernels.  Outputs (committed, all small):
     tests/golden/kernels_ref.npz      histograms, quantile positions / picks, LSQ-backward and FP8-backward masks + scale gradients
                                       from the reference's OWN `__global__` kernel bodies (sort.cu / linear.cu / floating.cu) run on
                                       the host (oracle/_ref/libref_kernels.so; --kernels-only regenerates just this file)
+    tests/golden/isotone.npz          TorchIsotoneObserver results (--isotone-only regenerates just this file)
 
 Import shims (the container has no onnx and a newer protobuf/numpy than ppq expects):
 stub `onnx*` modules, PROTOCOL_BUFFERS_PYTHON_IMPLEMENTATION=python, and a float() cast in
@@ -428,6 +429,39 @@ def gen_dynamic():
         out[key] = y.numpy()
     np.savez_compressed(os.path.join(HERE, 'dynamic.npz'), **out)
     print('dynamic.npz', len(out), 'arrays,', os.path.getsize(os.path.join(HERE, 'dynamic.npz')), 'bytes')
+def gen_isotone():
+    """observer/order.py: TorchIsotoneObserver on classification-like outputs (the reference's tests/test_isotone.py draws
+    softmax rows): multi-batch, single row, 3-D with the class axis last, an axis in the middle, and rows without any
+    candidate (min-max fall-back); symmetric and asymmetric."""
+    from ppq.core import OBSERVER_ISOTONE_OBSERVER_AXIS
+    from ppq.quantization.observer import TorchIsotoneObserver
+    g = torch.Generator().manual_seed(20240)
+    cases = [
+        ([torch.softmax(torch.randn(64, 10, generator=g) * 3, dim=-1) for _ in range(4)], -1),
+        ([torch.softmax(torch.rand(1, 10, generator=g), dim=-1)], -1),
+        ([torch.softmax(torch.randn(2, 7, 5, generator=g), dim=-1)], -1),
+        ([torch.softmax(torch.randn(6, 12, generator=g) * 2, dim=-1) for _ in range(3)], 1),
+        ([torch.randn(32, 100, generator=g)], -1),                       # logits, negative entries
+        ([torch.full([3, 4], 0.25)], -1),                                 # no candidate -> min-max fall-back
+    ]
+    out, k = {}, 0
+    for batches, axis in cases:
+        for sym in (True, False):
+            cfg = tqc(sym=sym, qmin=-128 if sym else 0, qmax=127 if sym else 255, algo='isotone',
+                      detail={OBSERVER_ISOTONE_OBSERVER_AXIS: axis})
+            cfg.state = QuantizationStates.INITIAL
+            ob = TorchIsotoneObserver(Variable(name='x'), cfg)
+            for b in batches: ob.observe(b)
+            ob.render_quantization_config()
+            out[f'iso_{k}_n'] = np.array(len(batches))
+            for i, b in enumerate(batches): out[f'iso_{k}_x{i}'] = b.numpy()
+            out[f'iso_{k}_meta'] = np.array([int(sym), axis, cfg.quant_min, cfg.quant_max])
+            out[f'iso_{k}_scale'] = cfg.scale.reshape(-1).numpy().astype(np.float32)
+            out[f'iso_{k}_offset'] = cfg.offset.reshape(-1).numpy().astype(np.float32)
+            k += 1
+    out['iso_n'] = np.array(k)
+    np.savez_compressed(os.path.join(HERE, 'isotone.npz'), **out)
+    print('isotone.npz', k)
 
 
 if __name__ == '__main__':
@@ -440,6 +474,8 @@ if __name__ == '__main__':
         gen_dynamic(); sys.exit(0)
     if '--kernels-only' in sys.argv:
         gen_kernels_ref(); sys.exit(0)
+    if '--isotone-only' in sys.argv:
+        gen_isotone(); sys.exit(0)
     if '--cuda-rule-only' not in sys.argv:
         gen_linear()
         gen_rounding()
@@ -449,3 +485,4 @@ if __name__ == '__main__':
     gen_kernels_ref()
     gen_to_int()
     gen_dynamic()
+    gen_isotone()

@@ -1151,3 +1151,73 @@ def test_float_scale_search_kernel_and_batched_floating_render(CUDA):
         assert b._quant_cfg.state.value == 4
         assert torch.equal(a._quant_cfg.scale, b._quant_cfg.scale) and torch.equal(a._quant_cfg.offset, b._quant_cfg.offset)
     assert len({float(ob._quant_cfg.scale.flatten()[0]) for ob in batched}) >= 4          # the candidates were really exercised
+
+
+@pytest.mark.parametrize('symmetrical', [True, False])
+def test_isotone_observer_never_worse_than_minmax_at_keeping_the_argmax(symmetrical):
+    """The property the reference's tests/test_isotone.py checks (10 000 random 10-class softmaxes per policy there, 1 500
+    here, on the GPU through the HIP fake-quant kernel): after isotone calibration the quantised arg-max is wrong no
+    more often than after min-max calibration of the same row."""
+    from ppq_amd.core import LinearQuantizationConfig, QuantizationStates
+    from ppq_amd.observer import OBSERVER_TABLE
+    from ppq_amd.qfunction import PPQLinearQuantFunction
+    cfg = LinearQuantizationConfig(symmetrical=symmetrical, quant_min=-128 if symmetrical else 0, quant_max=127 if symmetrical else 255,
+                                   num_of_bits=8, calibration='isotone')
+    var = type('V', (), {'name': 'TestVariable', 'is_parameter': False})()
+    g = torch.Generator().manual_seed(1)
+    rows = torch.sort(torch.softmax(torch.rand(1500, 10, generator=g), dim=-1), dim=-1)[0].to(DEV)
+    for i in range(rows.shape[0]):
+        value = rows[i: i + 1]
+        errors = []
+        for algo in ('isotone', 'minmax'):
+            cfg.state = QuantizationStates.INITIAL
+            ob = OBSERVER_TABLE[algo](var, cfg)
+            ob.observe(value)
+            ob.render_quantization_config()
+            q = PPQLinearQuantFunction(value, cfg)
+            errors.append(int(torch.sum(torch.argmax(value, dim=-1) != torch.argmax(q, dim=-1))))
+        assert errors[0] <= errors[1], (i, errors, value, cfg.scale)
+
+
+def test_isotone_calibration_pass_marks_softmax_outputs_and_calibrates_them():
+    """optim/calibration.py:325-423: IsotoneCalibrationPass rewrites the Softmax output configs (INITIAL, 'Isotone', axis) AND,
+    like the reference's (its optimize ends in super().optimize, :423), calibrates: the marked configs are rendered by the
+    isotone observer inside this very pass, every other config by the algorithm it already had."""
+    from ppq_amd import harness
+    from ppq_amd.calibration import IsotoneCalibrationPass
+    from ppq_amd.core import OBSERVER_ISOTONE_OBSERVER_AXIS
+    graph = harness.vit_graph(seed=0, depth=1, dim=64, heads=2, mlp_dim=128, patch=16, num_classes=10)
+    harness.quantize_graph(graph, 'minmax')
+    ex = harness.TorchExecutor(graph, DEV)
+    harness.ParameterQuantizePass().optimize(graph)
+    g = torch.Generator().manual_seed(2)
+    batches = [torch.randn(2, 3, 224, 224, generator=g).to(DEV) for _ in range(8)]
+    seen = []
+    from ppq_amd import observer as obs_mod
+    orig = obs_mod.TorchIsotoneObserver.render_quantization_config
+
+    def spy(self):
+        seen.append(self)
+        return orig(self)
+    obs_mod.TorchIsotoneObserver.render_quantization_config = spy
+    try:
+        IsotoneCalibrationPass(verbose=False, calib_steps=8).optimize(graph, dataloader=batches, executor=ex)
+    finally:
+        obs_mod.TorchIsotoneObserver.render_quantization_config = orig
+    marked = [op for op in graph.operations.values() if op.type == 'Softmax'
+              and str(op.config.output_quantization_config[0].observer_algorithm).lower() == 'isotone']
+    assert marked and all(OBSERVER_ISOTONE_OBSERVER_AXIS in op.config.output_quantization_config[0].detail for op in marked)
+    assert len(seen) == len(marked)
+    for op in marked:
+        c = op.config.output_quantization_config[0]
+        assert c.state.value == 4 and float(c.scale) > 0
+    for op in graph.operations.values():                                   # nothing is left uncalibrated
+        if hasattr(op, 'config'):
+            for c, var in op.config_with_variable:
+                assert c.state.value != 1, (op.name, var.name)
+    assert torch.isfinite(ex.forward(batches[0])[0]).all()
+    with pytest.raises(TypeError):
+        IsotoneCalibrationPass(variables='x').optimize(graph, dataloader=batches, executor=ex)
+    with pytest.raises(ValueError):
+        IsotoneCalibrationPass(variables=['no such variable']).optimize(graph, dataloader=batches, executor=ex)
+

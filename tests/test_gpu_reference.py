@@ -294,3 +294,37 @@ def test_reference_asymmetric_calibration_on_hip(method):
     for k, (s, o) in ref.items():
         assert torch.allclose(ours[k][0], s, rtol=1e-6, atol=0), (k, ours[k][0], s)
         assert torch.equal(ours[k][1], o), (k, ours[k][1], o)
+
+
+@pytest.mark.parametrize('symmetrical', [True, False])
+def test_isotone_observer_equals_the_reference(symmetrical):
+    """observer/order.py (OBSERVER_TABLE['isotone']): the reference's TorchIsotoneObserver vs this package's (a vectorised
+    sweep, not the reference's tuple walk) on the same batches of classification outputs -- the same scale and offset, bit
+    for bit, in the multi-batch case, in the single-row case of the reference's tests/test_isotone.py, on logits with many
+    ties between interval end points, and in the no-candidate fall-back to min-max."""
+    from ppq_amd.core import LinearQuantizationConfig as OurTQC
+    from ppq_amd.observer import OBSERVER_TABLE as OURS
+    RI.load()
+    from ppq import QuantizationStates
+    from ppq.IR import Variable
+    from ppq.lib import LinearQuantizationConfig as RefTQC
+    from ppq.quantization.observer import TorchIsotoneObserver as RefObserver
+    g = torch.Generator().manual_seed(5)
+    cases = [[torch.softmax(torch.randn(64, 10, generator=g) * 3, dim=-1) for _ in range(4)],      # multi batch
+             [torch.softmax(torch.rand(1, 10, generator=g), dim=-1)],                               # test_isotone.py's shape
+             [torch.softmax(torch.randn(2, 7, 5, generator=g), dim=-1)],                            # 3-D, axis -1
+             [torch.randint(-4, 9, [256, 6], generator=g).float() * 0.25],                          # quantised logits: tied end points
+             [torch.full([3, 4], 0.25)]]                                                             # no candidate: min-max fall-back
+    for batches in cases:
+        rc = RefTQC(symmetrical=symmetrical)
+        rc.state = QuantizationStates.INITIAL
+        ro = RefObserver(Variable(name='x'), rc)
+        oc = OurTQC(symmetrical=symmetrical, quant_min=rc.quant_min, quant_max=rc.quant_max, num_of_bits=8, calibration='isotone')
+        oo = OURS['isotone'](type('V', (), {'name': 'x', 'is_parameter': False})(), oc)
+        for b in batches:
+            ro.observe(b.to(DEV)); oo.observe(b.to(DEV))
+        ro.render_quantization_config(); oo.render_quantization_config()
+        assert int(getattr(oc.state, 'value', oc.state)) == 4
+        assert torch.equal(oc.scale.cpu().reshape(-1), rc.scale.cpu().reshape(-1)), (oc.scale, rc.scale)
+        assert torch.equal(oc.offset.cpu().reshape(-1), rc.offset.cpu().reshape(-1)), (oc.offset, rc.offset)
+

@@ -222,17 +222,24 @@ def _merge_worker(rank, world, port, q):
         def __init__(self, bufs): self.bufs = bufs
         def reducible(self): return self.bufs
 
+    class FakeRowSet:                       # the isotone observer's protocol: rows are gathered, not reduced
+        def __init__(self, rows): self.rows, self.got = rows, None
+        def reducible(self): return []
+        def gatherable(self): return [self.rows]
+        def take_gathered(self, merged): self.got = merged[0]
+
     g = torch.Generator().manual_seed(100 + rank)
     rng1 = torch.tensor([float(torch.randn(1, generator=g)) - 1, float(torch.randn(1, generator=g)) + 1])
     chan = torch.stack([torch.randn(5, generator=g) - 1, torch.randn(5, generator=g) + 1])
     hist = torch.randint(0, 1000, [64], generator=g, dtype=torch.int32)
     pct = torch.tensor([1.5 * (rank + 1), -2.0 * (rank + 1), 4.0])
     sse = torch.tensor([0.25 * (rank + 1), 1.0], dtype=torch.float64)          # FP8 'floating': per-candidate squared errors
+    pairs = FakeRowSet(torch.tensor([[10.0 * rank + i, float(i)] for i in range(rank + 2)]))     # 2 rows on rank 0, 3 on rank 1
     obs = [FakeObserver([(rng1[0:1], 'min'), (rng1[1:2], 'max')]), FakeObserver([(chan[0], 'min'), (chan[1], 'max')]),
-           FakeObserver([(hist, 'sum')]), FakeObserver([(pct, 'sum')]), FakeObserver([]), FakeObserver([(sse, 'sum')])]
+           FakeObserver([(hist, 'sum')]), FakeObserver([(pct, 'sum')]), FakeObserver([]), FakeObserver([(sse, 'sum')]), pairs]
     issued = merge_observers(obs)
     shard = shard_batches(list(range(10)))
-    q.put((rank, issued, rng1.tolist(), chan.tolist(), hist.tolist(), pct.tolist(), shard, sse.tolist()))
+    q.put((rank, issued, rng1.tolist(), chan.tolist(), hist.tolist(), pct.tolist(), shard, sse.tolist(), pairs.got.tolist()))
     dist.destroy_process_group()
 
 
@@ -258,11 +265,12 @@ def test_merge_observers_gloo_world2():
     want_rng = [min(exp[0][0][0], exp[1][0][0]).item(), max(exp[0][0][1], exp[1][0][1]).item()]
     want_chan = [torch.minimum(exp[0][1][0], exp[1][1][0]).tolist(), torch.maximum(exp[0][1][1], exp[1][1][1]).tolist()]
     want_hist = (exp[0][2] + exp[1][2]).tolist()
-    for rank, issued, rng1, chan, hist, pct, shard, sse in res:
-        assert issued == 4                                   # MIN(float) + SUM(int32, float32, float64)
+    for rank, issued, rng1, chan, hist, pct, shard, sse, pairs in res:
+        assert issued == 6                                   # MIN(float) + SUM(int32, float32, float64) + 2 all-gathers (row counts, rows)
         assert rng1 == want_rng and chan == want_chan and hist == want_hist
         assert pct == [4.5, -6.0, 8.0]
         assert sse == [0.75, 2.0]
+        assert pairs == [[0.0, 0.0], [1.0, 1.0], [10.0, 0.0], [11.0, 1.0], [12.0, 2.0]]      # rank order, ragged row counts
         assert shard == list(range(rank, 10, 2))
 
 
@@ -437,6 +445,12 @@ def _mismatch_worker(rank, world, port, q):
     class FakeObserver:
         def __init__(self, bufs): self.bufs = bufs
         def reducible(self): return self.bufs
+
+    class FakeRowSet:                       # the isotone observer's protocol: rows are gathered, not reduced
+        def __init__(self, rows): self.rows, self.got = rows, None
+        def reducible(self): return []
+        def gatherable(self): return [self.rows]
+        def take_gathered(self, merged): self.got = merged[0]
     obs = [FakeObserver([(torch.zeros(64, dtype=torch.int32), 'sum')])]
     if rank == 0: obs.append(FakeObserver([(torch.zeros(64, dtype=torch.int32), 'sum')]))    # rank 1 saw no batch for it
     try:
@@ -493,6 +507,28 @@ def test_block_builder_blocks_satisfy_the_reference_definition():
     assert len(by_sp['down5'].rps) == 1 and by_sp['conv2'].ep.name == 'conv4'
 
 
+def test_isotone_observer_equals_reference_goldens(golden_dir):
+    """OBSERVER_TABLE['isotone'] (observer/order.py) against 12 results rendered by the reference's TorchIsotoneObserver
+    (tests/golden/make_golden.py::gen_isotone): multi-batch, single row, 3-D, class axis in the middle, logits with
+    negative entries, the no-candidate fall-back to min-max; symmetric and asymmetric -- scale and offset bit for bit.
+    The observer launches no kernel (top-2 via torch, the interval sweep on the host), so this runs on the CPU."""
+    import torch
+    from ppq_amd.core import OBSERVER_ISOTONE_OBSERVER_AXIS, LinearQuantizationConfig
+    from ppq_amd.observer import OBSERVER_TABLE
+    z = np.load(os.path.join(golden_dir, 'isotone.npz'))
+    var = type('V', (), {'name': 'x', 'is_parameter': False})()
+    for k in range(int(z['iso_n'])):
+        sym, axis, qmin, qmax = (int(v) for v in z[f'iso_{k}_meta'])
+        cfg = LinearQuantizationConfig(symmetrical=bool(sym), quant_min=qmin, quant_max=qmax, num_of_bits=8, calibration='isotone')
+        cfg.detail[OBSERVER_ISOTONE_OBSERVER_AXIS] = axis
+        ob = OBSERVER_TABLE['isotone'](var, cfg)
+        for i in range(int(z[f'iso_{k}_n'])): ob.observe(torch.from_numpy(z[f'iso_{k}_x{i}']))
+        ob.render_quantization_config()
+        assert int(getattr(cfg.state, 'value', cfg.state)) == 4
+        assert np.array_equal(cfg.scale.reshape(-1).numpy().view(np.uint32), z[f'iso_{k}_scale'].view(np.uint32)), (k, cfg.scale, z[f'iso_{k}_scale'])
+        assert np.array_equal(cfg.offset.reshape(-1).numpy(), z[f'iso_{k}_offset']), (k, cfg.offset, z[f'iso_{k}_offset'])
+
+
 def test_block_split_equals_the_reference_on_resnet50_and_yolov6s():
     """ppq_amd.blocks (one forward sweep) vs the reference's BlockBuilder / split_graph_into_blocks
     (algorithm/training.py:191-315, optim/training.py:177-222) on the ResNet-50 topology -- residual fan-out / fan-in,
@@ -524,6 +560,48 @@ def test_block_split_equals_the_reference_on_resnet50_and_yolov6s():
         ref = [(b.sp.name, b.ep.name, frozenset(o.name for o in b.rps)) for b in p.split_graph_into_blocks(rg, order, limit)]
         ours = [(b.sp.name, b.ep.name, frozenset(o.name for o in b.rps)) for b in split_graph_into_blocks(hg, hg.topological_sort(), limit)]
         assert ref == ours and len(ours) == count, (limit, len(ref), len(ours))
+
+
+def _isotone_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ppq_amd.core import LinearQuantizationConfig
+    from ppq_amd.distributed import merge_observers
+    from ppq_amd.observer import OBSERVER_TABLE
+    g = torch.Generator().manual_seed(55)
+    batches = [torch.softmax(torch.randn(16 + 3 * i, 10, generator=g) * 3, dim=-1) for i in range(5)]     # ragged row counts
+    cfg = LinearQuantizationConfig(symmetrical=True, quant_min=-128, quant_max=127, num_of_bits=8, calibration='isotone')
+    ob = OBSERVER_TABLE['isotone'](type('V', (), {'name': 'x', 'is_parameter': False})(), cfg)
+    for i, b in enumerate(batches):
+        if i % world == rank: ob.observe(b)
+    issued = merge_observers([ob])
+    ob.render_quantization_config()
+    q.put((rank, issued, float(cfg.scale), float(cfg.offset)))
+    dist.destroy_process_group()
+
+
+def test_isotone_observer_data_parallel_gather_equals_union():
+    """Two gloo ranks observe disjoint (ragged) shards with the real isotone observer; after merge_observers (all-gather of
+    the top-2 pairs) both render the scale a single process renders from all batches."""
+    import torch.multiprocessing as mp
+    from ppq_amd.core import LinearQuantizationConfig
+    from ppq_amd.observer import OBSERVER_TABLE
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + ((os.getpid() + 77) % 2000)
+    procs = [ctx.Process(target=_isotone_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)])
+    for p in procs: p.join(timeout=60)
+    g = torch.Generator().manual_seed(55)
+    batches = [torch.softmax(torch.randn(16 + 3 * i, 10, generator=g) * 3, dim=-1) for i in range(5)]
+    cfg = LinearQuantizationConfig(symmetrical=True, quant_min=-128, quant_max=127, num_of_bits=8, calibration='isotone')
+    ob = OBSERVER_TABLE['isotone'](type('V', (), {'name': 'x', 'is_parameter': False})(), cfg)
+    for b in batches: ob.observe(b)
+    ob.render_quantization_config()
+    for rank, issued, scale, offset in res:
+        assert issued == 2 and scale == float(cfg.scale) and offset == float(cfg.offset), (rank, issued, scale, float(cfg.scale))
 
 
 def test_harness_quantizer_assigns_the_reference_config_states_on_resnet50():
