@@ -812,12 +812,27 @@ def install_into_ppq() -> None:
     REF_CONFIG.USING_CUDA_KERNEL = True
 
 
+_SAVED_PLUGIN_STATE: dict = {}       # what install_plugins_into_ppq(observers=True) replaced, for uninstall_from_ppq
+
+
 def uninstall_from_ppq() -> None:
-    """Undo :func:`install_into_ppq`: PPQ is back on its own torch path (USING_CUDA_KERNEL False, no extension)."""
+    """Undo :func:`install_into_ppq` AND :func:`install_plugins_into_ppq`: PPQ is back on its own torch path
+    (USING_CUDA_KERNEL False, no extension), its ``OBSERVER_TABLE`` holds its own observer classes again (entries this
+    package added are removed) and ``optim.calibration``'s two-phase type test points at its own classes.  The two ABC
+    registrations (hook, pass base class) cannot be withdrawn (``ABCMeta.register`` has no inverse) and are harmless:
+    they only make ``isinstance`` accept this package's objects."""
     from ppq.core import PPQ_CONFIG as REF_CONFIG
     from ppq.core.ffi import CUDA_COMPLIER as REF_COMPLIER
     REF_COMPLIER.__CUDA_EXTENTION__ = None
     REF_CONFIG.USING_CUDA_KERNEL = False
+    if _SAVED_PLUGIN_STATE:
+        import ppq.quantization.observer as ref_observer
+        import ppq.quantization.optim.calibration as ref_calibration
+        table = _SAVED_PLUGIN_STATE.pop('table')
+        ref_observer.OBSERVER_TABLE.clear()
+        ref_observer.OBSERVER_TABLE.update(table)
+        ref_calibration.TorchHistObserver = _SAVED_PLUGIN_STATE.pop('hist')
+        ref_calibration.TorchMSEObserver = _SAVED_PLUGIN_STATE.pop('mse')
 
 
 def install_plugins_into_ppq(observers: bool = True) -> None:
@@ -846,6 +861,9 @@ def install_plugins_into_ppq(observers: bool = True) -> None:
     if observers:
         import ppq.quantization.observer as ref_observer
         import ppq.quantization.optim.calibration as ref_calibration
+        if not _SAVED_PLUGIN_STATE:                                     # keep the ORIGINAL state across repeated installs
+            _SAVED_PLUGIN_STATE.update(table=dict(ref_observer.OBSERVER_TABLE), hist=ref_calibration.TorchHistObserver,
+                                       mse=ref_calibration.TorchMSEObserver)
         ref_observer.OBSERVER_TABLE.update(observer.OBSERVER_TABLE)
         ref_calibration.TorchHistObserver = observer.TorchHistObserver
         ref_calibration.TorchMSEObserver = observer.TorchMSEObserver

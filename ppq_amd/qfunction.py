@@ -177,8 +177,25 @@ def PPQLinearQuant_toInt(tensor: torch.Tensor, config) -> torch.Tensor:
     if config.policy.has_property(P.PER_CHANNEL): axis = config.channel_axis
     elif config.policy.has_property(P.PER_TENSOR): axis = None
     else: return tensor.type(dtype=dtype)                   # neither granularity: the reference casts the tensor as it is
-    return CUDA.LinearQuantize_ToInt(tensor, config.scale, config.offset, config.quant_min, config.quant_max,
-                                     rounding_value(config.rounding), axis, dtype)
+    if rounding_value(config.rounding) == 5:                # ROUND_TO_NEAR_INT: ppq_tensor_round raises this (utils/round.py:42-43)
+        raise NotImplementedError('Torch Tensor can not use this rounding policy(ROUND_TO_NEAR_INT) try ROUND_HALF_EVEN instead.')
+    scale, offset = config.scale, config.offset
+    if tensor.is_cuda:
+        dev = tensor.device
+        if scale.device != dev: scale = scale.to(dev)       # the reference's torch expression takes scale / offset from anywhere
+        if offset.device != dev: offset = offset.to(dev)
+        return CUDA.LinearQuantize_ToInt(tensor, scale, offset, config.quant_min, config.quant_max,
+                                         rounding_value(config.rounding), axis, dtype)
+    # A host-side tensor (an exporter converting stored weights): the reference evaluates its torch expression wherever the
+    # tensor lives.  There is no CPU implementation in this package -- the tensor is staged through the device, converted by
+    # the same kernel, and the integers come back to the host; without a device this raises like every other entry point.
+    if not torch.cuda.is_available():
+        raise RuntimeError('PPQLinearQuant_toInt: the tensor is on the host and no HIP device is available '
+                           '(ppq_amd has no CPU path by design)')
+    dev = scale.device if scale.is_cuda else torch.device('cuda', torch.cuda.current_device())
+    out = CUDA.LinearQuantize_ToInt(tensor.to(dev), scale.to(dev), offset.to(dev), config.quant_min, config.quant_max,
+                                    rounding_value(config.rounding), axis, dtype)
+    return out.to(tensor.device)
 
 
 def PPQuantFunction_toInt(tensor: torch.Tensor, config) -> torch.Tensor:

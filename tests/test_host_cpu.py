@@ -769,3 +769,34 @@ def test_to_int_dispatch_and_no_cpu_path():
     with pytest.raises(ValueError, match='Non-linear'): qfunction.PPQLinearQuant_toInt(t, FloatingQuantizationConfig())
     with pytest.raises(ValueError): qfunction.PPQuantFunction_toInt(t, FloatingQuantizationConfig())
     with pytest.raises(ValueError): qfunction.PPQuantFunction_toInt(t, LinearQuantizationConfig(dynamic=True))
+
+
+def test_uninstall_restores_the_reference_observer_table_and_type_test():
+    """install_plugins_into_ppq(observers=True) swaps PPQ's OBSERVER_TABLE entries and re-binds the two class names its
+    calibration pass type-tests (optim/calibration.py:196); uninstall_from_ppq() must put every one of them back,
+    also after a repeated install."""
+    from oracle import reference_import as RI
+    if RI.find_reference() is None: pytest.skip('reference not present on this machine')
+    RI.load()
+    import ppq.quantization.observer as ref_observer
+    import ppq.quantization.optim.calibration as ref_calibration
+    from ppq.core import PPQ_CONFIG as REF_CONFIG
+    from ppq.core.ffi import CUDA_COMPLIER as REF_COMPLIER
+
+    import ppq_amd
+    from ppq_amd import observer as ours
+    before_table = dict(ref_observer.OBSERVER_TABLE)
+    before = (ref_calibration.TorchHistObserver, ref_calibration.TorchMSEObserver, REF_CONFIG.USING_CUDA_KERNEL)
+    try:
+        ppq_amd.install_plugins_into_ppq(observers=True)
+        ppq_amd.install_plugins_into_ppq(observers=True)                   # twice: the saved state must stay the ORIGINAL one
+        assert ref_observer.OBSERVER_TABLE['kl'] is ours.TorchHistObserver and 'kl_channel' in ref_observer.OBSERVER_TABLE
+        assert ref_calibration.TorchHistObserver is ours.TorchHistObserver and REF_CONFIG.USING_CUDA_KERNEL is True
+        assert REF_COMPLIER.__CUDA_EXTENTION__ is ppq_amd.HIP_EXTENSION
+    finally:
+        ppq_amd.uninstall_from_ppq()
+    assert dict(ref_observer.OBSERVER_TABLE) == before_table and 'kl_channel' not in ref_observer.OBSERVER_TABLE
+    assert (ref_calibration.TorchHistObserver, ref_calibration.TorchMSEObserver) == before[:2]
+    assert REF_CONFIG.USING_CUDA_KERNEL is False and REF_COMPLIER.__CUDA_EXTENTION__ is None
+    ppq_amd.uninstall_from_ppq()                                           # idempotent
+    assert dict(ref_observer.OBSERVER_TABLE) == before_table
