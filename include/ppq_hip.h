@@ -40,9 +40,11 @@ typedef enum {
     PPQHIP_ERR_HIP = -3            /* a HIP runtime call failed (launch error, bad pointer ...) */
 } ppqhip_status;
 
+#define PPQHIP_ABI_VERSION 3   /* 2: quantile hints (round 3); 3: *_multi LSQ / min-max entry points, quantile sequence (round 4) */
+
 /* library / device introspection ------------------------------------------------------------- */
 const char* ppqhip_last_error(void);
-int ppqhip_version(void);                 /* ABI version, bumped on incompatible change (2: quantile hints) */
+int ppqhip_version(void);                 /* ABI version == PPQHIP_ABI_VERSION; bumped on incompatible change */
 int ppqhip_device_arch(char* buf, int n); /* gcnArchName of the current device, e.g. "gfx950:..." */
 
 /* linear (integer) fake quant ---------------------------------------------------------------- */
@@ -97,6 +99,24 @@ int ppqhip_fq_linear_c_bwd(const float* x, const float* scale, const float* offs
                            const float* grad_y, float* grad_x, float* grad_s, int64_t n,
                            int64_t num_channel, int64_t elem_per_channel,
                            int clip_min, int clip_max, int rounding, void* stream);
+
+/* LSQ backward of MANY per-channel tensors in one launch -- what a block-wise LSQ step needs for all the weights of its
+ * block (LearnedStepSizePass.finetune, optim/training.py:728-826, calls CuLSQ_LC.backward -> QuantizeTensor_LC_B once per
+ * weight per step, algorithm/training.py:63-90).  Per job exactly ppqhip_fq_linear_c_bwd: grad_x and grad_s OVERWRITTEN.
+ * One workgroup owns one channel: no atomics, no memset, fixed summation order (grad_x bit-identical to the per-tensor entry
+ * point; grad_s too when outer == 1 and 256 <= elem_per_channel <= 4096, else equal to float-summation tolerance).
+ * The job table travels in the kernel arguments (32 jobs per launch): nothing is uploaded, graph-capturable. */
+typedef struct ppqhip_lsq_job {
+    const float* x;
+    const float* scale;
+    const float* offset;
+    const float* grad_y;
+    float* grad_x;
+    float* grad_s;
+    int64_t n, num_channel, elem_per_channel;
+    int32_t clip_min, clip_max;
+} ppqhip_lsq_job;
+int ppqhip_fq_linear_c_bwd_multi(const ppqhip_lsq_job* jobs, int num_jobs, int rounding, void* stream);
 
 /* low-precision float (FP8 E4M3 / E5M2 / generic E,M) fake quant ------------------------------ */
 /* replaces QuantizeTensor_FT, floating.cu:57-75 (CUDA.FloatingQuantize_T ffi.py:272-288);
@@ -242,6 +262,23 @@ int ppqhip_minmax_t(const float* x, int64_t n, float* minmax, void* workspace, v
 /* per channel: mins[c], maxs[c] ACCUMULATE (seed with +inf / -inf). */
 int ppqhip_minmax_c(const float* x, int64_t n, int64_t num_channel, int64_t elem_per_channel,
                     float* mins, float* maxs, void* stream);
+
+/* per-channel min / max of MANY tensors in one launch: all the weights ParameterQuantizePass observes
+ * (optim/parameters.py:156-215 -> TorchMinMaxObserver.observe per parameter, observer/range.py:99-107).  Per job exactly
+ * ppqhip_minmax_c (bit-identical: min / max are order independent).  `fresh` != 0: mins / maxs are OVERWRITTEN instead of
+ * accumulated (the caller need not seed them with +-inf); allowed only when n == num_channel * elem_per_channel (channel
+ * axis outermost) and elem_per_channel <= 8192, i.e. one wave owns a channel -- refused otherwise.
+ * `device_table`: caller-owned device memory of ppqhip_minmax_c_multi_table_bytes(num_jobs) bytes; upload = 1 on the first
+ * call and whenever `jobs` changed (see ppqhip_fq_linear_multi). */
+typedef struct ppqhip_minmax_c_job {
+    const float* x;
+    float* mins;
+    float* maxs;
+    int64_t n, num_channel, elem_per_channel;
+    int32_t fresh, reserved;
+} ppqhip_minmax_c_job;
+int64_t ppqhip_minmax_c_multi_table_bytes(int num_jobs);
+int ppqhip_minmax_c_multi(const ppqhip_minmax_c_job* jobs, int num_jobs, void* device_table, int upload, void* stream);
 
 /* per-channel sums in double, deterministic order: sums[c] += sum of channel c.  The DC term of
  * BiasCorrectionPass.collect_bias (ppq/quantization/optim/training.py:438-448: torch.mean over

@@ -19,6 +19,8 @@ c_int = ctypes.c_int
 c_flt = ctypes.c_float
 c_vp = ctypes.c_void_p
 
+ABI_VERSION = 3              # == PPQHIP_ABI_VERSION of include/ppq_hip.h; a library of any other version is refused below
+
 
 class ProfEntry(ctypes.Structure):
     _fields_ = [('name', ctypes.c_char * 48), ('launches', ctypes.c_int64),
@@ -38,6 +40,7 @@ PROTOTYPES = {
                                        c_vp]),
     'ppqhip_fq_linear_c_bwd': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_int,
                                        c_int, c_int, c_vp]),
+    'ppqhip_fq_linear_c_bwd_multi': (c_int, [c_vp, c_int, c_int, c_vp]),
     'ppqhip_fq_float_t': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_flt, c_flt, c_int, c_vp]),
     'ppqhip_fq_float_c': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_int, c_int, c_flt, c_flt,
                                   c_int, c_vp]),
@@ -55,6 +58,8 @@ PROTOTYPES = {
     'ppqhip_minmax_workspace_bytes': (c_i64, [c_i64]),
     'ppqhip_minmax_t': (c_int, [c_f32p, c_i64, c_f32p, c_vp, c_vp]),
     'ppqhip_minmax_c': (c_int, [c_f32p, c_i64, c_i64, c_i64, c_f32p, c_f32p, c_vp]),
+    'ppqhip_minmax_c_multi_table_bytes': (c_i64, [c_int]),
+    'ppqhip_minmax_c_multi': (c_int, [c_vp, c_int, c_vp, c_int, c_vp]),
     'ppqhip_fq_linear_multi_table_bytes': (c_i64, [c_int]),
     'ppqhip_fq_linear_multi': (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     'ppqhip_float_scale_search_table_bytes': (c_i64, [c_int]),
@@ -115,6 +120,12 @@ for _name, (_res, _args) in PROTOTYPES.items():
     _fn = getattr(lib, _name)       # AttributeError here == header/library mismatch: fail loudly
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+# The library is git-ignored and built separately: a stale copy would be called with shifted arguments.
+if lib.ppqhip_version() != ABI_VERSION:
+    raise ImportError(f'{LIB_PATH} has ABI version {lib.ppqhip_version()}, this package needs {ABI_VERSION}: rebuild it '
+                      '(`make -C ppq_amd/csrc` or `python -c "import __graft_entry__ as g; g.build()"`)')
 
 
 def last_error() -> str:

@@ -555,6 +555,91 @@ __global__ __launch_bounds__(kBlock) void fq_linear_multi_kernel(const FqMultiAr
     }
 }
 
+// ---- LSQ backward of many per-channel tensors, one launch ------------------------------------------
+// A block-wise LSQ step (LearnedStepSizePass, optim/training.py:728-826) back-propagates through every weight of the
+// block: 5-10 tensors of 0.01 .. 10 MB, each a memset + a kernel of ~6 us in the per-tensor path (BENCH_r03: 224 launches
+// of 6.4 us on 3.7 MB = 0.07 of the roofline).  Here ONE launch serves them all: workgroup b -> (job, channel c); it
+// walks the `outer` rows of its channel with the row kernel's loop (U 16-B (x, dy) pairs in flight), block-reduces and
+// STORES grad_s[c] -- one workgroup owns a channel, so there is no atomic, no memset and the sum order is fixed.
+// With outer == 1 and 256 <= elem_per_channel <= 4096 (convolution weights, channel axis 0) the order is exactly the
+// per-tensor row kernel's, so grad_s is bit-identical to ppqhip_fq_linear_c_bwd; grad_x always is.
+// The job table travels BY VALUE in the kernel arguments (<= 32 jobs, 2.7 KB): dy is a fresh autograd tensor every step,
+// so a device-resident table would need an upload per step; by value it costs nothing and is graph-capturable.
+constexpr int kLsqMultiMax = 32;
+struct LsqJob {
+    const float* x;
+    const float* dy;
+    float* gx;
+    float* gs;
+    const float* scale;
+    const float* offset;
+    uint32_t C, epc, outer, vec_ok;
+    int qmin, qmax;
+    float grad_factor;
+    uint32_t pad;
+};
+struct LsqMultiArgs {
+    LsqJob jobs[kLsqMultiMax];
+    uint32_t first_block[kLsqMultiMax];
+    uint32_t count;
+    int rounding;
+};
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void fq_linear_c_bwd_multi_kernel(const LsqMultiArgs args) {
+    __shared__ float lds[kBlock / kWave];
+    uint32_t lo = 0, hi = args.count;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (args.first_block[mid] <= blockIdx.x) lo = mid; else hi = mid;
+    }
+    const LsqJob& j = args.jobs[lo];                    // kernel-argument segment: scalar loads
+    const uint32_t c = blockIdx.x - args.first_block[lo];
+    const float s = j.scale[c];
+    const float rcp_s = 1.0f / s;
+    const float o = __builtin_roundf(j.offset[c]);
+    const int oi = f2i_sat(o);
+    const uint32_t epc = j.epc, C = j.C;
+    const int qmin = j.qmin, qmax = j.qmax, rounding = args.rounding;
+    float acc = 0.f;
+    for (uint32_t n = 0; n < j.outer; n++) {
+        const size_t base = ((size_t)n * C + c) * epc;
+        if (j.vec_ok) {   // epc % 4 == 0, 16-B aligned bases
+            const float4* xv = reinterpret_cast<const float4*>(j.x + base);
+            const float4* dv = reinterpret_cast<const float4*>(j.dy + base);
+            float4* gv = reinterpret_cast<float4*>(j.gx + base);
+            constexpr int U = PPQHIP_LSQ_C_U;
+            const uint32_t v1 = epc >> 2;
+            for (uint32_t v = threadIdx.x; v < v1; v += kBlock * U) {
+                float4 a[U], d[U];
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t at = min(v + u * kBlock, v1 - 1);
+                    a[u] = xv[at]; d[u] = dv[at];
+                }
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    if (v + u * kBlock >= v1) break;
+                    float4 g;
+                    acc += lsq_bwd_elem<true, R>(a[u].x, d[u].x, s, rcp_s, o, oi, qmin, qmax, rounding, &g.x);
+                    acc += lsq_bwd_elem<true, R>(a[u].y, d[u].y, s, rcp_s, o, oi, qmin, qmax, rounding, &g.y);
+                    acc += lsq_bwd_elem<true, R>(a[u].z, d[u].z, s, rcp_s, o, oi, qmin, qmax, rounding, &g.z);
+                    acc += lsq_bwd_elem<true, R>(a[u].w, d[u].w, s, rcp_s, o, oi, qmin, qmax, rounding, &g.w);
+                    gv[v + u * kBlock] = g;
+                }
+            }
+        } else {
+            for (uint32_t e = threadIdx.x; e < epc; e += kBlock) {
+                float g;
+                acc += lsq_bwd_elem<true, R>(j.x[base + e], j.dy[base + e], s, rcp_s, o, oi, qmin, qmax, rounding, &g);
+                j.gx[base + e] = g;
+            }
+        }
+    }
+    const float tot = block_sum(acc, lds);
+    if (threadIdx.x == 0) j.gs[c] = tot * j.grad_factor;
+}
+
 }  // namespace ppqhip
 
 using namespace ppqhip;
@@ -759,6 +844,48 @@ int ppqhip_fq_linear_c_bwd(const float* x, const float* scale, const float* offs
                            grad_factor, rounding);
     }
     return finish_launch("fq_linear_c_bwd");
+}
+
+int ppqhip_fq_linear_c_bwd_multi(const ppqhip_lsq_job* jobs, int num_jobs, int rounding, void* stream) {
+    if (num_jobs <= 0) return PPQHIP_OK;
+    if (jobs == nullptr) { set_error("fq_linear_c_bwd_multi: jobs is null"); return PPQHIP_ERR_INVALID_VALUE; }
+    hipStream_t s = (hipStream_t)stream;
+    double bytes = 0.0;
+    for (int k = 0; k < num_jobs; k++) {
+        const ppqhip_lsq_job& j = jobs[k];
+        if (int st = validate_n(j.n, "fq_linear_c_bwd_multi")) return st;
+        if (int st = validate_channels(j.n, j.num_channel, j.elem_per_channel, "fq_linear_c_bwd_multi")) return st;
+        if (!j.x || !j.scale || !j.offset || !j.grad_y || !j.grad_x || !j.grad_s) {
+            set_error("fq_linear_c_bwd_multi: job %d has a null pointer", k); return PPQHIP_ERR_INVALID_VALUE;
+        }
+        bytes += 12.0 * (double)j.n;
+    }
+    LaunchScope scope(K_FQ_LINEAR_C_BWD, bytes, s);
+    for (int base = 0; base < num_jobs; base += kLsqMultiMax) {
+        const int count = (num_jobs - base) < kLsqMultiMax ? (num_jobs - base) : kLsqMultiMax;
+        LsqMultiArgs args;
+        args.count = (uint32_t)count; args.rounding = rounding;
+        uint32_t blocks = 0;
+        for (int k = 0; k < count; k++) {
+            const ppqhip_lsq_job& src = jobs[base + k];
+            LsqJob& d = args.jobs[k];
+            d.x = src.x; d.dy = src.grad_y; d.gx = src.grad_x; d.gs = src.grad_s; d.scale = src.scale; d.offset = src.offset;
+            d.C = (uint32_t)src.num_channel; d.epc = (uint32_t)src.elem_per_channel;
+            d.outer = (uint32_t)(src.n / (src.num_channel * src.elem_per_channel));
+            d.vec_ok = (src.elem_per_channel % 4 == 0 && aligned16(src.x) && aligned16(src.grad_y) && aligned16(src.grad_x)) ? 1u : 0u;
+            d.qmin = src.clip_min; d.qmax = src.clip_max;
+            d.grad_factor = (float)(1.0 / sqrt((double)src.n * (double)src.clip_max));      // rsqrtf(((double)n * clip_max)): linear.cu:402
+            d.pad = 0;
+            args.first_block[k] = blocks;
+            blocks += d.C;
+        }
+        for (int k = count; k < kLsqMultiMax; k++) args.first_block[k] = blocks;
+        if (rounding == ROUND_HALF_EVEN)
+            hipLaunchKernelGGL((fq_linear_c_bwd_multi_kernel<ROUND_HALF_EVEN>), dim3(blocks), dim3(kBlock), 0, s, args);
+        else
+            hipLaunchKernelGGL((fq_linear_c_bwd_multi_kernel<-1>), dim3(blocks), dim3(kBlock), 0, s, args);
+    }
+    return finish_launch("fq_linear_c_bwd_multi");
 }
 
 }  // extern "C"

@@ -9,6 +9,7 @@
 //   isotone_t            replaces Isotone_T (sort.cu:61-73): top-2 / bottom-2 reduction.
 #include <cmath>
 #include <cstdlib>
+#include <vector>
 
 #include "common.hpp"
 
@@ -393,6 +394,71 @@ static int validate(int64_t n, const char* what) {
     return PPQHIP_OK;
 }
 
+// ---- per-channel min / max of MANY tensors, one launch ----------------------------------------------
+// ParameterQuantizePass (optim/parameters.py:156-215) observes every weight of the graph once: 54 tensors of 0.01 .. 9 MB
+// for ResNet-50, each a ~7 us launch in the per-tensor path (profiles/r03_bench_kernel_stats.csv: 270 minmax_c launches).
+// One launch here: the job table is device resident (weights do not move), the kernel arguments carry the prefix of work
+// items, ONE WAVE per item as in minmax_c_wave_kernel: item -> (job, row, chunk of <= 8192 elements of that row).
+// A job whose channels each consist of exactly one item (outer == 1, one chunk: every convolution / Gemm weight with
+// channel axis 0) may be marked `fresh`: its wave STORES min / max, so the caller need not seed the buffers with +-inf
+// (three tiny launches per weight otherwise); all other jobs fold into seeded buffers with the float atomics.
+// min / max are order independent: results are bit-identical to ppqhip_minmax_c whatever the geometry.
+constexpr int kMMCMultiMax = 128;
+struct MMCJob {
+    const float* x;
+    float* mins;
+    float* maxs;
+    uint32_t C, epc, outer, chunks;
+    uint32_t vec_ok, fresh;
+};
+struct MMCMultiArgs {
+    uint32_t first_item[kMMCMultiMax];
+    uint32_t count;
+    uint32_t items;
+    const MMCJob* jobs;
+};
+
+__global__ __launch_bounds__(kBlock) void minmax_c_multi_kernel(const MMCMultiArgs args) {
+    const uint32_t item = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
+    if (item >= args.items) return;                                  // wave-uniform
+    const uint32_t lane = threadIdx.x & 63;
+    uint32_t lo = 0, hi = args.count;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (args.first_item[mid] <= item) lo = mid; else hi = mid;
+    }
+    const MMCJob j = args.jobs[__builtin_amdgcn_readfirstlane(lo)];   // wave-uniform address: scalar loads
+    const uint32_t local = item - args.first_item[lo];
+    const uint32_t row = local / j.chunks, chunk = local - row * j.chunks;
+    const uint32_t c = row % j.C;
+    const uint32_t e0 = chunk * kMMCChunk, e1 = min(e0 + kMMCChunk, j.epc);
+    const float* xr = j.x + (size_t)row * j.epc;
+    float mn = INFINITY, mx = -INFINITY;
+    if (j.vec_ok) {   // epc % 4 == 0, base 16-B aligned
+        const float4* xv = reinterpret_cast<const float4*>(xr);
+        const uint32_t v1 = e1 >> 2;
+        constexpr int U = 8;
+        for (uint32_t v0 = (e0 >> 2) + lane; v0 < v1; v0 += 64 * U) {
+            float4 a[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) a[u] = xv[min(v0 + 64 * u, v1 - 1)];       // clamped: loads stay unconditional
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                mn = fminf(fminf(mn, a[u].x), fminf(a[u].y, fminf(a[u].z, a[u].w)));
+                mx = fmaxf(fmaxf(mx, a[u].x), fmaxf(a[u].y, fmaxf(a[u].z, a[u].w)));
+            }
+        }
+    } else {
+        for (uint32_t e = e0 + lane; e < e1; e += 64) { const float a = xr[e]; mn = fminf(mn, a); mx = fmaxf(mx, a); }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    if (lane == 0) {
+        if (j.fresh) { j.mins[c] = mn; j.maxs[c] = mx; }                // the only item of its channel (host-checked)
+        else if (mn <= mx) { atomic_min_f32(&j.mins[c], mn); atomic_max_f32(&j.maxs[c], mx); }
+    }
+}
+
 }  // namespace ppqhip
 
 using namespace ppqhip;
@@ -568,6 +634,70 @@ int ppqhip_isotone_t(const float* x, int64_t n, float* dest, void* workspace, vo
     hipLaunchKernelGGL(isotone_kernel, dim3(1), dim3(kBlock), 0, s, (const float*)nullptr, 0u, (const Top2*)partial,
                        (uint32_t)grid, (Top2*)nullptr, dest, (uint32_t)n);
     return finish_launch("isotone_t");
+}
+
+int64_t ppqhip_minmax_c_multi_table_bytes(int num_jobs) {
+    return num_jobs > 0 ? (int64_t)sizeof(MMCJob) * num_jobs : 0;
+}
+
+int ppqhip_minmax_c_multi(const ppqhip_minmax_c_job* jobs, int num_jobs, void* device_table, int upload, void* stream) {
+    if (num_jobs <= 0) return PPQHIP_OK;
+    if (jobs == nullptr || device_table == nullptr) {
+        set_error("minmax_c_multi: jobs / device_table is null"); return PPQHIP_ERR_INVALID_VALUE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    double bytes = 0.0;
+    for (int k = 0; k < num_jobs; k++) {
+        const ppqhip_minmax_c_job& j = jobs[k];
+        if (int st = validate(j.n, "minmax_c_multi")) return st;
+        if (j.num_channel <= 0 || j.elem_per_channel <= 0 || j.n % (j.num_channel * j.elem_per_channel) != 0) {
+            set_error("minmax_c_multi: job %d: bad channel geometry", k); return PPQHIP_ERR_INVALID_VALUE;
+        }
+        if (!j.x || !j.mins || !j.maxs) { set_error("minmax_c_multi: job %d has a null pointer", k); return PPQHIP_ERR_INVALID_VALUE; }
+        const int64_t chunks = (j.elem_per_channel + kMMCChunk - 1) / kMMCChunk;
+        if (j.fresh && (j.n != j.num_channel * j.elem_per_channel || chunks != 1)) {
+            set_error("minmax_c_multi: job %d: `fresh` needs outer == 1 and elem_per_channel <= %u (one wave per channel)", k, kMMCChunk);
+            return PPQHIP_ERR_INVALID_VALUE;
+        }
+        if ((j.n / j.elem_per_channel) * chunks > 0x7fffffffLL) { set_error("minmax_c_multi: job %d: too many rows", k); return PPQHIP_ERR_INVALID_VALUE; }
+        bytes += 4.0 * (double)j.n;
+    }
+    LaunchScope scope(K_MINMAX_C, bytes, s);
+    for (int base = 0; base < num_jobs; base += kMMCMultiMax) {
+        const int count = (num_jobs - base) < kMMCMultiMax ? (num_jobs - base) : kMMCMultiMax;
+        MMCMultiArgs args;
+        args.count = (uint32_t)count;
+        args.jobs = (const MMCJob*)device_table + base;
+        std::vector<MMCJob> table(upload ? count : 0);
+        uint64_t items = 0;
+        for (int k = 0; k < count; k++) {
+            const ppqhip_minmax_c_job& src = jobs[base + k];
+            const uint32_t chunks = (uint32_t)((src.elem_per_channel + kMMCChunk - 1) / kMMCChunk);
+            const uint64_t rows = (uint64_t)(src.n / src.elem_per_channel);
+            args.first_item[k] = (uint32_t)items;
+            items += rows * chunks;
+            if (items > 0x7fffffffULL) { set_error("minmax_c_multi: too many work items in one call"); return PPQHIP_ERR_INVALID_VALUE; }
+            if (upload) {
+                MMCJob& d = table[k];
+                d.x = src.x; d.mins = src.mins; d.maxs = src.maxs;
+                d.C = (uint32_t)src.num_channel; d.epc = (uint32_t)src.elem_per_channel;
+                d.outer = (uint32_t)(rows / (uint64_t)src.num_channel); d.chunks = chunks;
+                d.vec_ok = (aligned16(src.x) && src.elem_per_channel % 4 == 0) ? 1u : 0u;
+                d.fresh = src.fresh ? 1u : 0u;
+            }
+        }
+        for (int k = count; k < kMMCMultiMax; k++) args.first_item[k] = (uint32_t)items;
+        args.items = (uint32_t)items;
+        if (upload) {
+            // pageable source: the runtime stages the copy before returning, `table` may go out of scope
+            if (int st = check_hip(hipMemcpyAsync((MMCJob*)device_table + base, table.data(), sizeof(MMCJob) * count,
+                                                  hipMemcpyHostToDevice, s), "minmax_c_multi table upload"))
+                return st;
+        }
+        const uint32_t blocks = (uint32_t)((items + kBlock / kWave - 1) / (kBlock / kWave));
+        hipLaunchKernelGGL(minmax_c_multi_kernel, dim3(blocks), dim3(kBlock), 0, s, args);
+    }
+    return finish_launch("minmax_c_multi");
 }
 
 }  // extern "C"

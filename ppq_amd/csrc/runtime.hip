@@ -96,7 +96,7 @@ extern "C" {
 
 const char* ppqhip_last_error(void) { return g_err; }
 
-int ppqhip_version(void) { return 2; }   // 2: ppqhip_quantile_t takes a hint, ppqhip_quantile_job carries one (round 3)
+int ppqhip_version(void) { return PPQHIP_ABI_VERSION; }   // include/ppq_hip.h; ppq_amd/_lib.py refuses any other value
 
 int ppqhip_device_arch(char* buf, int n) {
     int dev = 0;

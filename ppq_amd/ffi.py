@@ -138,6 +138,10 @@ _FQ_FLOAT_JOB = np.dtype([('x', '<u8'), ('scale', '<u8'), ('offset', '<u8'), ('o
                           ('clip_min', '<f4'), ('clip_max', '<f4')])
 _FLOAT_SEARCH_JOB = np.dtype([('x', '<u8'), ('rows', '<i8'), ('row_len', '<i8'), ('exponent', '<i4'), ('mantissa', '<i4'),
                               ('clip_min', '<f4'), ('clip_max', '<f4')])
+_LSQ_JOB = np.dtype([('x', '<u8'), ('scale', '<u8'), ('offset', '<u8'), ('grad_y', '<u8'), ('grad_x', '<u8'), ('grad_s', '<u8'),
+                     ('n', '<i8'), ('num_channel', '<i8'), ('elem_per_channel', '<i8'), ('clip_min', '<i4'), ('clip_max', '<i4')])
+_MINMAX_C_JOB = np.dtype([('x', '<u8'), ('mins', '<u8'), ('maxs', '<u8'), ('n', '<i8'), ('num_channel', '<i8'),
+                          ('elem_per_channel', '<i8'), ('fresh', '<i4'), ('reserved', '<i4')])
 _QUANTILE_JOB = np.dtype([('x', '<u8'), ('dest', '<u8'), ('hint', '<u8'), ('n', '<i8')])
 
 # Quantile_T(source, q) is stateless in the reference, but calibration calls it batch after batch from the same observer on
@@ -357,6 +361,43 @@ class _HipExtension:
                                               grad_s.data_ptr(), v.numel(), C, epc, int(clip_min), int(clip_max),
                                               int(rounding), _stream()))
         return [grad_x, grad_s]
+
+    @ staticmethod
+    def QuantizeTensor_LC_B_Multi(values, scales, offsets, grad_ys, clip_mins, clip_maxs, rounding: int, channel_axes,
+                                  grad_xs=None, grad_ss=None):
+        """``QuantizeTensor_LC_B`` for MANY per-channel tensors in ONE launch (``ppqhip_fq_linear_c_bwd_multi``): all the
+        weights of a block in a block-wise LSQ step.  Returns ``(grad_xs, grad_ss)``; pass preallocated lists to have them
+        written in place (they are what the caller installs as ``.grad``).  Per item the results are those of
+        ``QuantizeTensor_LC_B`` (grad_x bit for bit; grad_s bit for bit when the per-tensor path itself sums in a fixed
+        order, see include/ppq_hip.h)."""
+        n = len(values)
+        if n == 0: return [], []
+        if not (len(scales) == len(offsets) == len(grad_ys) == len(clip_mins) == len(clip_maxs) == len(channel_axes) == n):
+            raise RuntimeError(_KERNEL_FAILURE + 'QuantizeTensor_LC_B_Multi: argument lists differ in length')
+        dev = values[0].device
+        jobs = np.empty(n, dtype=_LSQ_JOB)
+        keep, gxs, gss = [], [], []
+        for k in range(n):
+            _f32(values[k], 'Value'); _f32(scales[k], 'Scale'); _f32(offsets[k], 'Offset'); _f32(grad_ys[k], 'Gard')
+            if values[k].device != dev or grad_ys[k].device != dev:
+                raise RuntimeError(_KERNEL_FAILURE + 'QuantizeTensor_LC_B_Multi: one device per call')
+            v = values[k].contiguous(); g = grad_ys[k].contiguous()
+            sc, of = scales[k].contiguous(), offsets[k].contiguous()
+            C, epc = _geometry(v.shape, channel_axes[k])
+            if sc.numel() != C or of.numel() != C:
+                raise RuntimeError(_KERNEL_FAILURE + f'QuantizeTensor_LC_B_Multi: item {k} needs {C} scales / offsets')
+            gx = torch.empty_like(g) if grad_xs is None else grad_xs[k]
+            gs = torch.empty_like(sc) if grad_ss is None else grad_ss[k]
+            if grad_xs is not None and (gx.shape != g.shape or not gx.is_contiguous() or gx.dtype != _F32):
+                raise RuntimeError(_KERNEL_FAILURE + f'QuantizeTensor_LC_B_Multi: grad_xs[{k}] must be a contiguous float32 tensor shaped like the value')
+            if grad_ss is not None and (gs.numel() != C or not gs.is_contiguous() or gs.dtype != _F32):
+                raise RuntimeError(_KERNEL_FAILURE + f'QuantizeTensor_LC_B_Multi: grad_ss[{k}] must be a contiguous float32[{C}]')
+            keep.append((v, g, sc, of)); gxs.append(gx); gss.append(gs)
+            jobs[k] = (v.data_ptr(), sc.data_ptr(), of.data_ptr(), g.data_ptr(), gx.data_ptr(), gs.data_ptr(), v.numel(), C, epc,
+                       int(clip_mins[k]), int(clip_maxs[k]))
+        with _DeviceOf(values[0]):
+            _raise(lib.ppqhip_fq_linear_c_bwd_multi(jobs.ctypes.data, n, int(rounding), _stream()))
+        return gxs, gss
 
     # ---- floating ----------------------------------------------------------------------------
     @ staticmethod
@@ -718,6 +759,49 @@ class _HipExtension:
             _raise(lib.ppqhip_minmax_c(v.data_ptr(), v.numel(), C, epc, mins.data_ptr(), maxs.data_ptr(), _stream()))
 
     @ staticmethod
+    def MinMax_C_Multi(values, channel_axes, mins, maxs, fresh: bool = False, table=None):
+        """``MinMax_C`` for MANY tensors in ONE launch (``ppqhip_minmax_c_multi``): every weight ParameterQuantizePass observes.
+        ``mins[k]`` / ``maxs[k]``: contiguous float32[C_k]; accumulated into (seed with +-inf) unless ``fresh``: then they are
+        OVERWRITTEN, allowed for tensors whose channel axis is the outermost one with at most 8192 elements per channel
+        (one wave per channel; ``minmax_c_fresh_ok``).  ``fresh`` may be a list with one flag per item; as a single True it
+        applies to the items that qualify, the others must have been seeded by the caller and are accumulated.
+        ``table``: an optional uint8 device tensor to reuse as the job table (returned)."""
+        n = len(values)
+        if n == 0: return table
+        if not (len(channel_axes) == len(mins) == len(maxs) == n):
+            raise RuntimeError(_KERNEL_FAILURE + 'MinMax_C_Multi: argument lists differ in length')
+        dev = values[0].device
+        jobs = np.empty(n, dtype=_MINMAX_C_JOB)
+        keep = []
+        for k in range(n):
+            _f32(values[k], 'Value'); _f32(mins[k], 'Mins'); _f32(maxs[k], 'Maxs')
+            if values[k].device != dev: raise RuntimeError(_KERNEL_FAILURE + 'MinMax_C_Multi: one device per call')
+            v = _dense(values[k], channel_axes[k])
+            C, epc = _geometry(v.shape, channel_axes[k])
+            if mins[k].numel() != C or maxs[k].numel() != C or not mins[k].is_contiguous() or not maxs[k].is_contiguous():
+                raise RuntimeError(_KERNEL_FAILURE + f'MinMax_C_Multi: item {k} needs contiguous float32[{C}] mins / maxs')
+            owns = bool(fresh[k] if isinstance(fresh, (list, tuple)) else fresh)
+            if owns and not (v.numel() == C * epc and epc <= 8192):
+                if isinstance(fresh, (list, tuple)):
+                    raise RuntimeError(_KERNEL_FAILURE + f'MinMax_C_Multi: item {k} cannot be `fresh` (see minmax_c_fresh_ok)')
+                owns = False
+            keep.append(v)
+            jobs[k] = (v.data_ptr(), mins[k].data_ptr(), maxs[k].data_ptr(), v.numel(), C, epc, 1 if owns else 0, 0)
+        need = int(lib.ppqhip_minmax_c_multi_table_bytes(n))
+        if table is None or table.numel() < need or table.device != dev:
+            table = torch.empty(need, dtype=torch.uint8, device=dev)
+        with _DeviceOf(values[0]):
+            _raise(lib.ppqhip_minmax_c_multi(jobs.ctypes.data, n, table.data_ptr(), 1, _stream()))
+        return table
+
+    @ staticmethod
+    def minmax_c_fresh_ok(value, channel_axis: int) -> bool:
+        """True when ``MinMax_C_Multi(fresh=True)`` will OVERWRITE this item's mins / maxs (see there)."""
+        v = _dense(value, channel_axis)
+        C, epc = _geometry(v.shape, channel_axis)
+        return v.numel() == C * epc and epc <= 8192
+
+    @ staticmethod
     def ChannelSum(value, channel_axis: int, sums) -> None:
         """sums (float64 [C]) += per-channel sum of value; deterministic double accumulation."""
         _f32(value, 'Value'); _check(sums, torch.float64, 'Sums(Expect to be FP64)')
@@ -895,6 +979,12 @@ class CUDA:
         return HIP_EXTENSION.QuantizeTensor_LC_B(tensor, scales, offsets, dy, minimum, maximum, rounding, channel_axis)
 
     @ staticmethod
+    def LinearQuantize_C_B_Multi(tensors, scales, offsets, dys, minimums, maximums, channel_axes, rounding: int,
+                                 grad_xs=None, grad_ss=None):
+        return HIP_EXTENSION.QuantizeTensor_LC_B_Multi(tensors, scales, offsets, dys, minimums, maximums, rounding, channel_axes,
+                                                       grad_xs, grad_ss)
+
+    @ staticmethod
     def Histogram_T(tensor, histogram, scale: float, clip_outliers: bool = True):
         HIP_EXTENSION.Histogram_T(tensor, scale, clip_outliers, histogram)
         return histogram
@@ -1001,6 +1091,14 @@ class CUDA:
     def MinMax_C(tensor, channel_axis: int, mins, maxs):
         HIP_EXTENSION.MinMax_C(tensor, channel_axis, mins, maxs)
         return mins, maxs
+
+    @ staticmethod
+    def MinMax_C_Multi(tensors, channel_axes, mins, maxs, fresh: bool = False, table=None):
+        return HIP_EXTENSION.MinMax_C_Multi(tensors, channel_axes, mins, maxs, fresh, table)
+
+    @ staticmethod
+    def minmax_c_fresh_ok(tensor, channel_axis: int) -> bool:
+        return HIP_EXTENSION.minmax_c_fresh_ok(tensor, channel_axis)
 
     @ staticmethod
     def ChannelSum(tensor, channel_axis: int, sums):

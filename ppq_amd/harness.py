@@ -422,16 +422,20 @@ def quantize_graph(graph: BaseGraph, activation_algorithm: str = 'kl', per_chann
 class ParameterQuantizePass:
     """optim/parameters.py:156-215: observe + render every INITIAL parameter config."""
     def optimize(self, graph: BaseGraph, **kwargs) -> None:
-        observers = []
+        from .observer import ObservationQueue, render_observers
+        observers, queue = [], ObservationQueue()
         for op in graph.operations.values():
             if not isinstance(op, QuantableOperation): continue
             for config, var in op.config_with_variable:
                 if var.is_parameter and is_initial(config):
                     ob = TensorObserverFactroy.build_observer(var, config)
-                    ob.observe(var.value)
+                    ob.queue = queue                   # the statistics of ALL parameters: one launch per kind (per-channel
+                    ob.observe(var.value)              # ranges -> ppqhip_minmax_c_multi), flushed by the first render
                     observers.append(ob)
-        from .observer import render_observers
+        queue.flush()
+        self.launches = queue.launches
         render_observers(observers)
+        for ob in observers: ob.queue = None
 
 
 class ParameterBakingPass:

@@ -84,10 +84,18 @@ def _flush_deferred_sets(pending: list) -> None:
     by_dev: Dict[object, list] = {}
     for item in pending: by_dev.setdefault(torch.device(item[3]), []).append(item)
     for dev, items in by_dev.items():
-        host = np.array([[s, o] for _, s, o, _ in items], dtype=np.float32).reshape(-1)
-        parts = torch.from_numpy(host).to(dev).unbind(0)
-        for k, (config, _, _, _) in enumerate(items):
-            config.scale, config.offset = parts[2 * k], parts[2 * k + 1]
+        # per-tensor items contribute (scale, offset), per-channel items their C scales then their C offsets
+        chunks = [np.asarray(v, dtype=np.float32).reshape(-1) for _, s, o, _ in items for v in (s, o)]
+        flat = torch.from_numpy(np.concatenate(chunks)).to(dev)
+        pos = 0
+        for k, (config, s, _, _) in enumerate(items):
+            if isinstance(s, (list, tuple)):                        # per channel: float32[C] views (range.py:130-131)
+                C = len(s)
+                config.scale, config.offset = flat[pos: pos + C], flat[pos + C: pos + 2 * C]
+                pos += 2 * C
+            else:                                                   # per tensor: 0-d views
+                config.scale, config.offset = flat[pos], flat[pos + 1]
+                pos += 2
             set_activated(config)
 
 
@@ -104,6 +112,8 @@ class ObservationQueue:
     4.0 / 4.7 / 5.0 TB/s for the histogram launch)."""
     def __init__(self, max_pending_bytes: int = 4 << 30):
         self._minmax = []                  # (tensor, slots)
+        self._minmax_c = []                # (tensor, channel_axis, mins, maxs, fresh)
+        self._c_tables = {}                # device -> job-table buffer of the per-channel launch, reused
         self._hist = {}                    # (asymmetric, bins, device) -> [(tensor, rows, p0, p1)]
         self._quantile = {}                # (q, device) -> [(tensor, dest)]
         self._bytes = 0
@@ -112,7 +122,7 @@ class ObservationQueue:
         self.recorder: Optional[list] = None   # RuntimeCalibrationPass(reuse_activations=True): (observer, tensor) of phase 1
 
     def __len__(self):
-        return (len(self._minmax) + sum(len(v) for v in self._hist.values())
+        return (len(self._minmax) + len(self._minmax_c) + sum(len(v) for v in self._hist.values())
                 + sum(len(v) for v in self._quantile.values()))
 
     def _grow(self, value) -> None:
@@ -121,6 +131,12 @@ class ObservationQueue:
 
     def add_minmax(self, value: torch.Tensor, slots: torch.Tensor) -> None:
         self._minmax.append((value, slots))
+        self._grow(value)
+
+    def add_minmax_c(self, value: torch.Tensor, channel_axis: int, mins: torch.Tensor, maxs: torch.Tensor, fresh: bool) -> None:
+        """Per-channel running range (``CUDA.MinMax_C_Multi``); ``fresh``: mins / maxs are uninitialised and this item
+        qualifies for being overwritten (``CUDA.minmax_c_fresh_ok``)."""
+        self._minmax_c.append((value, channel_axis, mins, maxs, bool(fresh)))
         self._grow(value)
 
     def add_hist(self, value: torch.Tensor, rows: torch.Tensor, asymmetric: bool, p0: float, p1: float = 0.0) -> None:
@@ -139,7 +155,16 @@ class ObservationQueue:
         if self._quantile:
             pending, self._quantile = self._quantile, {}
             for (q, _), items in pending.items():
-                CUDA.Quantile_Multi([v for v, _, _ in items], q, [d for _, d, _ in items], [h for _, _, h in items])
+                # one hint belongs to ONE job of a sequence: an observer that observed twice before this flush hands its
+                # hint to its LAST tensor only (the tails of two jobs would write the 8 hint words unsynchronised; results
+                # never depend on a hint, but a torn one costs the exact passes -- ADVICE r3)
+                hints, seen = [h for _, _, h in items], set()
+                for k in range(len(hints) - 1, -1, -1):
+                    if hints[k] is None: continue
+                    key = hints[k].data_ptr()
+                    if key in seen: hints[k] = None
+                    else: seen.add(key)
+                CUDA.Quantile_Multi([v for v, _, _ in items], q, [d for _, d, _ in items], hints)
                 self.launches += 1
         if self._minmax:
             by_dev = {}
@@ -147,6 +172,14 @@ class ObservationQueue:
             self._minmax = []
             for items in by_dev.values():
                 CUDA.MinMax_T_Slots_Multi([v for v, _ in items], [sl for _, sl in items])
+                self.launches += 1
+        if self._minmax_c:
+            by_dev = {}
+            for it in self._minmax_c: by_dev.setdefault(it[0].device, []).append(it)
+            self._minmax_c = []
+            for dev, items in by_dev.items():
+                self._c_tables[dev] = CUDA.MinMax_C_Multi([i[0] for i in items], [i[1] for i in items], [i[2] for i in items],
+                                                          [i[3] for i in items], [i[4] for i in items], self._c_tables.get(dev))
                 self.launches += 1
         if self._hist:
             pending, self._hist = self._hist, {}
@@ -229,6 +262,7 @@ class TorchMinMaxObserver(BaseTensorObserver):
         self._range: Optional[torch.Tensor] = None      # [2] = (min, max)   or   [2, C]
         self._slots: Optional[torch.Tensor] = None      # per-tensor: [minmax_slots, 2], one slot per workgroup
         self._slots_dirty = False
+        self._queued_c = False                          # a per-channel observation sits in the ObservationQueue
         self._host_range: Optional[np.ndarray] = None
         self._observed = False
 
@@ -247,11 +281,21 @@ class TorchMinMaxObserver(BaseTensorObserver):
             else: CUDA.MinMax_T_Slots(value, self._slots)    # no per-batch reduction kernel
             self._slots_dirty = True
         elif cfg.policy.has_property(P.PER_CHANNEL):
+            # weights (and other small tensors) join the forward's ONE multi-tensor launch; a big activation keeps its own
+            # launch (the single-tensor kernel groups several short rows per wave, the multi kernel does not)
+            queued = (self.queue is not None and value.is_cuda
+                      and (value.numel() <= (1 << 22) or CUDA.minmax_c_fresh_ok(value, cfg.channel_axis)))
+            fresh = False
             if self._range is None:
                 C = value.shape[cfg.channel_axis]
                 self._range = torch.empty((2, C), dtype=torch.float32, device=value.device)
-                self._range[0].fill_(float('inf')); self._range[1].fill_(float('-inf'))
-            CUDA.MinMax_C(value, cfg.channel_axis, self._range[0], self._range[1])
+                # a queued first observation of a weight-shaped tensor lets the multi launch OVERWRITE the range: no seeding
+                fresh = queued and CUDA.minmax_c_fresh_ok(value, cfg.channel_axis)
+                if not fresh: self._range[0].fill_(float('inf')); self._range[1].fill_(float('-inf'))
+            if queued:
+                self.queue.add_minmax_c(value, cfg.channel_axis, self._range[0], self._range[1], fresh)
+                self._queued_c = True
+            else: CUDA.MinMax_C(value, cfg.channel_axis, self._range[0], self._range[1])
         else:
             raise TypeError('Min-max Observer only work with per-tensor or per-channel quantize policy.')
         self._observed = True
@@ -259,6 +303,9 @@ class TorchMinMaxObserver(BaseTensorObserver):
 
     def _fold(self) -> None:
         """Fold the per-workgroup slots into the running [min, max] (one tiny launch, at render)."""
+        if self._queued_c:
+            self._drain()
+            self._queued_c = False
         if self._slots_dirty:
             self._drain()
             CUDA.MinMax_Slots_Finish(self._slots, self._range)
@@ -300,6 +347,9 @@ class TorchMinMaxObserver(BaseTensorObserver):
             for min_val, max_val in zip(r[0], r[1]):         # numpy float32 scalars, as in range.py:125-129
                 scale, offset = minmax_to_scale_offset(min_val=min_val, max_val=max_val, config=cfg)
                 scales.append(scale); offsets.append(offset)
+            if _DEFERRED_SETS is not None:                      # render_observers: one host-to-device copy for all configs
+                _DEFERRED_SETS.append((cfg, scales, offsets, device))
+                return
             cfg.scale = torch.tensor(scales, dtype=torch.float32, device=device)
             cfg.offset = torch.tensor(offsets, dtype=torch.float32, device=device)
             set_activated(cfg)

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(_lib.lib, name), f'{name} declared in include/ppq_hip.h but not exported'
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-    assert _lib.lib.ppqhip_version() == 2
+    assert _lib.lib.ppqhip_version() == _lib.ABI_VERSION == 3
 
 
 def test_no_cpu_fallback_and_error_convention():
@@ -756,13 +756,13 @@ def test_quantile_workspace_sizing_covers_the_layout():
 
 def test_to_int_dispatch_and_no_cpu_path():
     """PPQLinearQuant_toInt mirrors the reference's dispatch (qfunction/linear.py:218-238): non-linear configs raise, fewer than
-    8 bits raise, and -- like every kernel-backed function here -- a host tensor is refused instead of silently computed on
-    the CPU; PPQuantFunction_toInt refuses dynamic / non-linear policies (qfunction/__init__.py:47-60)."""
+    8 bits raise, and -- like every kernel-backed function here -- a host tensor is never computed on the CPU (with a device it
+    is staged through the kernel, tests/test_gpu_kernels.py; without one, as here, it raises); PPQuantFunction_toInt refuses dynamic / non-linear policies (qfunction/__init__.py:47-60)."""
     from ppq_amd import FloatingQuantizationConfig, LinearQuantizationConfig, QuantizationStates, qfunction
     t = torch.zeros(4, 6)
     cfg = LinearQuantizationConfig(symmetrical=True, num_of_bits=8)
     cfg.scale, cfg.offset, cfg.state = torch.ones(1), torch.zeros(1), QuantizationStates.ACTIVATED
-    with pytest.raises(RuntimeError, match='not on the GPU'): qfunction.PPQLinearQuant_toInt(t, cfg)
+    with pytest.raises(RuntimeError, match='no CPU path'): qfunction.PPQLinearQuant_toInt(t, cfg)
     low = LinearQuantizationConfig(symmetrical=True, num_of_bits=4, quant_min=-8, quant_max=7)
     low.scale, low.offset = torch.ones(1), torch.zeros(1)
     with pytest.raises(Exception, match='num of bits is unexpected'): qfunction.PPQLinearQuant_toInt(t, low)
