@@ -404,9 +404,13 @@ def workload_variants(args):
                         'roofline': {k: roof.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'launches', 'avg_launch_us',
                                                               'algorithmic_bytes_per_launch')}})
             if name == 'yolov6s_int4_lsq':      # per-block tensors of 0.05 .. 6 MB: every launch is latency-, not bandwidth-bound
-                out[-1]['roofline']['note'] = ('block-wise finetuning launches the LSQ backward on one small weight / activation at a time '
-                                               '(average 7 us per launch); the same kernels on [32,512,56,56]: 0.69-0.72 of 8 TB/s '
-                                               '(profiles/r03_microbench_randn.txt)')
+                out[-1]['execution'] = j['config'].get('execution')
+                out[-1]['launches_per_eager_step'] = j['config'].get('launches_per_eager_step')
+                out[-1]['per_tensor_eager_samples_per_s'] = j['config'].get('per_tensor_eager_samples_per_s')
+                out[-1]['roofline']['note'] = ('block-wise finetuning: all weight delegators of a block share ONE LSQ-backward launch per step '
+                                               '(ppqhip_fq_linear_c_bwd_multi; activations keep one launch each) and the step is replayed from a '
+                                               'HIP graph; per-block tensors of 0.05 .. 6 MB stay latency-bound; the same kernels on '
+                                               '[32,512,56,56]: 0.69-0.72 of 8 TB/s (profiles/r03_microbench_randn.txt)')
         except Exception as e:
             out.append({'workload': name, 'error': f'{type(e).__name__}: {e}'})
     return out
@@ -458,14 +462,23 @@ def main_lsq(args, rank, world, dev):
         del ex
     elapsed = sorted(times)[len(times) // 2]
     blocks = len(p.report)
-    roof, prof_rows = None, []
+    roof, prof_rows, launches_per_step, per_tensor_eager_s = None, [], None, 1.0
     if rank == 0 and world == 1:
         graph2, ex2 = build()
         torch.cuda.synchronize(); _lib.lib.ppqhip_prof_enable(1)
-        LearnedStepSizePass(steps=min(args.steps, 4), lr=1e-5, block_size=5).optimize(graph2, batches, ex2)
+        # launch statistics come from an EAGER pass (events cannot time launches that sit inside a replayed HIP graph)
+        pp = LearnedStepSizePass(steps=min(args.steps, 4), lr=1e-5, block_size=5, use_hip_graph=False)
+        pp.optimize(graph2, batches, ex2)
         torch.cuda.synchronize(); _lib.lib.ppqhip_prof_enable(0)
         prof_rows = collect_prof()
-        roof = roofline_entry(prof_rows, prefer=('fq_linear_t_bwd', 'fq_linear_c_bwd'))
+        roof = roofline_entry(prof_rows, prefer=('fq_linear_c_bwd', 'fq_linear_t_bwd'))
+        eager_steps = max(1, pp.stats['eager_steps'])
+        launches_per_step = {r['name']: round(r['launches'] / eager_steps, 2) for r in prof_rows}
+        # the same pass without this round's execution choices: per-tensor launches, eager steps (what round 3 measured)
+        graph3, ex3 = build()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        LearnedStepSizePass(steps=args.steps, lr=1e-5, block_size=5, group_weights=False, use_hip_graph=False).optimize(graph3, batches, ex3)
+        torch.cuda.synchronize(); per_tensor_eager_s = time.perf_counter() - t1
     if rank == 0:
         total_steps = blocks * args.steps
         samples = world * total_steps * args.batch
@@ -477,7 +490,11 @@ def main_lsq(args, rank, world, dev):
             'config': {'workload': f'{WORKLOADS[WORKLOAD][0]}; {blocks} blocks x {args.steps} Adam steps x batch {args.batch} x 3x{size}x{size} per GPU '
                                    f'(timed: the whole pass incl. its target / input collection)', 'samples': samples, 'batch': args.batch,
                        'blocks': blocks, 'optimizer_steps': total_steps, 'kept_blocks': sum(1 for _, a, b in p.report if b <= a),
-                       'parallelism': f'dp{world} (one flat gradient all-reduce per step)', 'rccl_ranks': world},
+                       'parallelism': f'dp{world} (one flat gradient all-reduce per step)', 'rccl_ranks': world,
+                       'execution': dict(p.stats, note='grouped_weights: weight delegators served by ONE forward + ONE backward launch per step; '
+                                                        'graph_replays: optimizer steps replayed from a captured HIP graph'),
+                       'launches_per_eager_step': launches_per_step if (rank == 0 and world == 1) else None,
+                       'per_tensor_eager_samples_per_s': round(samples / per_tensor_eager_s, 2) if (rank == 0 and world == 1) else None},
             'roofline': roof, 'cpu_baseline': None,
             'kernels': [{'name': r['name'], 'launches': r['launches'], 'total_ms': round(r['total_ms'], 3),
                          'GBps': round(r['total_bytes'] / max(r['total_ms'], 1e-9) / 1e6, 1)} for r in prof_rows]}), flush=True)

