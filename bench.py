@@ -491,7 +491,7 @@ def main_lsq(args, rank, world, dev):
                                    f'(timed: the whole pass incl. its target / input collection)', 'samples': samples, 'batch': args.batch,
                        'blocks': blocks, 'optimizer_steps': total_steps, 'kept_blocks': sum(1 for _, a, b in p.report if b <= a),
                        'parallelism': f'dp{world} (one flat gradient all-reduce per step)', 'rccl_ranks': world,
-                       'execution': dict(p.stats, note='grouped_weights: weight delegators served by ONE forward + ONE backward launch per step; '
+                       'execution': dict(p.stats, graph_error=LearnedStepSizePass.graph_error, note='grouped_weights: weight delegators served by ONE forward + ONE backward launch per step; '
                                                         'graph_replays: optimizer steps replayed from a captured HIP graph'),
                        'launches_per_eager_step': launches_per_step if (rank == 0 and world == 1) else None,
                        'per_tensor_eager_samples_per_s': round(samples / per_tensor_eager_s, 2) if (rank == 0 and world == 1) else None},

@@ -159,7 +159,9 @@ class LSQDelegator:
         self.group, self.slot = None, None          # set by LSQWeightGroup: this weight rides the block's multi-tensor launches
         self.param_backup = None
         if self.is_parameter and is_parameter_trainable:
-            self.param_backup = self.var.value.clone()
+            # detached: a grad-tracked clone of a requires_grad leaf would create (and keep alive) the leaf's AccumulateGrad node
+            # on whatever stream is current NOW -- the step then runs on another stream and a graph capture of it breaks
+            self.param_backup = self.var.value.detach().clone()
         active = (state_value(config.state) == QuantizationStates.ACTIVATED.value and config.dominated_by == config)
         self.scale_backup, self.is_scale_trainable = None, False
         if is_scale_trainable:
@@ -301,7 +303,8 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
             if any({k: (tuple(v.shape), v.dtype) for k, v in d.items()} != first for d in dicts[1:]): return False
         return True
 
-    _graph_broken = False
+    _graph_broken = False      # a capture failed in this process: later blocks / passes stay eager (reason: graph_error)
+    graph_error = None
     _pool = None
 
     def _train_with_graph(self, train_step, qt_inputs, fp_outputs) -> int:
@@ -336,8 +339,8 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
                     graph.capture_end()
         except Exception as e:                          # a library call that cannot be captured: finish eagerly, stop trying
             LearnedStepSizePass._graph_broken = True
+            LearnedStepSizePass.graph_error = self.stats['graph_error'] = f'{type(e).__name__}: {str(e)[:400]}'
             self.stats['graph_failures'] += 1
-            self.stats['graph_error'] = f'{type(e).__name__}: {str(e)[:300]}'
             torch.cuda.synchronize()
             return 1
         self.stats['graph_blocks'] += 1
