@@ -235,6 +235,7 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
         # optimizer step of a block captured ONCE as a HIP graph and replayed for its remaining steps (single process only)
         self.group_weights = group_weights
         self.use_hip_graph = use_hip_graph
+        self.capture_error_mode = 'global'
         self.report = []
         self.stats = {'blocks': 0, 'graph_blocks': 0, 'graph_replays': 0, 'eager_steps': 0, 'grouped_weights': 0, 'graph_failures': 0}
 
@@ -305,7 +306,6 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
 
     _graph_broken = False      # a capture failed in this process: later blocks / passes stay eager (reason: graph_error)
     graph_error = None
-    _pool = None
 
     def _train_with_graph(self, train_step, qt_inputs, fp_outputs) -> int:
         """Step 0 eagerly on a side stream, ONE capture of the same step on that stream, replays for the rest; returns the
@@ -326,20 +326,31 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
         torch.cuda.current_stream().wait_stream(side)
         self.stats['eager_steps'] += 1
         # capture_begin / capture_end directly: the torch.cuda.graph() context manager empties the caching allocator on entry,
-        # which with one capture per block (27 for the YOLOv6-s-like graph) means re-allocating every buffer 27 times
+        # which with one capture per block (27 for the YOLOv6-s-like graph) means re-allocating every buffer 27 times.
+        # (Each graph keeps its own private pool: it dies with the graph at the end of this function.)
         graph = torch.cuda.CUDAGraph()
-        if self._pool is None: self._pool = torch.cuda.graph_pool_handle()      # one private pool for the pass's graphs
         torch.cuda.synchronize()
-        try:
-            with torch.cuda.stream(side):
-                graph.capture_begin(pool=self._pool, capture_error_mode='global')
+        error = None
+        with torch.cuda.stream(side):
+            try:
+                graph.capture_begin(capture_error_mode=self.capture_error_mode)
+            except Exception as e:
+                error = e
+            else:
                 try:
                     train_step(static_in, static_fp)
-                finally:
+                except Exception as e:                  # keep the FIRST error: ending a broken capture raises again
+                    error = e
+                try:
                     graph.capture_end()
-        except Exception as e:                          # a library call that cannot be captured: finish eagerly, stop trying
+                except Exception as e:
+                    error = error or e
+        if error is not None:                           # a call that cannot be captured: finish eagerly, stop trying
+            import traceback
             LearnedStepSizePass._graph_broken = True
-            LearnedStepSizePass.graph_error = self.stats['graph_error'] = f'{type(e).__name__}: {str(e)[:400]}'
+            LearnedStepSizePass.graph_error = self.stats['graph_error'] = \
+                f'{type(error).__name__}: {str(error)[:600]} @ ' + ' <- '.join(
+                    f'{f.name}:{f.lineno}' for f in reversed(traceback.extract_tb(error.__traceback__)[-6:]))
             self.stats['graph_failures'] += 1
             torch.cuda.synchronize()
             return 1

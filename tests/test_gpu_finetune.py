@@ -261,7 +261,7 @@ def test_grouped_weight_launches_equal_the_per_tensor_lsq_path():
     rounding of zero), and the pass reports that it really grouped."""
     _g, _, p_ref, ref = _lsq_variant(1, group_weights=False, use_hip_graph=False)
     _, _, p_grp, grp = _lsq_variant(1, group_weights=True, use_hip_graph=False)
-    assert p_ref.stats['grouped_weights'] == 0 and p_grp.stats['grouped_weights'] >= 4
+    assert p_ref.stats['grouped_weights'] == 0 and p_grp.stats['grouped_weights'] >= 2
     assert [r[0] for r in p_ref.report] == [r[0] for r in p_grp.report]
     for key in ref:                          # one Adam step moves an element by at most lr = 1e-3 (sign flips of ~0 gradients: 2 lr)
         assert (ref[key] - grp[key]).abs().max() <= 2.1e-3, key
