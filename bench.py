@@ -407,6 +407,7 @@ def workload_variants(args):
                 out[-1]['execution'] = j['config'].get('execution')
                 out[-1]['launches_per_eager_step'] = j['config'].get('launches_per_eager_step')
                 out[-1]['per_tensor_eager_samples_per_s'] = j['config'].get('per_tensor_eager_samples_per_s')
+                out[-1]['phase_ms_whole_pass'] = j['config'].get('phase_ms_whole_pass')
                 out[-1]['roofline']['note'] = ('block-wise finetuning: all weight delegators of a block share ONE LSQ-backward launch per step '
                                                '(ppqhip_fq_linear_c_bwd_multi; activations keep one launch each) and the step is replayed from a '
                                                'HIP graph; per-block tensors of 0.05 .. 6 MB stay latency-bound; the same kernels on '
@@ -462,7 +463,7 @@ def main_lsq(args, rank, world, dev):
         del ex
     elapsed = sorted(times)[len(times) // 2]
     blocks = len(p.report)
-    roof, prof_rows, launches_per_step, per_tensor_eager_s = None, [], None, 1.0
+    roof, prof_rows, launches_per_step, per_tensor_eager_s, phase_ms = None, [], None, 1.0, None
     if rank == 0 and world == 1:
         graph2, ex2 = build()
         torch.cuda.synchronize(); _lib.lib.ppqhip_prof_enable(1)
@@ -474,10 +475,19 @@ def main_lsq(args, rank, world, dev):
         roof = roofline_entry(prof_rows, prefer=('fq_linear_c_bwd', 'fq_linear_t_bwd'))
         eager_steps = max(1, pp.stats['eager_steps'])
         launches_per_step = {r['name']: round(r['launches'] / eager_steps, 2) for r in prof_rows}
+        # where the pass spends its time (synchronised phases; a separate pass, not the timed one)
+        graph4, ex4 = build()
+        pq = LearnedStepSizePass(steps=args.steps, lr=1e-5, block_size=5)
+        pq.profile_phases = True
+        pq.optimize(graph4, batches, ex4)
+        phase_ms = {k: round(v, 1) for k, v in pq.phase_ms.items()}
+        del graph4, ex4
         # the same pass without this round's execution choices: per-tensor launches, eager steps (what round 3 measured)
         graph3, ex3 = build()
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        LearnedStepSizePass(steps=args.steps, lr=1e-5, block_size=5, group_weights=False, use_hip_graph=False).optimize(graph3, batches, ex3)
+        pr = LearnedStepSizePass(steps=args.steps, lr=1e-5, block_size=5, group_weights=False, use_hip_graph=False)
+        pr.incremental_inputs = False
+        pr.optimize(graph3, batches, ex3)
         torch.cuda.synchronize(); per_tensor_eager_s = time.perf_counter() - t1
     if rank == 0:
         total_steps = blocks * args.steps
@@ -494,6 +504,7 @@ def main_lsq(args, rank, world, dev):
                        'execution': dict(p.stats, graph_error=LearnedStepSizePass.graph_error, note='grouped_weights: weight delegators served by ONE forward + ONE backward launch per step; '
                                                         'graph_replays: optimizer steps replayed from a captured HIP graph'),
                        'launches_per_eager_step': launches_per_step if (rank == 0 and world == 1) else None,
+                       'phase_ms_whole_pass': phase_ms,
                        'per_tensor_eager_samples_per_s': round(samples / per_tensor_eager_s, 2) if (rank == 0 and world == 1) else None},
             'roofline': roof, 'cpu_baseline': None,
             'kernels': [{'name': r['name'], 'launches': r['launches'], 'total_ms': round(r['total_ms'], 3),

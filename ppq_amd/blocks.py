@@ -139,6 +139,42 @@ def collect(graph, block: TrainableBlock, executor, batches: Iterable, fp_output
     return qt_inputs, fp_outputs
 
 
+class PrefixCache:
+    """The quantised activations a block-wise pass needs as block inputs, computed INCREMENTALLY.
+
+    The reference obtains the inputs of every block with a full forward from the graph inputs (training.py:224-298, per
+    block and batch): O(blocks x graph) work.  The inputs of block k + 1 only differ from what was already computed for
+    block k by the operations in between, so this cache keeps, per calibration batch, every quantised activation computed so
+    far (``TorchExecutor.forward_cached``) and, when a block has been trained, drops what depends on it: the outputs of the
+    block's operations and everything downstream.  Each operation of the prefix therefore runs once per batch in its final
+    state -- same values as the reference's walk (a cached tensor never depends on a parameter / scale changed after it was
+    computed), 4 forwards instead of 4 x 27 / 2 for the YOLOv6-s-like graph.  Everything stays on the device."""
+    def __init__(self, graph, executor, batches):
+        self.graph, self.executor, self.batches = graph, executor, list(batches)
+        self.values: List[Dict[str, torch.Tensor]] = [dict() for _ in self.batches]
+
+    @ torch.no_grad()
+    def inputs_of(self, block: 'TrainableBlock') -> List[dict]:
+        feeds = [v for v in block.sp.inputs if not v.is_parameter]
+        names = [v.name for v in feeds]
+        out = []
+        for b, cache in zip(self.batches, self.values):
+            vals = self.executor.forward_cached(b, names, cache)
+            out.append({n: x.detach() for n, x in zip(names, vals)})
+        return out
+
+    def invalidate(self, block: 'TrainableBlock') -> None:
+        """The block's parameters / scales changed: forget its outputs and everything computed from them."""
+        dead, stack = set(), [v for op in block.rps for v in op.outputs]
+        while stack:
+            v = stack.pop()
+            if v.name in dead: continue
+            dead.add(v.name)
+            for d in v.dest_ops: stack.extend(d.outputs)
+        for cache in self.values:
+            for n in dead: cache.pop(n, None)
+
+
 @ torch.no_grad()
 def compute_block_loss(block: TrainableBlock, qt_inputs, fp_outputs, executor, loss_fn=torch_mean_square_error) -> float:
     """optim/training.py:300-335."""

@@ -329,6 +329,42 @@ class TorchExecutor:
         return q
 
     @ torch.no_grad()
+    def forward_cached(self, inputs, output_names: List[str], cache: Dict[str, torch.Tensor]) -> List[torch.Tensor]:
+        """``forward(inputs, output_names)`` that REUSES the quantised activations in ``cache`` (variable name -> tensor) and
+        adds every tensor it computes: only the operations between what is cached and what is asked for run.  The values are
+        those of ``forward`` as long as the owner drops the entries that depend on parameters / scales it changed
+        (blocks.PrefixCache does).  A block-wise pass asks for the inputs of block after block: with the cache the quantised
+        prefix of the graph is walked once per batch overall instead of once per block."""
+        g = self._graph
+        if isinstance(inputs, torch.Tensor): inputs = {next(iter(g.inputs)): inputs}
+        elif isinstance(inputs, (list, tuple)): inputs = {k: v for k, v in zip(g.inputs, inputs)}
+        for name, value in inputs.items():
+            if name not in cache: cache[name] = self._place(value)
+        need, stack = set(), [g.variables[n] for n in output_names]
+        while stack:
+            v = stack.pop()
+            if v.name in cache or v.is_parameter: continue
+            op = v.source_op
+            if op is None: raise ValueError(f'forward_cached: graph input {v.name} was not fed')
+            if op.name in need: continue
+            need.add(op.name)
+            stack.extend(op.inputs)
+        ops = [op for op in g.topological_sort() if op.name in need]
+        if ops: self._fused_parameters(ops)
+        for op in ops:
+            raw_in = [v.value if v.is_parameter else cache[v.name] for v in op.inputs]
+            if isinstance(op, QuantableOperation):
+                qin = [self._quantize_parameter(v, c) if v.is_parameter else self.quantize_function(x, c)
+                       for v, x, c in zip(op.inputs, raw_in, op.config.input_quantization_config)]
+            else: qin = raw_in
+            outs = _forward(op, qin)
+            outs = list(outs) if isinstance(outs, (list, tuple)) else [outs]
+            if isinstance(op, QuantableOperation):
+                outs = [self.quantize_function(y, c) for y, c in zip(outs, op.config.output_quantization_config)]
+            for v, y in zip(op.outputs, outs): cache[v.name] = y
+        return [cache[n] for n in output_names]
+
+    @ torch.no_grad()
     def forward(self, inputs, output_names: List[str] = None, hooks: Dict[str, object] = None) -> List[torch.Tensor]:
         g = self._graph
         if isinstance(inputs, torch.Tensor): inputs = {next(iter(g.inputs)): inputs}

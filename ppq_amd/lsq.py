@@ -236,8 +236,25 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
         self.group_weights = group_weights
         self.use_hip_graph = use_hip_graph
         self.capture_error_mode = 'global'
+        self.incremental_inputs = True          # quantised block inputs from blocks.PrefixCache instead of a full forward per block
+        self.profile_phases = False             # True: synchronise around the phases and fill phase_ms (a measuring aid)
+        self.phase_ms = {}
         self.report = []
         self.stats = {'blocks': 0, 'graph_blocks': 0, 'graph_replays': 0, 'eager_steps': 0, 'grouped_weights': 0, 'graph_failures': 0}
+
+    def _phase(self, name: str):
+        import contextlib
+        import time
+        if not self.profile_phases: return contextlib.nullcontext()
+
+        @ contextlib.contextmanager
+        def timed():
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            try: yield
+            finally:
+                torch.cuda.synchronize()
+                self.phase_ms[name] = self.phase_ms.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
+        return timed()
 
     def _world(self) -> int:
         import torch.distributed as dist
@@ -320,10 +337,11 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                   # the library's scratch / workspaces are per stream: warm THIS one
-            load(0)
-            train_step(static_in, static_fp)
-        torch.cuda.current_stream().wait_stream(side)
+        with self._phase('graph_step0_eager'):
+            with torch.cuda.stream(side):               # the library's scratch / workspaces are per stream: warm THIS one
+                load(0)
+                train_step(static_in, static_fp)
+            torch.cuda.current_stream().wait_stream(side)
         self.stats['eager_steps'] += 1
         # capture_begin / capture_end directly: the torch.cuda.graph() context manager empties the caching allocator on entry,
         # which with one capture per block (27 for the YOLOv6-s-like graph) means re-allocating every buffer 27 times.
@@ -331,7 +349,7 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
         graph = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         error = None
-        with torch.cuda.stream(side):
+        with self._phase('graph_capture'), torch.cuda.stream(side):
             try:
                 graph.capture_begin(capture_error_mode=self.capture_error_mode)
             except Exception as e:
@@ -355,17 +373,19 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
             torch.cuda.synchronize()
             return 1
         self.stats['graph_blocks'] += 1
-        for step in range(1, self.steps):
-            load(step % n)
-            graph.replay()
-            self.stats['graph_replays'] += 1
-        torch.cuda.current_stream().synchronize()       # the graph's private pool dies with `graph`: no replay may be in flight
+        with self._phase('graph_replays'):
+            for step in range(1, self.steps):
+                load(step % n)
+                graph.replay()
+                self.stats['graph_replays'] += 1
+            torch.cuda.current_stream().synchronize()   # the graph's private pool dies with `graph`: no replay may be in flight
         return self.steps
 
     def finetune(self, block, executor, qt_inputs, fp_outputs):
         """training.py:728-826 for one block."""
         self.enable_block_gradient(block)
-        pre_loss = self._block_loss(block, qt_inputs, fp_outputs, executor)
+        with self._phase('pre_loss'):
+            pre_loss = self._block_loss(block, qt_inputs, fp_outputs, executor)
         delegators, tensors = {}, []
         for op in block.rps:
             if not hasattr(op, 'config'): continue
@@ -417,11 +437,13 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
             opt.step()
 
         done = self._train_with_graph(train_step, qt_inputs, fp_outputs) if graphable else 0
-        for step in range(done, self.steps):
-            train_step(qt_inputs[step % len(qt_inputs)], fp_outputs[step % len(qt_inputs)])
-            self.stats['eager_steps'] += 1
+        with self._phase('eager_steps'):
+            for step in range(done, self.steps):
+                train_step(qt_inputs[step % len(qt_inputs)], fp_outputs[step % len(qt_inputs)])
+                self.stats['eager_steps'] += 1
         for g in groups: g.outputs = None             # the arena is stale after the last optimizer step: per-tensor path from here
-        post_loss = self._block_loss(block, qt_inputs, fp_outputs, executor)
+        with self._phase('post_loss'):
+            post_loss = self._block_loss(block, qt_inputs, fp_outputs, executor)
         for g in groups: g.release()
         for cfg, d in delegators.items():
             if post_loss > pre_loss: d.withdraw()
@@ -450,12 +472,18 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
         # quantisation time -- what earlier blocks train does not move the targets of later ones, so the targets of EVERY
         # block come from ONE dequantised forward per batch (the reference runs that forward again for each block,
         # training.py:224-298: same values, 27 x the work on the YOLOv6-s-like graph; 288 GB of HBM hold them all)
-        from .blocks import collect_fp_outputs
-        all_fp = collect_fp_outputs(graph, blocks, executor, batches) if blocks else []
+        from .blocks import PrefixCache, collect_fp_outputs
+        with self._phase('collect_fp_targets'):
+            all_fp = collect_fp_outputs(graph, blocks, executor, batches) if blocks else []
+        # quantised block inputs: incrementally (blocks.PrefixCache) -- the prefix of the graph runs once per batch overall
+        prefix = PrefixCache(graph, executor, batches) if self.incremental_inputs else None
         for k, block in enumerate(blocks):
-            qt_inputs, fp_outputs = collect(graph, block, executor, batches, fp_outputs=all_fp[k])
+            with self._phase('collect_block_inputs'):
+                if prefix is not None: qt_inputs, fp_outputs = prefix.inputs_of(block), all_fp[k]
+                else: qt_inputs, fp_outputs = collect(graph, block, executor, batches, fp_outputs=all_fp[k])
             all_fp[k] = None
             pre_loss, post_loss = self.finetune(block, executor, qt_inputs, fp_outputs)
+            if prefix is not None: prefix.invalidate(block)
             self.report.append((str(block), pre_loss, post_loss))
         if not self.report: return 0.0, 0.0
         return sum(r[1] for r in self.report), sum(min(r[1], r[2]) for r in self.report)
