@@ -288,9 +288,9 @@ def test_hip_graph_replay_of_the_block_step_equals_eager_steps():
     for key in eager:
         assert (eager[key] - graphed[key]).abs().max() <= 6 * 2.1e-3, key
     for k, ((n, a, b), (_, c, d)) in enumerate(zip(p_e.report, p_g.report)):
-        # the first block starts from identical tensors; later blocks see what the earlier ones trained (lr-sized differences)
-        assert abs(a - c) <= (1e-6 if k == 0 else 0.2) * max(a, 1e-12) + 1e-12, (n, a, c)
-        assert np.isfinite(d)
+        # the first block starts from identical tensors
+        if k == 0: assert abs(a - c) <= 1e-6 * max(a, 1e-12) + 1e-12, (n, a, c)
+        assert np.isfinite(c) and np.isfinite(d)           # (later blocks: an earlier keep / withdraw decision may differ -- see the file header)
     out = ex_g.forward(torch.rand(2, 3, 24, 24, device=DEV))[0]
     assert torch.isfinite(out).all()
     for op in graph_g.operations.values():                      # nothing is left trainable after the graphed pass either
