@@ -20,7 +20,9 @@
 namespace ppqhip {
 
 constexpr int kWave = 64;            // wavefront width on gfx950
-constexpr int kNumCU = 256;          // MI355X
+constexpr int kNumCU = 256;          // MI355X (SPX): sizes the persistent per-workgroup accumulators (an upper bound on grids)
+int num_cu();                        // compute units of the CURRENT device (hipDeviceProp_t::multiProcessorCount, cached): a
+                                     // partitioned device (CPX / DPX) gets proportionally smaller grids; never more than kNumCU
 constexpr int kBlock = 256;          // default workgroup: 4 waves, one per SIMD
 
 enum Rounding : int {

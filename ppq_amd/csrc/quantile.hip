@@ -28,6 +28,10 @@
 // The result is exact in every case; the hint only decides how much is read.  Hot path: 7 launches, 4 of them empty.
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
+
+#include <hip/hip_cooperative_groups.h>
 
 #include "common.hpp"
 
@@ -862,13 +866,40 @@ __device__ __forceinline__ uint32_t first_slice(uint32_t g, uint32_t G, uint32_t
 
 // ---- F1: exact histogram of the top 12 key bits of every job with an open side; tail: bucket + rank per open side ---
 constexpr int kQTrash = 64;
-__global__ __launch_bounds__(kBlock) void quantile_f1_kernel(const QSeq s) {
-    __shared__ uint32_t modes[2 * kQMaxJobs];
-    __shared__ int h[kQ1];
-    __shared__ uint32_t scratch[32];
-    __shared__ uint32_t sel[2];
-    __shared__ uint32_t flag;
-    if (!s.all_open && s.header[kGOpen] == 0u) return;
+// LDS of the three exact passes: they never run at the same time, so the fused kernel below overlays them (a union).
+struct F1Lds {
+    uint32_t modes[2 * kQMaxJobs];
+    int h[kQ1];
+    uint32_t scratch[32];
+    uint32_t sel[2];
+    uint32_t flag;
+};
+constexpr uint32_t kF2LocalCap = 512;
+struct F2Lds {
+    uint32_t modes[2 * kQMaxJobs];
+    uint32_t h[2 * (kQ2 + kQTrash)];
+    uint32_t red[4][kBlock / kWave];
+    uint32_t staged[2][kF2LocalCap];
+    uint32_t staged_n[2], staged_base[2];
+    uint32_t tail_keys[kQCap];          // the tail's LDS copy of a candidate list
+    uint32_t scratch[32];
+    uint32_t sel[2];
+    uint32_t flag;
+};
+struct F3Lds {
+    uint32_t modes[2 * kQMaxJobs];
+    uint32_t h[2 * (kQ3 + kQTrash)];
+    uint32_t scratch[32];
+    uint32_t sel[2];
+    uint32_t flag;
+};
+
+__device__ __forceinline__ void quantile_f1_body(const QSeq& s, F1Lds& L) {
+    uint32_t (&modes)[2 * kQMaxJobs] = L.modes;
+    int (&h)[kQ1] = L.h;
+    uint32_t (&scratch)[32] = L.scratch;
+    uint32_t (&sel)[2] = L.sel;
+    uint32_t& flag = L.flag;
     const uint32_t G = gridDim.x, g = blockIdx.x;
     load_modes(modes, s);
     for (int i = threadIdx.x; i < kQ1; i += kBlock) h[i] = 0;
@@ -919,18 +950,18 @@ __global__ __launch_bounds__(kBlock) void quantile_f1_kernel(const QSeq s) {
 // one reservation per workgroup); else histogram of the middle 12 bits + min / max key of the bucket.
 // tail: COMPACT -> finish on the candidate list; all keys of the bucket equal (saturated values) -> done; else the
 // 24-bit prefix for F3.
-__global__ __launch_bounds__(kBlock) void quantile_f2_kernel(const QSeq s) {
-    __shared__ uint32_t modes[2 * kQMaxJobs];
-    __shared__ uint32_t h[2 * (kQ2 + kQTrash)];
-    __shared__ uint32_t red[4][kBlock / kWave];
-    constexpr uint32_t kLocalCap = 512;
-    __shared__ uint32_t staged[2][kLocalCap];
-    __shared__ uint32_t staged_n[2], staged_base[2];
-    __shared__ uint32_t tail_keys[kQCap];          // the tail's LDS copy of a candidate list
-    __shared__ uint32_t scratch[32];
-    __shared__ uint32_t sel[2];
-    __shared__ uint32_t flag;
-    if (!s.all_open && s.header[kGOpen] == 0u) return;
+__device__ __forceinline__ void quantile_f2_body(const QSeq& s, F2Lds& L) {
+    uint32_t (&modes)[2 * kQMaxJobs] = L.modes;
+    uint32_t (&h)[2 * (kQ2 + kQTrash)] = L.h;
+    uint32_t (&red)[4][kBlock / kWave] = L.red;
+    constexpr uint32_t kLocalCap = kF2LocalCap;
+    uint32_t (&staged)[2][kLocalCap] = L.staged;
+    uint32_t (&staged_n)[2] = L.staged_n;
+    uint32_t (&staged_base)[2] = L.staged_base;
+    uint32_t (&tail_keys)[kQCap] = L.tail_keys;
+    uint32_t (&scratch)[32] = L.scratch;
+    uint32_t (&sel)[2] = L.sel;
+    uint32_t& flag = L.flag;
     const uint32_t G = gridDim.x, g = blockIdx.x;
     load_modes(modes, s);
     for (int i = threadIdx.x; i < 2 * (kQ2 + kQTrash); i += kBlock) h[i] = 0;
@@ -1086,13 +1117,12 @@ __global__ __launch_bounds__(kBlock) void quantile_f2_kernel(const QSeq s) {
 }
 
 // ---- F3: last 8 bits of the sides still open; tail: pick ----------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void quantile_f3_kernel(const QSeq s) {
-    __shared__ uint32_t modes[2 * kQMaxJobs];
-    __shared__ uint32_t h[2 * (kQ3 + kQTrash)];
-    __shared__ uint32_t scratch[32];
-    __shared__ uint32_t sel[2];
-    __shared__ uint32_t flag;
-    if (s.header[kGOpen3] == 0u) return;
+__device__ __forceinline__ void quantile_f3_body(const QSeq& s, F3Lds& L) {
+    uint32_t (&modes)[2 * kQMaxJobs] = L.modes;
+    uint32_t (&h)[2 * (kQ3 + kQTrash)] = L.h;
+    uint32_t (&scratch)[32] = L.scratch;
+    uint32_t (&sel)[2] = L.sel;
+    uint32_t& flag = L.flag;
     const uint32_t G = gridDim.x, g = blockIdx.x;
     load_modes(modes, s);
     for (int i = threadIdx.x; i < 2 * (kQ3 + kQTrash); i += kBlock) h[i] = 0;
@@ -1161,10 +1191,77 @@ __global__ __launch_bounds__(kBlock) void quantile_f3_kernel(const QSeq s) {
     }
 }
 
+// ---- the exact passes as ONE launch ----------------------------------------------------------------------------------
+// On the hot path nothing is open and F1 / F2 / F3 were three launches that each started ~1000 workgroups to read one word
+// and return (~4.6 us apiece behind a 36 us filter).  Fused: a COOPERATIVE launch (hipLaunchCooperativeKernel: the runtime
+// guarantees that the whole grid is resident, so a grid-wide barrier cannot deadlock) runs the three passes back to back with
+// cooperative_groups' grid.sync() between them -- the barrier carries the agent-scope release / acquire that makes the
+// tails' results (modes, buckets, header[kGOpen3]) visible to every workgroup, what the kernel boundaries did before.
+// Nothing open: every workgroup takes the same early exit before the first barrier -- ONE near-empty launch.
+// The three stand-alone kernels stay as the fall-back when a cooperative launch is refused.
+union ExactLds { F1Lds f1; F2Lds f2; F3Lds f3; };
+
+__global__ __launch_bounds__(kBlock) void quantile_exact_kernel(const QSeq s) {
+    __shared__ ExactLds lds;
+    if (!s.all_open && s.header[kGOpen] == 0u) return;               // grid-uniform: written by an earlier launch
+    cooperative_groups::grid_group grid = cooperative_groups::this_grid();
+    quantile_f1_body(s, lds.f1);
+    grid.sync();
+    quantile_f2_body(s, lds.f2);
+    grid.sync();
+    if (__hip_atomic_load(&s.header[kGOpen3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) quantile_f3_body(s, lds.f3);
+}
+
+__global__ __launch_bounds__(kBlock) void quantile_f1_kernel(const QSeq s) {
+    __shared__ F1Lds lds;
+    if (!s.all_open && s.header[kGOpen] == 0u) return;
+    quantile_f1_body(s, lds);
+}
+__global__ __launch_bounds__(kBlock) void quantile_f2_kernel(const QSeq s) {
+    __shared__ F2Lds lds;
+    if (!s.all_open && s.header[kGOpen] == 0u) return;
+    quantile_f2_body(s, lds);
+}
+__global__ __launch_bounds__(kBlock) void quantile_f3_kernel(const QSeq s) {
+    __shared__ F3Lds lds;
+    if (s.header[kGOpen3] == 0u) return;
+    quantile_f3_body(s, lds);
+}
+
 static int validate(int64_t n, const char* what) {
     if (n <= 0) { set_error("%s: tensor is empty", what); return PPQHIP_ERR_INVALID_VALUE; }
     if (n > 0x7fffffffLL) { set_error("%s: too many elements", what); return PPQHIP_ERR_INVALID_VALUE; }
     return PPQHIP_OK;
+}
+
+// Hints this process has already handed to a sequence, with the (n, k_hi, k_lo) they were used for.  A job whose hint is in
+// here will almost certainly find it valid on the device, so a sequence made of such jobs skips the SAMPLE launch (it would
+// start, read one word and return).  Only an optimisation: the device still validates every hint; one that select A dropped
+// in the meantime leaves its job without thresholds, which the exact passes settle (and they write a working hint).
+static bool g_quantile_no_coop = false;       // a cooperative launch was refused once: stop trying in this process
+static std::mutex g_seen_mu;
+static std::unordered_map<const void*, uint64_t> g_seen_hints;
+static uint64_t seen_tag(uint32_t n, uint32_t k_hi, uint32_t k_lo) {
+    return ((uint64_t)n * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)k_hi << 32) ^ (uint64_t)k_lo ^ 0x5bd1e995ull;
+}
+
+// co-resident workgroups of the fused exact kernel on the current device (cooperative launches may not exceed it)
+static uint32_t exact_grid_limit() {
+    static std::mutex mu;
+    static std::unordered_map<int, uint32_t> per_device;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = per_device.find(dev);
+    if (it != per_device.end()) return it->second;
+    int per_cu = 0, coop = 0;
+    uint32_t limit = 0;
+    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess && coop != 0 &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, quantile_exact_kernel, kBlock, 0) == hipSuccess && per_cu > 0)
+        limit = (uint32_t)per_cu * (uint32_t)num_cu();
+    (void)hipGetLastError();
+    per_device[dev] = limit;
+    return limit;
 }
 
 static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, float q, void* workspace, hipStream_t s,
@@ -1176,6 +1273,7 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
         const int count = (num_jobs - seq_base) < kQMaxJobs ? (num_jobs - seq_base) : kQMaxJobs;
         uint32_t tiles = 0, units = 0;
         int64_t elems = 0;
+        bool all_seen = true;                      // every job brings a hint this process used before for the same ranks
         for (int base = 0; base < count; base += kQInitMax) {
             QInitArgs a;
             a.count = (uint32_t)((count - base) < kQInitMax ? (count - base) : kQInitMax);
@@ -1194,6 +1292,17 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
                 };
                 QUpload& e = a.e[k];
                 e.x = src.x; e.dest = src.dest; e.hint = src.hint; e.n = (uint32_t)n; e.k_hi = pos(q); e.k_lo = pos(1 - q); e.pad = 0;
+                if (src.hint == nullptr) all_seen = false;
+                else {
+                    const uint64_t tag = seen_tag(e.n, e.k_hi, e.k_lo);
+                    std::lock_guard<std::mutex> lk(g_seen_mu);
+                    auto it = g_seen_hints.find(src.hint);
+                    if (it == g_seen_hints.end() || it->second != tag) {
+                        all_seen = false;
+                        if (g_seen_hints.size() > (1u << 16)) g_seen_hints.clear();
+                        g_seen_hints[src.hint] = tag;
+                    }
+                }
                 tiles += q_job_tiles(e.n, aligned16(src.x));
                 units += q_job_units(e.n);
                 spec_at += 2 * (size_t)quantile_spec_cap((uint64_t)n);
@@ -1208,20 +1317,35 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
         seq.fixed = fixed + (size_t)seq_base * kQWords;
         seq.count = (uint32_t)count; seq.total_tiles = tiles; seq.total_units = units;
         seq.all_open = elems >= kQSpeculateMinElems ? 0u : 1u;
+        const uint32_t cus = (uint32_t)num_cu();
         if (!seq.all_open) {
-            uint32_t gs = units < 1024u ? units : 1024u;
-            hipLaunchKernelGGL(quantile_sample_kernel, dim3(gs), dim3(kBlock), 0, s, seq);
+            if (!all_seen) {
+                uint32_t gs = units < 1024u ? units : 1024u;
+                hipLaunchKernelGGL(quantile_sample_kernel, dim3(gs), dim3(kBlock), 0, s, seq);
+            }
             uint32_t gf = tiles / 2;                  // >= 2 tiles per workgroup
             if (gf < 1) gf = 1;
-            if (gf > (uint32_t)(kNumCU * kQFWgPerCu)) gf = kNumCU * kQFWgPerCu;
+            if (gf > cus * kQFWgPerCu) gf = cus * kQFWgPerCu;
             hipLaunchKernelGGL(quantile_filter_kernel, dim3(gf), dim3(kQFBlock), 0, s, seq);
             hipLaunchKernelGGL(quantile_select_a_kernel, dim3(2 * (uint32_t)count), dim3(kQSABlock), 0, s, seq);
         }
-        uint32_t gF = tiles < (uint32_t)(kNumCU * 4) ? tiles : (uint32_t)(kNumCU * 4);
+        // the exact passes: ONE cooperative launch (grid <= what is co-resident), else the three stand-alone kernels
+        uint32_t gF = tiles < cus * 4 ? tiles : cus * 4;
         if (gF < 1) gF = 1;
-        hipLaunchKernelGGL(quantile_f1_kernel, dim3(gF), dim3(kBlock), 0, s, seq);
-        hipLaunchKernelGGL(quantile_f2_kernel, dim3(gF), dim3(kBlock), 0, s, seq);
-        hipLaunchKernelGGL(quantile_f3_kernel, dim3(gF), dim3(kBlock), 0, s, seq);
+        const uint32_t limit = exact_grid_limit();
+        bool fused = false;
+        if (limit > 0 && !g_quantile_no_coop) {
+            uint32_t gc = gF < limit ? gF : limit;
+            void* params[] = {(void*)&seq};
+            const hipError_t e = hipLaunchCooperativeKernel((const void*)quantile_exact_kernel, dim3(gc), dim3(kBlock), params, 0, s);
+            if (e == hipSuccess) fused = true;
+            else { (void)hipGetLastError(); g_quantile_no_coop = true; }      // refused (e.g. inside a stream capture): stand-alone kernels
+        }
+        if (!fused) {
+            hipLaunchKernelGGL(quantile_f1_kernel, dim3(gF), dim3(kBlock), 0, s, seq);
+            hipLaunchKernelGGL(quantile_f2_kernel, dim3(gF), dim3(kBlock), 0, s, seq);
+            hipLaunchKernelGGL(quantile_f3_kernel, dim3(gF), dim3(kBlock), 0, s, seq);
+        }
     }
     return finish_launch(what);
 }

@@ -32,6 +32,21 @@ const char* const kKernelNames[K_NUM] = {
     "fq_float_bwd", "hist_sym_t", "hist_asym_t", "hist_sym_c", "quantile_t", "isotone_t", "minmax_t",
     "minmax_c", "mse_search", "kl_losses", "tensor_clip", "rounding_loss", "channel_sum", "float_scale_search"};
 
+int num_cu() {
+    static std::mutex mu;
+    static std::map<int, int> per_device;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return kNumCU;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = per_device.find(dev);
+    if (it != per_device.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = kNumCU;
+    if (n > kNumCU) n = kNumCU;          // the persistent accumulators have kNumCU x k rows / slots
+    per_device[dev] = n;
+    return n;
+}
+
 // ---- per-(device, stream) scratch arena ---------------------------------------------------
 // Kernels that need a few KiB..MiB of device scratch (two-stage reductions) take it from here:
 // launches on one stream are ordered, so one buffer per (device, stream) is race-free.
