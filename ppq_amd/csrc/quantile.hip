@@ -25,13 +25,12 @@
 //                             threshold with a known, sufficient number of keys beyond it, or ON a heavily tied answer).
 //                             With nothing open each returns on one load.
 //
-// The result is exact in every case; the hint only decides how much is read.  Hot path: 7 launches, 4 of them empty.
+// The result is exact in every case; the hint only decides how much is read.  Hot path (a sequence of hints this process
+// has used before): init, filter, select A + three near-empty small-grid launches (the sample launch is skipped).
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
 #include <unordered_map>
-
-#include <hip/hip_cooperative_groups.h>
 
 #include "common.hpp"
 
@@ -1191,27 +1190,14 @@ __device__ __forceinline__ void quantile_f3_body(const QSeq& s, F3Lds& L) {
     }
 }
 
-// ---- the exact passes as ONE launch ----------------------------------------------------------------------------------
-// On the hot path nothing is open and F1 / F2 / F3 were three launches that each started ~1000 workgroups to read one word
-// and return (~4.6 us apiece behind a 36 us filter).  Fused: a COOPERATIVE launch (hipLaunchCooperativeKernel: the runtime
-// guarantees that the whole grid is resident, so a grid-wide barrier cannot deadlock) runs the three passes back to back with
-// cooperative_groups' grid.sync() between them -- the barrier carries the agent-scope release / acquire that makes the
-// tails' results (modes, buckets, header[kGOpen3]) visible to every workgroup, what the kernel boundaries did before.
-// Nothing open: every workgroup takes the same early exit before the first barrier -- ONE near-empty launch.
-// The three stand-alone kernels stay as the fall-back when a cooperative launch is refused.
-union ExactLds { F1Lds f1; F2Lds f2; F3Lds f3; };
-
-__global__ __launch_bounds__(kBlock) void quantile_exact_kernel(const QSeq s) {
-    __shared__ ExactLds lds;
-    if (!s.all_open && s.header[kGOpen] == 0u) return;               // grid-uniform: written by an earlier launch
-    cooperative_groups::grid_group grid = cooperative_groups::this_grid();
-    quantile_f1_body(s, lds.f1);
-    grid.sync();
-    quantile_f2_body(s, lds.f2);
-    grid.sync();
-    if (__hip_atomic_load(&s.header[kGOpen3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) quantile_f3_body(s, lds.f3);
-}
-
+// ---- the exact passes as kernels ---------------------------------------------------------------------------------------
+// (Round 4 fused the three into ONE cooperative launch -- hipLaunchCooperativeKernel + grid.sync() between the passes, early
+// exit when nothing is open.  Correct, all quantile tests green, and SLOWER: a cooperative launch costs ~20 us on this stack
+// (B hinted 23.6 -> 41.1 us, Bx32 57.6 -> 76.3 us, in situ 0.75 -> 0.68 of the roofline; profiles/r04_quantile_coop.txt), so
+// the passes stay three ordinary launches that return on one load when nothing is open.  What the host CAN know is whether the
+// sequence is made of hints it has used before: then the sample launch is skipped and the three near-empty launches get a
+// small grid -- any grid is correct, every workgroup takes slices g, g + G, ..; a hinted job that does fall through to the
+// exact passes just finishes them on fewer workgroups.)
 __global__ __launch_bounds__(kBlock) void quantile_f1_kernel(const QSeq s) {
     __shared__ F1Lds lds;
     if (!s.all_open && s.header[kGOpen] == 0u) return;
@@ -1238,30 +1224,10 @@ static int validate(int64_t n, const char* what) {
 // here will almost certainly find it valid on the device, so a sequence made of such jobs skips the SAMPLE launch (it would
 // start, read one word and return).  Only an optimisation: the device still validates every hint; one that select A dropped
 // in the meantime leaves its job without thresholds, which the exact passes settle (and they write a working hint).
-static bool g_quantile_no_coop = false;       // a cooperative launch was refused once: stop trying in this process
 static std::mutex g_seen_mu;
 static std::unordered_map<const void*, uint64_t> g_seen_hints;
 static uint64_t seen_tag(uint32_t n, uint32_t k_hi, uint32_t k_lo) {
     return ((uint64_t)n * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)k_hi << 32) ^ (uint64_t)k_lo ^ 0x5bd1e995ull;
-}
-
-// co-resident workgroups of the fused exact kernel on the current device (cooperative launches may not exceed it)
-static uint32_t exact_grid_limit() {
-    static std::mutex mu;
-    static std::unordered_map<int, uint32_t> per_device;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    std::lock_guard<std::mutex> lk(mu);
-    auto it = per_device.find(dev);
-    if (it != per_device.end()) return it->second;
-    int per_cu = 0, coop = 0;
-    uint32_t limit = 0;
-    if (hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess && coop != 0 &&
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, quantile_exact_kernel, kBlock, 0) == hipSuccess && per_cu > 0)
-        limit = (uint32_t)per_cu * (uint32_t)num_cu();
-    (void)hipGetLastError();
-    per_device[dev] = limit;
-    return limit;
 }
 
 static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, float q, void* workspace, hipStream_t s,
@@ -1329,23 +1295,14 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
             hipLaunchKernelGGL(quantile_filter_kernel, dim3(gf), dim3(kQFBlock), 0, s, seq);
             hipLaunchKernelGGL(quantile_select_a_kernel, dim3(2 * (uint32_t)count), dim3(kQSABlock), 0, s, seq);
         }
-        // the exact passes: ONE cooperative launch (grid <= what is co-resident), else the three stand-alone kernels
+        // the exact passes: a full grid when a job may well need them (a cold job, a tiny sequence), a small one when every job
+        // rides a hint this process has used before (see the note above the kernels)
         uint32_t gF = tiles < cus * 4 ? tiles : cus * 4;
+        if (!seq.all_open && all_seen && gF > cus / 2) gF = cus / 2;
         if (gF < 1) gF = 1;
-        const uint32_t limit = exact_grid_limit();
-        bool fused = false;
-        if (limit > 0 && !g_quantile_no_coop) {
-            uint32_t gc = gF < limit ? gF : limit;
-            void* params[] = {(void*)&seq};
-            const hipError_t e = hipLaunchCooperativeKernel((const void*)quantile_exact_kernel, dim3(gc), dim3(kBlock), params, 0, s);
-            if (e == hipSuccess) fused = true;
-            else { (void)hipGetLastError(); g_quantile_no_coop = true; }      // refused (e.g. inside a stream capture): stand-alone kernels
-        }
-        if (!fused) {
-            hipLaunchKernelGGL(quantile_f1_kernel, dim3(gF), dim3(kBlock), 0, s, seq);
-            hipLaunchKernelGGL(quantile_f2_kernel, dim3(gF), dim3(kBlock), 0, s, seq);
-            hipLaunchKernelGGL(quantile_f3_kernel, dim3(gF), dim3(kBlock), 0, s, seq);
-        }
+        hipLaunchKernelGGL(quantile_f1_kernel, dim3(gF), dim3(kBlock), 0, s, seq);
+        hipLaunchKernelGGL(quantile_f2_kernel, dim3(gF), dim3(kBlock), 0, s, seq);
+        hipLaunchKernelGGL(quantile_f3_kernel, dim3(gF), dim3(kBlock), 0, s, seq);
     }
     return finish_launch(what);
 }
