@@ -386,6 +386,8 @@ def workload_variants(args):
     for name, extra in (('resnet50_cfg3', ['--workload', 'resnet50_cfg3', '--steps', '4', '--batch', '32']),
                         ('vit_b16_fp8', ['--workload', 'vit_b16_fp8', '--steps', '4', '--batch', '16']),
                         ('yolov6s_int4_lsq', ['--workload', 'yolov6s_int4_lsq', '--steps', '8', '--batch', '8']),
+                        # the headline pass at the reference's DEFAULT KL bin count (core/common.py:18: 4096; BASELINE quotes 2048)
+                        ('resnet50_kl_bins4096', ['--workload', 'resnet50', '--bins', '4096', '--steps', '8', '--batch', '32']),
                         # the percentile observer on the headline topology: the in-situ number of the quantile launch
                         # sequence (quantile.hip; one sequence per forward over 72 tensors, hints from the previous batch)
                         ('resnet50_percentile', ['--workload', 'resnet50', '--method', 'percentile', '--steps', '16', '--batch', '32'])):
@@ -662,6 +664,10 @@ def main():
 
     if args.variants and world == 1 and WORKLOAD == 'resnet50':
         variants += seam_variants(dev, batches, args.steps, args.bins, args.method)
+        # the same two seams at SURVEY 8(d)'s literal protocol size: batch 1 (64 of the 256 samples: host time per tensor call
+        # is the step here -- the facade's share of it: tools/call_overhead.py, profiles/r04_call_overhead.txt)
+        g1 = torch.Generator(device=dev).manual_seed(99)
+        variants += seam_variants(dev, [torch.rand(1, 3, 224, 224, device=dev, generator=g1) for _ in range(64)], 64, args.bins, args.method)
         torch.cuda.empty_cache()
         variants += workload_variants(args)
 

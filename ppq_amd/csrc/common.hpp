@@ -401,7 +401,8 @@ struct HotCounter {
 
 // grid size for a streaming kernel that consumes `work_items` items, `per_block` per block-pass,
 // capped so that the chip holds every block at once (8 x 256-thread blocks per CU).
-inline int stream_grid(int64_t work_items, int64_t per_block, int max_blocks = kNumCU * 8) {
+inline int stream_grid(int64_t work_items, int64_t per_block, int max_blocks = 0) {
+    if (max_blocks <= 0) max_blocks = num_cu() * 8;
     int64_t b = (work_items + per_block - 1) / per_block;
     if (b < 1) b = 1;
     if (b > max_blocks) b = max_blocks;

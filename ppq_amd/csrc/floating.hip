@@ -707,7 +707,7 @@ int ppqhip_fq_float_c_bwd(const float* x, const float* scale, const float* offse
     if (elem_per_channel < 64) {
         if (int st = check_hip(hipMemsetAsync(grad_s, 0, sizeof(float) * (size_t)num_channel, s), "memset grad_s")) return st;
         const int use_lds = num_channel <= 8192;
-        hipLaunchKernelGGL(fq_float_bwd_generic_kernel, dim3(stream_grid(n, kBlock * 8, kNumCU * 2)), dim3(kBlock),
+        hipLaunchKernelGGL(fq_float_bwd_generic_kernel, dim3(stream_grid(n, kBlock * 8, num_cu() * 2)), dim3(kBlock),
                            use_lds ? sizeof(float) * (size_t)num_channel : 0, s, x, scale, offset, grad_y, grad_x, grad_s, (uint32_t)n,
                            make_fastdiv((uint32_t)elem_per_channel), make_fastdiv((uint32_t)num_channel), use_lds, fmt, clip_min,
                            clip_max, denom, rounding);

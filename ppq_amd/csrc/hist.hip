@@ -502,7 +502,8 @@ static int persistent_grid(uint32_t tiles) {
     uint32_t g = tiles / PPQHIP_HIST_MIN_TILES;
     if (g > PPQHIP_HIST_ATOMIC_MAX_WG) g = tiles / (2 * PPQHIP_HIST_MIN_TILES);
     if (g < 1) g = 1;
-    if (g > (uint32_t)kHistRows) g = kHistRows;
+    const uint32_t cap = (uint32_t)(num_cu() * kHistWgPerCu);      // <= kHistRows: a partitioned device runs a smaller grid
+    if (g > cap) g = cap;
     return (int)g;
 }
 
@@ -666,7 +667,7 @@ static int hist_c_impl(const float* x, int64_t n, int64_t num_channel, int64_t e
     if (elem_per_channel % 4 == 0 && elem_per_channel >= 64 && aligned16(x) && num_bins <= kMaxLdsBins) {
         const uint32_t C = (uint32_t)num_channel, outer = (uint32_t)(n / (num_channel * elem_per_channel));
         // one workgroup per channel; channels are split over row ranges only while that is what fills the chip
-        const uint32_t want_wgs = (uint32_t)kNumCU * PPQHIP_HIST_C_WGPC;
+        const uint32_t want_wgs = (uint32_t)num_cu() * PPQHIP_HIST_C_WGPC;
         uint32_t splits = C >= want_wgs ? 1u : (want_wgs + C - 1) / C;
         const uint64_t tiles_per_channel = ((uint64_t)outer * (uint64_t)(elem_per_channel / 4)) / kTileVec;      // a split should have >= 1 full tile
         if (splits > tiles_per_channel) splits = tiles_per_channel > 0 ? (uint32_t)tiles_per_channel : 1u;
@@ -683,7 +684,7 @@ static int hist_c_impl(const float* x, int64_t n, int64_t num_channel, int64_t e
 #undef PPQ_LAUNCH_HIST_CC
     } else if (n / num_channel >= 256 && num_bins <= kMaxLdsBins) {        // >= 256 elements per channel, not float4-addressable
         const uint32_t C = (uint32_t)num_channel, outer = (uint32_t)(n / (num_channel * elem_per_channel));
-        const uint32_t want_wgs = (uint32_t)kNumCU * PPQHIP_HIST_C_WGPC;
+        const uint32_t want_wgs = (uint32_t)num_cu() * PPQHIP_HIST_C_WGPC;
         uint32_t splits = C >= want_wgs ? 1u : (want_wgs + C - 1) / C;
         const uint64_t trips_per_channel = ((uint64_t)outer * (uint64_t)elem_per_channel) / (kHistBlock * 8);   // >= 8 trips per split
         if (splits > trips_per_channel) splits = trips_per_channel > 0 ? (uint32_t)trips_per_channel : 1u;

@@ -838,7 +838,7 @@ int ppqhip_fq_linear_c_bwd(const float* x, const float* scale, const float* offs
     } else {
         const int use_lds = num_channel <= 8192;
         const size_t lds = use_lds ? sizeof(float) * (size_t)num_channel : 0;
-        hipLaunchKernelGGL(fq_linear_c_bwd_generic_kernel, dim3(stream_grid(n, kBlock * 8, kNumCU * 2)),
+        hipLaunchKernelGGL(fq_linear_c_bwd_generic_kernel, dim3(stream_grid(n, kBlock * 8, num_cu() * 2)),
                            dim3(kBlock), lds, s, x, scale, offset, grad_y, grad_x, grad_s, (uint32_t)n,
                            make_fastdiv((uint32_t)elem_per_channel), nc, use_lds, clip_min, clip_max,
                            grad_factor, rounding);

@@ -474,7 +474,7 @@ static int minmax_t_impl(const float* x, int64_t n, float* minmax, void* workspa
     // 8 workgroups per CU, each streaming one contiguous chunk; streaming (nontemporal) loads once the
     // tensor cannot be cache resident (sweep on MI355X, 205 MB: 5.7 TB/s vs 5.1 with plain loads)
     const bool nt = n >= (48ll << 20);
-    const int grid = stream_grid(n, kBlock * 4 * 4, kNumCU * 8);
+    const int grid = stream_grid(n, kBlock * 4 * 4, num_cu() * 8);
     float* partial = slots;
     const int accumulate = slots != nullptr;
     if (!slots && grid > 32) {
@@ -503,7 +503,8 @@ int64_t ppqhip_minmax_slots(void) { return (int64_t)kNumCU * 8; }
 static void launch_minmax_persistent(const MinMaxJobs& args, int64_t elems, hipStream_t s) {
     uint32_t grid = args.total_tiles / 2;                       // at least two tiles per workgroup
     if (grid < 1) grid = 1;
-    if (grid > (uint32_t)kMMGrid) grid = kMMGrid;
+    const uint32_t mm_cap = (uint32_t)(num_cu() * PPQHIP_MM_WGPC);      // <= kMMGrid (one slot per workgroup)
+    if (grid > mm_cap) grid = mm_cap;
     // streaming (nontemporal) loads once the data cannot be cache resident
     if (elems >= (48ll << 20)) hipLaunchKernelGGL((minmax_persistent_kernel<true>), dim3(grid), dim3(kMMBlock), 0, s, args);
     else hipLaunchKernelGGL((minmax_persistent_kernel<false>), dim3(grid), dim3(kMMBlock), 0, s, args);
@@ -576,7 +577,7 @@ int ppqhip_minmax_c(const float* x, int64_t n, int64_t num_channel, int64_t elem
         // short rows: K rows of a channel per wave while that leaves the chip >= 32 waves per CU
         uint32_t K = 1;
         if (chunks == 1) {
-            K = (uint32_t)(rows / (kNumCU * PPQHIP_MMC_WPC));
+            K = (uint32_t)(rows / (num_cu() * PPQHIP_MMC_WPC));
             const uint32_t k_bytes = (uint32_t)(65536 / (elem_per_channel * 4));       // <= 64 KB per wave
             if (K > k_bytes) K = k_bytes;
             if (K > outer) K = outer;
@@ -589,7 +590,7 @@ int ppqhip_minmax_c(const float* x, int64_t n, int64_t num_channel, int64_t elem
     } else {
         const int use_lds = num_channel <= 4096;
         const size_t lds = use_lds ? 2 * sizeof(float) * (size_t)num_channel : 0;
-        hipLaunchKernelGGL(minmax_c_generic_kernel, dim3(stream_grid(n, kBlock * 16, kNumCU * 2)), dim3(kBlock), lds,
+        hipLaunchKernelGGL(minmax_c_generic_kernel, dim3(stream_grid(n, kBlock * 16, num_cu() * 2)), dim3(kBlock), lds,
                            s, x, (uint32_t)n, make_fastdiv((uint32_t)elem_per_channel), nc, use_lds, mins, maxs);
     }
     return finish_launch("minmax_c");
@@ -606,7 +607,7 @@ int ppqhip_channel_sum(const float* x, int64_t n, int64_t num_channel, int64_t e
     const uint32_t C = (uint32_t)num_channel, epc = (uint32_t)elem_per_channel;
     const uint32_t outer = (uint32_t)(n / (num_channel * elem_per_channel));
     if (epc >= 64) {
-        uint32_t S = (4 * kNumCU + C - 1) / C;            // >= 4 workgroups per CU in total
+        uint32_t S = (4 * (uint32_t)num_cu() + C - 1) / C;            // >= 4 workgroups per CU in total
         if (S > outer) S = outer;
         if (S < 1) S = 1;
         double* partial = (double*)scratch(s, sizeof(double) * (size_t)S * C);

@@ -134,7 +134,7 @@ int ppqhip_rounding_loss(const float* x, const float* scale, const float* offset
     LaunchScope scope(K_ROUNDING_LOSS, 4.0 * (double)n, s);
     if (int st = check_hip(hipMemsetAsync(out, 0, sizeof(float), s), "memset loss")) return st;
     const int pc = num_channel > 0;
-    hipLaunchKernelGGL(rounding_loss_kernel, dim3(stream_grid(n, kBlock * 8, kNumCU * 4)), dim3(kBlock), 0, s, x, scale,
+    hipLaunchKernelGGL(rounding_loss_kernel, dim3(stream_grid(n, kBlock * 8, num_cu() * 4)), dim3(kBlock), 0, s, x, scale,
                        offset, out, (uint32_t)n, make_fastdiv(pc ? (uint32_t)elem_per_channel : 1u),
                        make_fastdiv(pc ? (uint32_t)num_channel : 1u), pc, clip_min, clip_max, rounding,
                        1.0f / sqrtf((float)n));

@@ -703,26 +703,34 @@ def test_block_builder_on_random_dags_vs_the_reference_walk():
     assert builds > 500 and 0 < differs < builds // 5
 
 
-def test_drop_in_quantile_hint_is_per_calling_object():
-    """CUDA.Quantile(tensor, q) is stateless in the reference; the facade finds the calling observer on the frame stack and keeps
-    one threshold hint per (caller, device, numel, q), weakly: two observers of equal shape never share thresholds, a plain
-    function gets none (every call samples), and a collected observer releases its hints."""
+def test_drop_in_quantile_hint_belongs_to_the_declared_owner():
+    """CUDA.Quantile(tensor, q) is stateless in the reference.  A caller that declares itself the owner of the calls it makes
+    (``ffi.quantile_hint_owner``; install_into_ppq() wraps the reference's percentile observer in it) gets one threshold hint per
+    (owner, device, numel, q), weakly held: two observers of equal shape never share thresholds, nothing declared means no hint
+    (every call samples) whatever the call stack looks like, owners nest, and a collected observer releases its hints."""
+    import functools
     import gc
     from ppq_amd import ffi
     dev = torch.device('cpu')                      # the bookkeeping is device agnostic; kernels are not involved
 
-    def facade(numel, q):                          # stands for CUDA.Quantile -> HIP_EXTENSION.Quantile_T (two frames, no `self`)
-        def quantile_t(): return ffi._caller_quantile_hint(dev, numel, q)
-        return quantile_t()
+    def facade(numel, q): return ffi._owner_quantile_hint(dev, numel, q)      # what Quantile_T(hint='auto') evaluates
 
     class Observer:
-        def observe(self, numel, q=0.9999): return facade(numel, q)
+        def observe(self, numel, q=0.9999):
+            with ffi.quantile_hint_owner(self):
+                return functools.partial(lambda: facade(numel, q))()           # wrappers in between do not matter
+
+        def undeclared(self, numel, q=0.9999): return facade(numel, q)
     a, b = Observer(), Observer()
     ha, hb = a.observe(1000), b.observe(1000)
     assert ha is not None and hb is not None and ha is not hb
     assert a.observe(1000) is ha and a.observe(1001) is not ha and a.observe(1000, 0.999) is not ha
     assert ha.dtype == torch.int32 and ha.numel() == 8 and int(ha.abs().sum()) == 0
-    assert facade(1000, 0.9999) is None            # called from a function: no owner, no hint
+    assert facade(1000, 0.9999) is None and a.undeclared(1000) is None        # a `self` on the stack is not a declaration
+    with ffi.quantile_hint_owner(a):
+        with ffi.quantile_hint_owner(b): assert facade(1000, 0.9999) is hb    # innermost owner
+        assert facade(1000, 0.9999) is ha                                      # restored on exit
+    assert facade(1000, 0.9999) is None
 
     def short_lived():
         o = Observer(); o.observe(5)
