@@ -110,6 +110,13 @@ class QuantizationStates(Enum):
         return state_value(state) in (cls.ACTIVATED.value, cls.PASSIVE.value)
 
 
+class QuantizationVisibility(Enum):
+    """ppq/core/quant.py:20-23."""
+    FORCE_EXPORT = 1
+    EXPORT_WHEN_ACTIVE = 2
+    INTERNAL = 3
+
+
 def state_value(state) -> int:
     return int(getattr(state, 'value', state))
 
@@ -151,6 +158,8 @@ class TensorQuantizationConfig:
         self.channel_axis = channel_axis
         self.observer_algorithm = observer_algorithm
         self.detail = {} if detail is None else detail
+        self._dominator = self                               # union-find root pointer (quant.py:596)
+        self.visibility = QuantizationVisibility.EXPORT_WHEN_ACTIVE
         TensorQuantizationConfig._counter += 1
         self._hash = TensorQuantizationConfig._counter
 
@@ -160,16 +169,53 @@ class TensorQuantizationConfig:
 
     @ property
     def dominated_by(self):
-        return self
+        """Root of this config's union-find tree (quant.py:647-675), with path compression."""
+        if self._dominator is self: return self
+        root = self._dominator.dominated_by
+        self._dominator = root
+        return root
+
+    @ dominated_by.setter
+    def dominated_by(self, o) -> None:
+        """quant.py:677-691: the trees of self and o are joined under o's root; this config becomes OVERLAPPED."""
+        if not isinstance(o, TensorQuantizationConfig):
+            raise TypeError('Error with TQC.dominated_by = o: o must be another Tensor Quantization Config, '
+                            f'however {type(o)} was given.')
+        if o._hash == self._hash: raise ValueError('Error with TQC.dominated_by = o: o must not equal to TQC its self.')
+        root, dominator = self.dominated_by, o.dominated_by
+        if root is not dominator:
+            root._dominator = dominator
+            self._dominator = dominator
+            root.state = QuantizationStates.OVERLAPPED
+            self.state = QuantizationStates.OVERLAPPED
 
     @ property
-    def scale(self) -> torch.Tensor: return self._scale
+    def master_by(self):
+        return self.dominated_by
+
+    @ master_by.setter
+    def master_by(self, master) -> None:
+        """quant.py:702-713: a PASSIVE config takes scale / offset from its master (Clip bounds, Pad value)."""
+        if not isinstance(master, TensorQuantizationConfig):
+            raise TypeError('Error with TQC.master_by(o): o must be another Tensor Quantization Config, '
+                            f'however {type(master)} was given.')
+        if master._hash == self._hash: raise ValueError('Error with TQC.dominated_by = o: o must not equal to TQC its self.')
+        self._dominator = master
+        self.state = QuantizationStates.PASSIVE if (master.scale is not None and master.offset is not None) \
+            else QuantizationStates.PASSIVE_INIT
+
+    @ property
+    def scale(self) -> torch.Tensor:
+        root = self.dominated_by
+        return self._scale if root is self else root.scale     # quant.py:743-749
 
     @ scale.setter
     def scale(self, value: Any): self._scale = value
 
     @ property
-    def offset(self) -> torch.Tensor: return self._offset
+    def offset(self) -> torch.Tensor:
+        root = self.dominated_by
+        return self._offset if root is self else root.offset
 
     @ offset.setter
     def offset(self, value: Any): self._offset = value

@@ -411,7 +411,7 @@ class TorchExecutor:
 # ------------------------------------------------------------------------------------ quantizer
 def quantize_graph(graph: BaseGraph, activation_algorithm: str = 'kl', per_channel_weight: bool = True,
                    symmetrical: bool = True, weight_symmetrical: bool = True, num_of_bits: int = 8,
-                   hist_bins: int = None, fp8: bool = False) -> None:
+                   hist_bins: int = None, fp8: bool = False, passive_bias: bool = False) -> None:
     """TensorRT-style INT8 policy (TensorRTQuantizer.py:12-107): per-tensor activations on every
     operation, per-channel `minmax` weights on axis 0, FP32 bias; then the state edits of
     QuantizeFusionPass (computing op -> activation, passive ops) and QuantizeSimplifyPass."""
@@ -434,6 +434,12 @@ def quantize_graph(graph: BaseGraph, activation_algorithm: str = 'kl', per_chann
                 in_cfgs.append(LinearQuantizationConfig(symmetrical=weight_symmetrical, quant_min=wmin, quant_max=wmax,
                                                         num_of_bits=num_of_bits, calibration='minmax',
                                                         channel_axis=0 if per_channel_weight else None))
+            elif v.is_parameter and passive_bias and not fp8 and op.type in COMPUTING_OP and i == 2:
+                # the integer platforms' policy (PPLQuantizer.py:54-66): a 32-bit symmetric bias whose scale is NOT observed but
+                # derived -- input scale x weight scale -- by PassiveParameterQuantizePass once both are calibrated
+                in_cfgs.append(LinearQuantizationConfig(symmetrical=True, quant_min=-(2 ** 31 - 1), quant_max=2 ** 31 - 1, num_of_bits=32,
+                                                        calibration=None, channel_axis=0 if per_channel_weight else None))
+                in_cfgs[-1].state = QuantizationStates.PASSIVE_INIT
             elif v.is_parameter:
                 c = act_cfg(); c.state = QuantizationStates.FP32      # bias / norm parameters stay FP32
                 in_cfgs.append(c)

@@ -334,3 +334,41 @@ def test_prefix_cache_block_inputs_equal_the_full_forward_collection():
                         if not v.is_parameter and isinstance(c.scale, torch.Tensor) and c.state.value == 4: c.scale.mul_(1.02)
         prefix.invalidate(block)
 
+
+def test_passive_bias_policy_rides_a_passive_delegator_through_lsq():
+    """The integer platforms' bias policy (PPLQuantizer.py:54-66: 32-bit symmetric per-channel, PASSIVE_INIT) on the harness:
+    ParameterQuantizePass leaves the bias alone, calibration runs with it unquantised, PassiveParameterQuantizePass
+    (optim/parameters.py:13-153) gives it scale = weight scale x input scale and state PASSIVE, the executor then fake-quantises
+    it through the per-channel kernel, and the LSQ pass puts a PASSIVE LSQDelegator on it (algorithm/training.py:329: trainable
+    value with a backup, scale not trainable) -- the keep / withdraw contract holds for the biases too."""
+    from ppq_amd import harness
+    from ppq_amd.blocks import split_graph_into_blocks
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    from ppq_amd.core import QuantizationStates as S
+    from ppq_amd.lsq import LearnedStepSizePass
+    from ppq_amd.parameters import PassiveParameterQuantizePass
+    graph = harness.small_cnn_graph(seed=5, width=16)
+    harness.quantize_graph(graph, 'minmax', passive_bias=True)
+    ex = harness.TorchExecutor(graph, DEV)
+    harness.ParameterQuantizePass().optimize(graph)
+    g = torch.Generator().manual_seed(7)
+    batches = [torch.rand(8, 3, 24, 24, generator=g).to(DEV) for _ in range(8)]
+    biases = [(op, op.config.input_quantization_config[2]) for op in graph.operations.values()
+              if hasattr(op, 'config') and op.type in ('Conv', 'Gemm') and len(op.inputs) == 3]
+    assert len(biases) >= 3 and all(c.state == S.PASSIVE_INIT for _, c in biases)
+    fp_bias_out = ex.forward(batches[0])[0].clone()
+    RuntimeCalibrationPass().optimize(graph, dataloader=batches, executor=ex, calib_steps=8)
+    assert all(c.state == S.PASSIVE_INIT for _, c in biases)
+    p = PassiveParameterQuantizePass(); p.optimize(graph)
+    assert p.unresolved == []
+    for op, c in biases:
+        i_cfg, w_cfg, _ = op.config.input_quantization_config
+        assert c.state == S.PASSIVE and torch.equal(c.scale, w_cfg.scale * i_cfg.scale) and float(c.offset.abs().sum()) == 0
+        assert c.scale.numel() == op.inputs[2].value.numel()
+    out = ex.forward(batches[0])[0]
+    assert torch.isfinite(out).all() and not torch.equal(out, fp_bias_out)
+    before = _snapshot(graph)
+    lsq = LearnedStepSizePass(steps=20, lr=1e-3)
+    lsq.optimize(graph, batches, ex)
+    _check_contract(graph, ex, before, split_graph_into_blocks(graph, graph.topological_sort(), 5), lsq.report)
+

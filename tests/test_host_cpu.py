@@ -808,3 +808,73 @@ def test_uninstall_restores_the_reference_observer_table_and_type_test():
     assert REF_CONFIG.USING_CUDA_KERNEL is False and REF_COMPLIER.__CUDA_EXTENTION__ is None
     ppq_amd.uninstall_from_ppq()                                           # idempotent
     assert dict(ref_observer.OBSERVER_TABLE) == before_table
+
+
+def test_passive_parameter_pass_equals_the_reference_pass():
+    """PassiveParameterQuantizePass (optim/parameters.py:13-153) on the REFERENCE's own quantised ResNet-50-topology graph, the
+    bias configs switched to the integer platforms' PASSIVE_INIT policy (PPLQuantizer.py:54-66) in two copies: the reference's
+    pass on one, this package's (duck-typed on the reference's IR) on the other -- every bias config ends PASSIVE with the same
+    scale (= weight scale x input scale), zero offset; an unquantised input raises PermissionError in both; nothing stays
+    PASSIVE_INIT.  Host logic only: runs on the CPU."""
+    from oracle import reference_import as RI
+    if RI.find_reference() is None: pytest.skip('reference not present on this machine')
+    from ppq_amd import harness
+    from ppq_amd.parameters import PassiveParameterQuantizePass as Ours
+    RI.load()
+    from ppq.core import QuantizationStates as RS
+    from ppq.quantization.optim import PassiveParameterQuantizePass as Ref
+    from ppq.quantization.optim import RuntimeCalibrationPass as RefCalibration
+
+    def prepared():
+        rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(harness.small_cnn_graph(seed=0)), 'cpu', torch.rand(2, 3, 32, 32), method='minmax')
+        gen = torch.Generator().manual_seed(0)
+        RefCalibration(method='minmax').optimize(graph=rg, dataloader=[torch.rand(2, 3, 32, 32, generator=gen) for _ in range(8)],
+                                                 executor=rex, calib_steps=8, collate_fn=None)
+        n = 0
+        for op in rg.operations.values():
+            if hasattr(op, 'config') and op.type in {'Conv', 'Gemm'} and op.num_of_input == 3:
+                b = op.config.input_quantization_config[-1]
+                b.num_of_bits, b.quant_max, b.quant_min = 32, 2 ** 31 - 1, -(2 ** 31 - 1)
+                b.state = RS.PASSIVE_INIT
+                n += 1
+        assert n >= 3
+        return rg
+    a, b = prepared(), prepared()
+    Ref().optimize(a)
+    p = Ours(); p.optimize(b)
+    assert p.unresolved == []
+    for (na, oa), (nb, ob) in zip(a.operations.items(), b.operations.items()):
+        assert na == nb
+        if not hasattr(oa, 'config'): continue
+        for ca, cb in zip(oa.config.input_quantization_config, ob.config.input_quantization_config):
+            assert ca.state == cb.state, (na, ca.state, cb.state)
+            if ca.state == RS.PASSIVE:
+                assert torch.equal(ca.scale, cb.scale) and torch.equal(ca.offset, cb.offset), na
+        if oa.type in {'Conv', 'Gemm'} and oa.num_of_input == 3:
+            i_cfg, w_cfg, b_cfg = ob.config.input_quantization_config
+            assert b_cfg.state == RS.PASSIVE and torch.equal(b_cfg.scale, w_cfg.scale * i_cfg.scale)
+    # the input of the first operation set back to INITIAL: both refuse
+    for g, cls in ((prepared(), Ref), (prepared(), Ours)):
+        first = next(op for op in g.operations.values() if hasattr(op, 'config') and op.type == 'Conv')
+        first.config.input_quantization_config[0].state = RS.INITIAL
+        with pytest.raises(PermissionError): cls().optimize(g)
+
+
+def test_config_dominance_and_master_follow_the_reference_union_find():
+    """TensorQuantizationConfig.dominated_by / master_by (core/quant.py:647-713): a dominated config becomes OVERLAPPED and reads
+    its root's scale / offset (chains are compressed), a mastered one becomes PASSIVE (PASSIVE_INIT while the master has no
+    scale yet); self-domination is refused."""
+    from ppq_amd import LinearQuantizationConfig, QuantizationStates as S
+    a, b, c = LinearQuantizationConfig(), LinearQuantizationConfig(), LinearQuantizationConfig()
+    a.scale, a.offset = torch.tensor([0.5]), torch.tensor([0.0])
+    assert a.dominated_by is a and b.dominated_by is b
+    b.dominated_by = a
+    c.dominated_by = b
+    assert c.dominated_by is a and b.state == S.OVERLAPPED and c.state == S.OVERLAPPED and c.scale is a.scale
+    d, e = LinearQuantizationConfig(), LinearQuantizationConfig()
+    d.master_by = a
+    assert d.state == S.PASSIVE and d.scale is a.scale and d.master_by is a
+    e.master_by = LinearQuantizationConfig()
+    assert e.state == S.PASSIVE_INIT
+    with pytest.raises(ValueError): a.master_by = a
+    with pytest.raises(TypeError): a.dominated_by = 3
