@@ -226,6 +226,7 @@ __device__ __forceinline__ float fq_float_bwd_elem(float v, float d, float s, fl
 }
 
 constexpr uint32_t kFloatBwdChunk = 4096;      // elements per workgroup
+template <bool NT>
 __global__ __launch_bounds__(kBlock) void fq_float_bwd_row_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
     const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ partial, uint32_t epc, int vec_ok,
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(kBlock) void fq_float_bwd_row_kernel(
         for (uint32_t v = (lo >> 2) + threadIdx.x; v < v1; v += kBlock * 4) {
             float4 a[4], d[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) { const uint32_t at = min(v + u * kBlock, v1 - 1); a[u] = xv[at]; d[u] = dv[at]; }
+            for (int u = 0; u < 4; u++) { const uint32_t at = min(v + u * kBlock, v1 - 1); a[u] = load4<NT>(&xv[at]); d[u] = load4<NT>(&dv[at]); }
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 if (v + u * kBlock >= v1) break;
@@ -719,9 +720,15 @@ int ppqhip_fq_float_c_bwd(const float* x, const float* scale, const float* offse
     float* partial = (float*)scratch(s, sizeof(float) * (size_t)(rows * chunks));
     if (partial == nullptr) return PPQHIP_ERR_HIP;
     const int vec_ok = (elem_per_channel % 4 == 0 && aligned16(x) && aligned16(grad_y) && aligned16(grad_x)) ? 1 : 0;
-    hipLaunchKernelGGL(fq_float_bwd_row_kernel, dim3((uint32_t)(rows * chunks)), dim3(kBlock), 0, s, x, scale, offset, grad_y,
-                       grad_x, partial, (uint32_t)elem_per_channel, vec_ok, make_fastdiv(chunks),
-                       make_fastdiv((uint32_t)num_channel), fmt, clip_min, clip_max, rounding);
+    // x and dy together exceed cache residency from 96 MiB each: streaming (nontemporal) loads, as the linear backward kernels
+    if (n >= (24ll << 20))
+        hipLaunchKernelGGL(fq_float_bwd_row_kernel<true>, dim3((uint32_t)(rows * chunks)), dim3(kBlock), 0, s, x, scale, offset, grad_y,
+                           grad_x, partial, (uint32_t)elem_per_channel, vec_ok, make_fastdiv(chunks),
+                           make_fastdiv((uint32_t)num_channel), fmt, clip_min, clip_max, rounding);
+    else
+        hipLaunchKernelGGL(fq_float_bwd_row_kernel<false>, dim3((uint32_t)(rows * chunks)), dim3(kBlock), 0, s, x, scale, offset, grad_y,
+                           grad_x, partial, (uint32_t)elem_per_channel, vec_ok, make_fastdiv(chunks),
+                           make_fastdiv((uint32_t)num_channel), fmt, clip_min, clip_max, rounding);
     hipLaunchKernelGGL(fq_float_bwd_finish_kernel, dim3((uint32_t)num_channel), dim3(kBlock), 0, s, (const float*)partial,
                        (uint32_t)rows, chunks, (uint32_t)num_channel, denom, grad_s);
     return finish_launch("fq_float_c_bwd");

@@ -194,6 +194,38 @@ __global__ __launch_bounds__(kBlock) void to_int8_x16_kernel(const float* __rest
     *reinterpret_cast<uint4*>(out + i0) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// The same conversion with COALESCED loads: lane l of a workgroup reads float4 number base + l + u * kBlock (a wave reads
+// 1 KiB contiguous per instruction, U of them in flight; the x16 kernel above makes every lane walk its own 64-B segment, four
+// partial touches of each cache line) and writes the 4 bytes of each float4 as one dword: 256 B contiguous per wave and store.
+// Streaming (nontemporal) loads when the tensor exceeds cache residency.
+template <typename OUT, bool CHANNEL, bool NT>
+__global__ __launch_bounds__(kBlock) void to_int8_vec_kernel(const float4* __restrict__ x, const float* __restrict__ scale,
+                                                             const float* __restrict__ offset, uint32_t* __restrict__ out, uint32_t nvec,
+                                                             FastDiv vec_per_channel, FastDiv num_channel, float qmin, float qmax,
+                                                             int rounding) {
+    constexpr int U = 4;
+    const uint32_t base = blockIdx.x * (kBlock * U) + threadIdx.x;
+    float4 a[U];
+    float s[U], o[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t vv = min(base + u * kBlock, nvec - 1);      // clamped: loads stay unconditional
+        a[u] = load4<NT>(&x[vv]);
+        uint32_t c = 0;
+        if (CHANNEL) { const uint32_t row = fdiv(vv, vec_per_channel); c = row - fdiv(row, num_channel) * num_channel.d; }
+        s[u] = scale[c]; o[u] = offset[c];
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const uint32_t vv = base + u * kBlock;
+        if (vv < nvec) {
+            const int q0 = to_int_scalar(a[u].x, s[u], o[u], qmin, qmax, rounding), q1 = to_int_scalar(a[u].y, s[u], o[u], qmin, qmax, rounding);
+            const int q2 = to_int_scalar(a[u].z, s[u], o[u], qmin, qmax, rounding), q3 = to_int_scalar(a[u].w, s[u], o[u], qmin, qmax, rounding);
+            out[vv] = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
+        }
+    }
+}
+
 // --------------------------------------------------------------------------- LSQ backward
 // One element of QuantizeTensor_LT_B / _LC_B (linear.cu:255-274 / :352-372).  `o` is the rounded
 // offset kept as float, as in the reference; returns the partial d(loss)/d(scale) term.
@@ -319,7 +351,7 @@ __global__ __launch_bounds__(kLsqFinishBlock) void lsq_finish_kernel(const float
 
 // rows = outer * C rows of `epc` contiguous elements; block b handles chunk (b % chunks) of row
 // (b / chunks) -> one channel per block, one atomic per block (spread over C addresses).
-template <int R>
+template <int R, bool NT>
 __global__ __launch_bounds__(kBlock) void fq_linear_c_bwd_row_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
     const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ gs, uint32_t epc, int vec_ok,
@@ -350,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void fq_linear_c_bwd_row_kernel(
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 const uint32_t at = min(v + u * kBlock, v1 - 1);          // clamped: loads stay unconditional
-                a[u] = xv[at]; d[u] = dv[at];
+                a[u] = load4<NT>(&xv[at]); d[u] = load4<NT>(&dv[at]);
             }
 #pragma unroll
             for (int u = 0; u < U; u++) {
@@ -691,7 +723,10 @@ int ppqhip_fq_linear_multi(const ppqhip_fq_job* jobs, int num_jobs, int rounding
         bytes += 8.0 * (double)jobs[k].n;
     }
     LaunchScope scope(K_FQ_LINEAR_C, bytes, s);
-    constexpr int U = 2;
+#ifndef PPQHIP_FQM_U
+#define PPQHIP_FQM_U 2
+#endif
+    constexpr int U = PPQHIP_FQM_U;
     for (int base = 0; base < num_jobs; base += kFqMultiMax) {
         const int count = (num_jobs - base) < kFqMultiMax ? (num_jobs - base) : kFqMultiMax;
         FqMultiArgs args;
@@ -745,6 +780,31 @@ static int to_int_impl(const float* x, const float* scale, const float* offset, 
     const float qmin = (float)clip_min, qmax = (float)clip_max;
     // 1-byte outputs, 16-B aligned both ways, channels in whole groups of 16: the bulk goes through the 16-per-lane kernel,
     // the (< 16 element) rest through the general one
+#ifndef PPQHIP_TOINT_X16
+    // 1-byte outputs, 16-B aligned input, 4-B aligned output, channels in whole float4s: the coalesced kernel takes n / 4 groups,
+    // the (< 4 element) rest goes through the general one
+    if (out_dtype != 2 && aligned16(x) && (reinterpret_cast<uintptr_t>(out) % 4 == 0) && (!channel || epc % 4 == 0) && n >= 4) {
+        const uint32_t nvec = (uint32_t)(n / 4);
+        const dim3 gv((nvec + kBlock * 4 - 1) / (kBlock * 4));
+        const FastDiv vpc = make_fastdiv((uint32_t)(channel ? epc / 4 : 1));
+        const bool nt = n >= kStreamElems;
+#define PPQ_LAUNCH_TOINTV(T, CH, NT) hipLaunchKernelGGL((to_int8_vec_kernel<T, CH, NT>), gv, dim3(kBlock), 0, s, (const float4*)x, scale, \
+                                                        offset, (uint32_t*)out, nvec, vpc, nc, qmin, qmax, rounding)
+        if (out_dtype == 0) {
+            if (channel) { if (nt) PPQ_LAUNCH_TOINTV(int8_t, true, true); else PPQ_LAUNCH_TOINTV(int8_t, true, false); }
+            else { if (nt) PPQ_LAUNCH_TOINTV(int8_t, false, true); else PPQ_LAUNCH_TOINTV(int8_t, false, false); }
+        } else {
+            if (channel) { if (nt) PPQ_LAUNCH_TOINTV(uint8_t, true, true); else PPQ_LAUNCH_TOINTV(uint8_t, true, false); }
+            else { if (nt) PPQ_LAUNCH_TOINTV(uint8_t, false, true); else PPQ_LAUNCH_TOINTV(uint8_t, false, false); }
+        }
+#undef PPQ_LAUNCH_TOINTV
+        const int64_t done = (int64_t)nvec * 4;
+        if (done == n) return finish_launch(what);
+        if (!channel) return to_int_impl(x + done, scale, offset, (uint8_t*)out + done, n - done, 1, n - done, clip_min, clip_max, rounding,
+                                         out_dtype, false, stream, what);
+        set_error("%s: internal: ragged tail with channels", what); return PPQHIP_ERR_INVALID_VALUE;      // n % (C * epc) == 0 and epc % 4 == 0
+    }
+#endif
     if (out_dtype != 2 && aligned16(x) && aligned16(out) && (!channel || epc % 16 == 0) && n >= 16) {
         const uint32_t n16 = (uint32_t)(n / 16);
         const dim3 g16((n16 + kBlock - 1) / kBlock);
@@ -827,14 +887,14 @@ int ppqhip_fq_linear_c_bwd(const float* x, const float* scale, const float* offs
         const uint32_t chunks = (uint32_t)((elem_per_channel + chunk_elems - 1) / chunk_elems);
         const int64_t rows = n / elem_per_channel;
         const int vec_ok = (elem_per_channel % 4 == 0 && aligned16(x) && aligned16(grad_y) && aligned16(grad_x)) ? 1 : 0;
-        if (rounding == ROUND_HALF_EVEN)
-            hipLaunchKernelGGL((fq_linear_c_bwd_row_kernel<ROUND_HALF_EVEN>), dim3((uint32_t)(rows * chunks)),
-                               dim3(kBlock), 0, s, x, scale, offset, grad_y, grad_x, grad_s, (uint32_t)elem_per_channel,
-                               vec_ok, make_fastdiv(chunks), nc, chunk_elems, clip_min, clip_max, grad_factor, rounding);
-        else
-            hipLaunchKernelGGL((fq_linear_c_bwd_row_kernel<-1>), dim3((uint32_t)(rows * chunks)), dim3(kBlock), 0, s, x,
-                               scale, offset, grad_y, grad_x, grad_s, (uint32_t)elem_per_channel, vec_ok,
-                               make_fastdiv(chunks), nc, chunk_elems, clip_min, clip_max, grad_factor, rounding);
+        const bool nt = n >= kStreamElems / 2;      // x and dy together exceed cache residency: streaming loads (as lsq_bwd_t)
+#define PPQ_LAUNCH_LSQ_C(R, NT)                                                                                        \
+        hipLaunchKernelGGL((fq_linear_c_bwd_row_kernel<R, NT>), dim3((uint32_t)(rows * chunks)), dim3(kBlock), 0, s, x,   \
+                           scale, offset, grad_y, grad_x, grad_s, (uint32_t)elem_per_channel, vec_ok,                  \
+                           make_fastdiv(chunks), nc, chunk_elems, clip_min, clip_max, grad_factor, rounding)
+        if (rounding == ROUND_HALF_EVEN) { if (nt) PPQ_LAUNCH_LSQ_C(ROUND_HALF_EVEN, true); else PPQ_LAUNCH_LSQ_C(ROUND_HALF_EVEN, false); }
+        else { if (nt) PPQ_LAUNCH_LSQ_C(-1, true); else PPQ_LAUNCH_LSQ_C(-1, false); }
+#undef PPQ_LAUNCH_LSQ_C
     } else {
         const int use_lds = num_channel <= 8192;
         const size_t lds = use_lds ? sizeof(float) * (size_t)num_channel : 0;

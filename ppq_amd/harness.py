@@ -450,19 +450,25 @@ def quantize_graph(graph: BaseGraph, activation_algorithm: str = 'kl', per_chann
         for v in qop.outputs: v.source_op = qop
         graph.operations[name] = qop
     ops = list(graph.operations.values())
-    # QuantizeFusionPass: computing op followed by a single activation -> the conv output is not
-    # quantised on its own; passive operations share their input's quantisation
-    for op in ops:
-        out = op.outputs[0]
-        if op.type in COMPUTING_OP | {'Add'} and len(out.dest_ops) == 1 and out.dest_ops[0].type in {'Relu', 'Gelu'}:
-            op.config.output_quantization_config[0].state = QuantizationStates.OVERLAPPED
-        if op.type in PASSIVE_OPERATIONS:
-            op.config.output_quantization_config[0].state = QuantizationStates.OVERLAPPED
-    # QuantizeSimplifyPass: an input produced by a quantable op is already quantised by its producer
+    # The states AND the dominance links the reference's refine passes leave (TensorQuantizationConfig.dominated_by: an
+    # OVERLAPPED config reads its root's scale / offset, which is what PassiveParameterQuantizePass multiplies):
+    # QuantizeSimplifyPass (optim/refine.py): an input produced by a quantable op is already quantised by its producer
     for op in ops:
         for v, c in zip(op.inputs, op.config.input_quantization_config):
             if v.source_op is not None and is_initial(c):
-                c.state = QuantizationStates.OVERLAPPED
+                src = v.source_op
+                c.dominated_by = src.config.output_quantization_config[src.outputs.index(v)]        # -> OVERLAPPED
+    # QuantizeFusionPass: computing op followed by a single activation -> the conv output is not quantised on its own (the
+    # activation's output config rules it); passive operations share their input's quantisation
+    for op in ops:
+        out = op.outputs[0]
+        if op.type in COMPUTING_OP | {'Add'} and len(out.dest_ops) == 1 and out.dest_ops[0].type in {'Relu', 'Gelu'}:
+            op.config.output_quantization_config[0].dominated_by = out.dest_ops[0].config.output_quantization_config[0]
+        if op.type in PASSIVE_OPERATIONS:
+            first = op.config.input_quantization_config[0]
+            if first.dominated_by is not op.config.output_quantization_config[0].dominated_by:
+                op.config.output_quantization_config[0].dominated_by = first
+            else: op.config.output_quantization_config[0].state = QuantizationStates.OVERLAPPED
 
 
 class ParameterQuantizePass:

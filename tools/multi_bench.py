@@ -47,3 +47,39 @@ for name, fn in (('hist multi', lambda: CUDA.Histogram_T_Rows_Multi(xs, rows, sc
                  ('quantile per-tensor', per_tensor_quantile)):
     us = timed(fn)
     print(f'{name:18s} {us:9.1f} us  {total / us / 1e6:7.2f} TB/s')
+
+# ---- the weights of ResNet-50 (54 tensors, 0.01 .. 9 MB): ONE fake-quant launch / ONE min-max launch for all of them
+from ppq_amd import harness  # noqa: E402
+from ppq_amd.ffi import LinearQuantizePlan  # noqa: E402
+g = harness.resnet50_graph(seed=0)
+ws = [v.value.to(dev) for op in g.operations.values() for i, v in enumerate(op.inputs) if v.is_parameter and i == 1]
+wbytes = sum(w.numel() for w in ws) * 4
+scs = [torch.rand(w.shape[0], device=dev) * 0.01 + 0.001 for w in ws]
+ofs = [torch.zeros(w.shape[0], device=dev) for w in ws]
+plans = [LinearQuantizePlan([(w.clone() if k else w, s, o, 0, -128, 127) for w, s, o in zip(ws, scs, ofs)]) for k in range(4)]   # rotate 4 arenas
+mins = [torch.empty(w.shape[0], device=dev) for w in ws]; maxs = [torch.empty(w.shape[0], device=dev) for w in ws]
+k = [0]
+
+
+def fq_multi():
+    k[0] += 1
+    plans[k[0] % 4].run()
+
+
+def fq_per_tensor():
+    for w, s, o in zip(ws, scs, ofs): CUDA.LinearQuantize_C(w, s, o, 0, -128, 127, 0)
+
+
+def mm_per_tensor():
+    for w, a, b in zip(ws, mins, maxs):
+        a.fill_(float('inf')); b.fill_(float('-inf'))
+        CUDA.MinMax_C(w, 0, a, b)
+
+
+print(f'{len(ws)} weights, {wbytes / 1e6:.0f} MB')
+for name, fn, nbytes in (('fq_linear multi', fq_multi, 2 * wbytes), ('fq_linear per-tensor', fq_per_tensor, 2 * wbytes),
+                         ('minmax_c multi (fresh)', lambda: CUDA.MinMax_C_Multi(ws, [0] * len(ws), mins, maxs, True), wbytes),
+                         ('minmax_c per-tensor (+2 fills)', mm_per_tensor, wbytes)):
+    us = timed(fn)
+    print(f'{name:32s} {us:9.1f} us  {nbytes / us / 1e6:7.2f} TB/s')
+
