@@ -43,6 +43,7 @@ def _block_keys(block):
             if v.is_parameter and isinstance(v.value, torch.Tensor): keys.append(('p', v.name))
         if hasattr(op, 'config'):
             for i, (c, v) in enumerate(op.config_with_variable):
+                if c.dominated_by is not c: continue         # an OVERLAPPED config reads its root's scale: another op owns (and may train) it
                 if isinstance(c.scale, torch.Tensor): keys.append(('s', op.name, i))
                 if isinstance(c.offset, torch.Tensor): keys.append(('o', op.name, i))
     return keys
