@@ -622,6 +622,28 @@ def main():
                                and int(getattr(c.state, 'value', c.state)) == 4))
     merge_stats = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in m.items()} for m in p.merge_stats]
 
+    # roofline leg: the identical pass once more with hipEvent pairs around every library launch
+    # (measured right behind the timed passes, before the variants churn the allocator: the same tensors in the same memory state)
+    roof = None
+    prof_rows = []
+    if rank == 0:
+        graph2, ex2 = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params, bool(args.channels_last))
+        torch.cuda.synchronize()
+        _lib.lib.ppqhip_prof_enable(1)
+        if world == 1:
+            run_pass(graph2, ex2, batches, args.steps, args.method, False, False, bool(args.batch_observations), False,
+                     (args.queue_mib << 20) or None)   # eager, one stream -> clean event pairs
+        else:   # collectives need every rank; profile the local (non-merged) statistics path only
+            from ppq_amd.calibration import RuntimeCalibrationPass
+            pp = RuntimeCalibrationPass(method=args.method, check_steps=False, async_observe=False, use_hip_graph=False)
+            pp._render = lambda: __import__('ppq_amd.observer', fromlist=['render_observers']).render_observers(pp._all_tensor_observers())
+            pp.optimize(graph2, dataloader=batches, executor=ex2, calib_steps=args.steps)
+        torch.cuda.synchronize()
+        _lib.lib.ppqhip_prof_enable(0)
+        prof_rows = collect_prof()
+        del graph2, ex2
+        roof = roofline_entry(prof_rows, prefer={'vit_b16_fp8': ('fq_float',), 'resnet50_cfg3': ('hist_asym_t',)}.get(WORKLOAD))
+
     # BASELINE config 2 exactly as SURVEY 8(d) words it: batch 1, calib_steps 256 (launch-bound: HIP-graph replay pays)
     variants = []
     if args.variants and world == 1 and not (args.batch == 1 and args.steps == 256):
@@ -676,26 +698,6 @@ def main():
         torch.cuda.empty_cache()
         variants += workload_variants(args)
 
-    # roofline leg: the identical pass once more with hipEvent pairs around every library launch
-    roof = None
-    prof_rows = []
-    if rank == 0:
-        graph2, ex2 = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params, bool(args.channels_last))
-        torch.cuda.synchronize()
-        _lib.lib.ppqhip_prof_enable(1)
-        if world == 1:
-            run_pass(graph2, ex2, batches, args.steps, args.method, False, False, bool(args.batch_observations), False,
-                     (args.queue_mib << 20) or None)   # eager, one stream -> clean event pairs
-        else:   # collectives need every rank; profile the local (non-merged) statistics path only
-            from ppq_amd.calibration import RuntimeCalibrationPass
-            pp = RuntimeCalibrationPass(method=args.method, check_steps=False, async_observe=False, use_hip_graph=False)
-            pp._render = lambda: __import__('ppq_amd.observer', fromlist=['render_observers']).render_observers(pp._all_tensor_observers())
-            pp.optimize(graph2, dataloader=batches, executor=ex2, calib_steps=args.steps)
-        torch.cuda.synchronize()
-        _lib.lib.ppqhip_prof_enable(0)
-        prof_rows = collect_prof()
-        del graph2, ex2
-        roof = roofline_entry(prof_rows, prefer={'vit_b16_fp8': ('fq_float',), 'resnet50_cfg3': ('hist_asym_t',)}.get(WORKLOAD))
     if world > 1:
         barrier(world)
     torch.cuda.empty_cache()
