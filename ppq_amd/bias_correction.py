@@ -17,7 +17,8 @@ from typing import Callable, Iterable, List, Tuple
 
 import torch
 
-from .blocks import collect, compute_block_loss, split_graph_into_blocks, torch_mean_square_error
+from .blocks import (PrefixCache, collect, collect_all_fp_outputs, compute_block_loss, split_graph_into_blocks,
+                     torch_mean_square_error)
 from .calibration import QuantizationOptimizationPass
 from .ffi import CUDA
 
@@ -88,7 +89,16 @@ class BiasCorrectionPass(QuantizationOptimizationPass):
         self.report = []
         blocks = split_graph_into_blocks(graph, graph.topological_sort(), self.block_size,
                                          interested_layers=self.interested_layers)
-        for block in blocks:
-            qt_inputs, fp_outputs = collect(graph, block, executor, batches)
+        # FP32 targets of every block from ONE dequantised forward per batch (they depend on the parameters stored at quantisation
+        # time only) and quantised block inputs computed incrementally (blocks.PrefixCache: a corrected block invalidates what it
+        # feeds) -- the reference runs two full forwards per block and batch (training.py:224-298); same values
+        all_fp = collect_all_fp_outputs(graph, blocks, executor, batches)
+        prefix = PrefixCache(graph, executor, batches) if all_fp is not None else None
+        for k, block in enumerate(blocks):
+            if prefix is not None:
+                qt_inputs, fp_outputs = prefix.inputs_of(block), all_fp[k]
+                all_fp[k] = None
+            else: qt_inputs, fp_outputs = collect(graph, block, executor, batches)
             pre_loss, post_loss = self.correct_bias(qt_inputs, fp_outputs, block, executor, graph)
+            if prefix is not None: prefix.invalidate(block)
             self.report.append((block.sp.name, pre_loss, post_loss))

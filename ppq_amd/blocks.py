@@ -139,6 +139,19 @@ def collect(graph, block: TrainableBlock, executor, batches: Iterable, fp_output
     return qt_inputs, fp_outputs
 
 
+def collect_all_fp_outputs(graph, blocks: List['TrainableBlock'], executor, batches, max_resident_bytes: int = 64 << 30):
+    """``collect_fp_outputs`` for every block at once when the targets fit ``max_resident_bytes`` of HBM (judged from the first
+    batch), else None -- the caller then collects per block as the reference does.  The targets depend on the parameters stored
+    at quantisation time only (IR/quantize.py:124-160), so one dequantised forward per batch serves all blocks."""
+    batches = list(batches)
+    if not blocks or not batches: return [[] for _ in blocks]
+    first = collect_fp_outputs(graph, blocks, executor, batches[:1])
+    per_batch = sum(t.numel() * t.element_size() for per_block in first for d in per_block for t in d.values())
+    if per_batch * len(batches) > max_resident_bytes: return None
+    rest = collect_fp_outputs(graph, blocks, executor, batches[1:]) if len(batches) > 1 else [[] for _ in blocks]
+    return [a + b for a, b in zip(first, rest)]
+
+
 class PrefixCache:
     """The quantised activations a block-wise pass needs as block inputs, computed INCREMENTALLY.
 

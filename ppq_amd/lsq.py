@@ -472,16 +472,17 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
         # quantisation time -- what earlier blocks train does not move the targets of later ones, so the targets of EVERY
         # block come from ONE dequantised forward per batch (the reference runs that forward again for each block,
         # training.py:224-298: same values, 27 x the work on the YOLOv6-s-like graph; 288 GB of HBM hold them all)
-        from .blocks import PrefixCache, collect_fp_outputs
+        from .blocks import PrefixCache, collect_all_fp_outputs
         with self._phase('collect_fp_targets'):
-            all_fp = collect_fp_outputs(graph, blocks, executor, batches) if blocks else []
+            all_fp = collect_all_fp_outputs(graph, blocks, executor, batches) if self.incremental_inputs else None
         # quantised block inputs: incrementally (blocks.PrefixCache) -- the prefix of the graph runs once per batch overall
         prefix = PrefixCache(graph, executor, batches) if self.incremental_inputs else None
         for k, block in enumerate(blocks):
             with self._phase('collect_block_inputs'):
-                if prefix is not None: qt_inputs, fp_outputs = prefix.inputs_of(block), all_fp[k]
-                else: qt_inputs, fp_outputs = collect(graph, block, executor, batches, fp_outputs=all_fp[k])
-            all_fp[k] = None
+                targets = all_fp[k] if all_fp is not None else None       # None: too large to keep for all blocks -> per block
+                if prefix is not None and targets is not None: qt_inputs, fp_outputs = prefix.inputs_of(block), targets
+                else: qt_inputs, fp_outputs = collect(graph, block, executor, batches, fp_outputs=targets)
+            if all_fp is not None: all_fp[k] = None
             pre_loss, post_loss = self.finetune(block, executor, qt_inputs, fp_outputs)
             if prefix is not None: prefix.invalidate(block)
             self.report.append((str(block), pre_loss, post_loss))
