@@ -325,7 +325,16 @@ def test_prefix_cache_block_inputs_equal_the_full_forward_collection():
         want, _ = collect(graph, block, ex, batches, fp_outputs=fake_targets)
         for a, b in zip(got, want):
             assert set(a) == set(b)
-            for n in a: assert torch.equal(a[n], b[n]), (k, str(block), n)
+            for n in a:
+                # The two sides run the SAME operations on the same tensors, but at different times: MIOpen's FP32 convolutions are
+                # not bitwise repeatable run to run (atomics; DESIGN 6 notes the same of the headline's two forwards), and a sum
+                # that lands on the other side of a rounding tie moves a fake-quantised value by one step.  So: equal except for a
+                # handful of elements, each off by at most two INT8 steps of the tensor.
+                if torch.equal(a[n], b[n]): continue
+                step = float(b[n].abs().max()) / 127.0
+                diff = (a[n] - b[n]).abs()
+                assert float(diff.max()) <= 2.02 * step and float((diff > 0).float().mean()) <= 2e-3, \
+                    (k, str(block), n, float(diff.max()), step, float((diff > 0).float().mean()))
         with torch.no_grad():                                   # "train" the block: weights and activation scales move
             for op in block.rps:
                 for v in op.inputs:
