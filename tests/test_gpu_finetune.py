@@ -304,7 +304,8 @@ def test_prefix_cache_block_inputs_equal_the_full_forward_collection():
     """blocks.PrefixCache (quantised block inputs computed incrementally, TorchExecutor.forward_cached) against collect()'s full
     forward from the graph inputs (training.py:224-298), block after block on the YOLOv6-s-like graph (fan-outs, Concat, 6
     outputs), with the block's weights and scales CHANGED between two blocks the way training changes them: every block input of
-    every batch is bit-identical, and nothing stale survives an invalidation."""
+    every batch is the full forward's (bit for bit up to the vendor convolutions' own run-to-run rounding), and nothing stale
+    survives an invalidation (a stale input would differ everywhere, not on a handful of rounding ties)."""
     from ppq_amd import harness
     from ppq_amd.blocks import PrefixCache, collect, split_graph_into_blocks
     from ppq_amd.calibration import RuntimeCalibrationPass
