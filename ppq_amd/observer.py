@@ -136,6 +136,9 @@ class ObservationQueue:
     def add_minmax_c(self, value: torch.Tensor, channel_axis: int, mins: torch.Tensor, maxs: torch.Tensor, fresh: bool) -> None:
         """Per-channel running range (``CUDA.MinMax_C_Multi``); ``fresh``: mins / maxs are uninitialised and this item
         qualifies for being overwritten (``CUDA.minmax_c_fresh_ok``)."""
+        # one buffer, one job per launch: a second observation of the same observer must not share a launch with a pending
+        # `fresh` (overwriting) job of it -- the two would race on the buffer
+        if any(m.data_ptr() == mins.data_ptr() for _, _, m, _, _ in self._minmax_c): self.flush()
         self._minmax_c.append((value, channel_axis, mins, maxs, bool(fresh)))
         self._grow(value)
 
