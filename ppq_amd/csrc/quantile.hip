@@ -25,13 +25,9 @@
 //                             threshold with a known, sufficient number of keys beyond it, or ON a heavily tied answer).
 //                             With nothing open each returns on one load.
 //
-// The result is exact in every case; the hint only decides how much is read.  Hot path (a sequence of hints this process
-// has used before): init, filter, select A + three near-empty small-grid launches (the sample launch is skipped).
+// The result is exact in every case; the hint only decides how much is read.  Hot path: 7 launches, 4 of them return on one load.
 #include <cmath>
 #include <cstdlib>
-#include <mutex>
-#include <unordered_map>
-
 #include "common.hpp"
 
 namespace ppqhip {
@@ -1194,10 +1190,10 @@ __device__ __forceinline__ void quantile_f3_body(const QSeq& s, F3Lds& L) {
 // (Round 4 fused the three into ONE cooperative launch -- hipLaunchCooperativeKernel + grid.sync() between the passes, early
 // exit when nothing is open.  Correct, all quantile tests green, and SLOWER: a cooperative launch costs ~20 us on this stack
 // (B hinted 23.6 -> 41.1 us, Bx32 57.6 -> 76.3 us, in situ 0.75 -> 0.68 of the roofline; profiles/r04_quantile_coop.txt), so
-// the passes stay three ordinary launches that return on one load when nothing is open.  What the host CAN know is whether the
-// sequence is made of hints it has used before: then the sample launch is skipped and the three near-empty launches get a
-// small grid -- any grid is correct, every workgroup takes slices g, g + G, ..; a hinted job that does fall through to the
-// exact passes just finishes them on fewer workgroups.)
+// the passes stay three ordinary launches that return on one load when nothing is open.  Skipping the sample launch and shrinking
+// these grids for sequences made of already-used hints was measured too (Bx32 57.6 -> 55.6 us, within run-to-run noise: back to
+// back the near-empty launches overlap with the tail of the launch before them) and not kept: a hint that select A drops would
+// then leave its job to exact passes on a small grid instead of a resampled filter.)
 __global__ __launch_bounds__(kBlock) void quantile_f1_kernel(const QSeq s) {
     __shared__ F1Lds lds;
     if (!s.all_open && s.header[kGOpen] == 0u) return;
@@ -1220,16 +1216,6 @@ static int validate(int64_t n, const char* what) {
     return PPQHIP_OK;
 }
 
-// Hints this process has already handed to a sequence, with the (n, k_hi, k_lo) they were used for.  A job whose hint is in
-// here will almost certainly find it valid on the device, so a sequence made of such jobs skips the SAMPLE launch (it would
-// start, read one word and return).  Only an optimisation: the device still validates every hint; one that select A dropped
-// in the meantime leaves its job without thresholds, which the exact passes settle (and they write a working hint).
-static std::mutex g_seen_mu;
-static std::unordered_map<const void*, uint64_t> g_seen_hints;
-static uint64_t seen_tag(uint32_t n, uint32_t k_hi, uint32_t k_lo) {
-    return ((uint64_t)n * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)k_hi << 32) ^ (uint64_t)k_lo ^ 0x5bd1e995ull;
-}
-
 static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, float q, void* workspace, hipStream_t s,
                                const char* what) {
     uint8_t* prefix = (uint8_t*)workspace;
@@ -1239,7 +1225,6 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
         const int count = (num_jobs - seq_base) < kQMaxJobs ? (num_jobs - seq_base) : kQMaxJobs;
         uint32_t tiles = 0, units = 0;
         int64_t elems = 0;
-        bool all_seen = true;                      // every job brings a hint this process used before for the same ranks
         for (int base = 0; base < count; base += kQInitMax) {
             QInitArgs a;
             a.count = (uint32_t)((count - base) < kQInitMax ? (count - base) : kQInitMax);
@@ -1258,17 +1243,6 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
                 };
                 QUpload& e = a.e[k];
                 e.x = src.x; e.dest = src.dest; e.hint = src.hint; e.n = (uint32_t)n; e.k_hi = pos(q); e.k_lo = pos(1 - q); e.pad = 0;
-                if (src.hint == nullptr) all_seen = false;
-                else {
-                    const uint64_t tag = seen_tag(e.n, e.k_hi, e.k_lo);
-                    std::lock_guard<std::mutex> lk(g_seen_mu);
-                    auto it = g_seen_hints.find(src.hint);
-                    if (it == g_seen_hints.end() || it->second != tag) {
-                        all_seen = false;
-                        if (g_seen_hints.size() > (1u << 16)) g_seen_hints.clear();
-                        g_seen_hints[src.hint] = tag;
-                    }
-                }
                 tiles += q_job_tiles(e.n, aligned16(src.x));
                 units += q_job_units(e.n);
                 spec_at += 2 * (size_t)quantile_spec_cap((uint64_t)n);
@@ -1285,20 +1259,15 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
         seq.all_open = elems >= kQSpeculateMinElems ? 0u : 1u;
         const uint32_t cus = (uint32_t)num_cu();
         if (!seq.all_open) {
-            if (!all_seen) {
-                uint32_t gs = units < 1024u ? units : 1024u;
-                hipLaunchKernelGGL(quantile_sample_kernel, dim3(gs), dim3(kBlock), 0, s, seq);
-            }
+            uint32_t gs = units < 1024u ? units : 1024u;
+            hipLaunchKernelGGL(quantile_sample_kernel, dim3(gs), dim3(kBlock), 0, s, seq);      // returns on one load when no job is cold
             uint32_t gf = tiles / 2;                  // >= 2 tiles per workgroup
             if (gf < 1) gf = 1;
             if (gf > cus * kQFWgPerCu) gf = cus * kQFWgPerCu;
             hipLaunchKernelGGL(quantile_filter_kernel, dim3(gf), dim3(kQFBlock), 0, s, seq);
             hipLaunchKernelGGL(quantile_select_a_kernel, dim3(2 * (uint32_t)count), dim3(kQSABlock), 0, s, seq);
         }
-        // the exact passes: a full grid when a job may well need them (a cold job, a tiny sequence), a small one when every job
-        // rides a hint this process has used before (see the note above the kernels)
         uint32_t gF = tiles < cus * 4 ? tiles : cus * 4;
-        if (!seq.all_open && all_seen && gF > cus / 2) gF = cus / 2;
         if (gF < 1) gF = 1;
         hipLaunchKernelGGL(quantile_f1_kernel, dim3(gF), dim3(kBlock), 0, s, seq);
         hipLaunchKernelGGL(quantile_f2_kernel, dim3(gF), dim3(kBlock), 0, s, seq);
