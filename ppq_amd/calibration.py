@@ -282,6 +282,70 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
             self._render()
 
 
+class PPLDSPTIReCalibrationPass(RuntimeCalibrationPass):
+    """optim/calibration.py:216-322: the extra calibration the PPL DSP TI platforms ask for -- a PER-CHANNEL running range of
+    every computing operation's output (of the Relu / Clip behind it when that is its only consumer), plus a per-tensor range of
+    the graph's input where a computing operation reads it; nothing is rendered, the ranges are recorded in the consumer config's
+    ``detail['range_min' / 'range_max']``.  The observers are this package's device-resident min/max observers (per channel:
+    ``ppqhip_minmax_c``, no transpose-and-flatten copy per batch as in observer/range.py:99-107), read back with one copy each at
+    the end.  The per-tensor entries are 1-tuples, as the reference writes them (calibration.py:319-320 end in a comma)."""
+    def __init__(self, method: str = None, override: bool = False) -> None:
+        super().__init__(method, override)
+        self.name = 'PPQ ReCalibration For Computing Op Pass'
+
+    def optimize(self, graph, dataloader: Iterable, executor, calib_steps: int, collate_fn: Callable = None, **kwargs) -> None:
+        from .blocks import COMPUTING_OP, downstream_operations
+        from .core import QuantizationPolicy, QuantizationProperty as P, TensorQuantizationConfig
+        from .observer import CalibrationHook, TensorObserverFactroy, TorchMinMaxObserver
+        self._collate_fn, self._calib_steps = collate_fn, calib_steps
+        assert calib_steps >= 8, ('Insufficient Calibration Detected, to better quantize your network, more calibration steps is '
+                                  'demonded, we strongly recommend you to prepare more calibration data and more calibration '
+                                  'steps is preferred here. (at least 8)')
+        assert calib_steps <= 512, ('Calibration steps is too large, ppq is capable for quantizing your network within 32-128 '
+                                    'calibration steps. More calibraiton steps will greatly delay ppq\'s calibration procedure. '
+                                    'Reset your calib_steps parameter please.')
+
+        def probe(like, per_channel: bool, consumer):
+            bits = P.SYMMETRICAL.value + P.LINEAR.value + (P.PER_CHANNEL.value if per_channel else P.PER_TENSOR.value)
+            return TensorQuantizationConfig(policy=QuantizationPolicy(bits), rounding=like.rounding, num_of_bits=like.num_of_bits,
+                                            quant_min=like.quant_min, quant_max=like.quant_max, scale=None, offset=None,
+                                            observer_algorithm='Minmax', state=QuantizationStates.INITIAL,
+                                            channel_axis=1 if per_channel else None, detail={'consumer': consumer})
+        hooks = {}
+        for operation in graph.topological_sort():
+            if not hasattr(operation, 'config') or operation.type not in COMPUTING_OP: continue
+            output_cfg = operation.config.output_quantization_config[0]
+            master_cfg, master_operation, master_var = output_cfg, operation, operation.outputs[0]
+            table = {}
+            if operation.inputs[0].name in graph.inputs:            # is all input data greater than 0? a basic range suffices
+                input_cfg = operation.config.input_quantization_config[0]
+                table[input_cfg] = TensorObserverFactroy.build_observer(operation.inputs[0], probe(input_cfg, False, input_cfg))
+            followers = downstream_operations(operation)
+            if len(followers) == 1 and followers[0].type in {'Relu', 'Clip'} and hasattr(followers[0], 'config'):
+                if table:
+                    hooks[operation.name] = CalibrationHook(operation, table)
+                    table = {}
+                master_operation = followers[0]
+                master_cfg = master_operation.config.output_quantization_config[0]
+                master_var = master_operation.outputs[0]
+            table[master_cfg] = TensorObserverFactroy.build_observer(master_var, probe(master_cfg, True, output_cfg))
+            assert master_operation.name not in hooks, 'register an operation in calibration hooks twice'
+            hooks[master_operation.name] = CalibrationHook(master_operation, table)
+
+        self._queue = None
+        self.calibrate(desc='ReCalibration For Computing Ops', dataloader=dataloader, executor=executor, hooks=hooks)
+
+        for hook in hooks.values():
+            for observer in hook._observer_table.values():
+                cfg = observer._quant_cfg.detail['consumer']
+                assert isinstance(observer, TorchMinMaxObserver)
+                r = observer._range_on_host()
+                if observer._quant_cfg.policy.has_property(P.PER_CHANNEL):
+                    cfg.detail.update({'range_min': r[0].copy(), 'range_max': r[1].copy()})
+                else:
+                    cfg.detail.update({'range_min': (float(r[0]),), 'range_max': (float(r[1]),)})
+
+
 class IsotoneCalibrationPass(RuntimeCalibrationPass):
     """optim/calibration.py:325-423.  Marks classification outputs for the order-preserving 'isotone' observer -- by default the
     output of every Softmax that owns its config, otherwise the variables named in ``variables`` with ``axis`` as the class

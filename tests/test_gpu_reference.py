@@ -328,3 +328,52 @@ def test_isotone_observer_equals_the_reference(symmetrical):
         assert torch.equal(oc.scale.cpu().reshape(-1), rc.scale.cpu().reshape(-1)), (oc.scale, rc.scale)
         assert torch.equal(oc.offset.cpu().reshape(-1), rc.offset.cpu().reshape(-1)), (oc.offset, rc.offset)
 
+
+def test_reference_ti_recalibration_pass_on_hip_vs_this_package():
+    """optim/calibration.py:216-322 (PPLDSPTIReCalibrationPass): the reference's own pass on its own graph / executor (GPU, these
+    kernels installed) vs ppq_amd.calibration.PPLDSPTIReCalibrationPass on the harness, same weights and batches, both after the
+    same calibration: the same configs receive `range_min` / `range_max`, the per-channel ranges (the output of every computing
+    operation, or of the Relu behind it) agree channel by channel to float noise of the vendor convolutions, the per-tensor range
+    of the graph input exactly, and the per-tensor entries are the reference's 1-tuples."""
+    import ppq_amd
+    from ppq_amd import harness
+    from ppq_amd.calibration import PPLDSPTIReCalibrationPass, RuntimeCalibrationPass
+    RI.load()
+    ppq_amd.install_into_ppq()
+    from ppq.quantization.optim import PPLDSPTIReCalibrationPass as RefPass
+    g = torch.Generator().manual_seed(11)
+    batches = [torch.rand(4, 3, 32, 32, generator=g).to(DEV) * 2 - 0.5 for _ in range(8)]
+    rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(harness.small_cnn_graph(seed=0)), DEV, batches[0], method='minmax')
+    RI.calibrate(rg, rex, batches, method='minmax')
+    RefPass().optimize(graph=rg, dataloader=batches, executor=rex, calib_steps=8, collate_fn=None)
+    hg = harness.small_cnn_graph(seed=0)
+    harness.quantize_graph(hg, 'minmax')
+    hex_ = harness.TorchExecutor(hg, DEV)
+    harness.ParameterQuantizePass().optimize(hg)
+    RuntimeCalibrationPass(method='minmax').optimize(hg, dataloader=batches, executor=hex_, calib_steps=8)
+    PPLDSPTIReCalibrationPass().optimize(hg, dataloader=batches, executor=hex_, calib_steps=8)
+
+    def ranges(graph):
+        out = {}
+        for op in graph.operations.values():
+            if not hasattr(op, 'config'): continue
+            for i, (c, v) in enumerate(op.config_with_variable):
+                if 'range_min' in c.detail: out[(op.name, i)] = (c.detail['range_min'], c.detail['range_max'])
+        return out
+    ref, ours = ranges(rg), ranges(hg)
+    assert set(ref) == set(ours) and len(ours) >= 4, sorted(set(ref) ^ set(ours))
+    per_channel = per_tensor = 0
+    for key in ref:
+        (rmin, rmax), (omin, omax) = ref[key], ours[key]
+        if isinstance(rmin, tuple):
+            assert isinstance(omin, tuple) and len(omin) == 1 and omin == rmin and omax == rmax, (key, omin, rmin)     # the graph input: same bits
+            per_tensor += 1
+        else:
+            assert omin.shape == rmin.shape and omin.dtype == rmin.dtype
+            scale = max(float(np.abs(rmax).max()), 1e-6)
+            assert np.abs(omin - rmin).max() <= 1e-5 * scale and np.abs(omax - rmax).max() <= 1e-5 * scale, key
+            per_channel += 1
+    assert per_channel >= 3 and per_tensor >= 1
+    with pytest.raises(AssertionError):
+        PPLDSPTIReCalibrationPass().optimize(hg, dataloader=batches, executor=hex_, calib_steps=4)
+
