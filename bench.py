@@ -164,15 +164,12 @@ def build_workload(dev, bins, method, cache_params=False, fuse_params=True, chan
     return graph, ex
 
 
-OVERLAP_STATS = False        # --overlap-stats: RuntimeCalibrationPass(overlap_statistics=True)
-
-
 def run_pass(graph, ex, batches, steps, method, async_observe=False, hip_graph=False, batch_observations=True,
              reuse_activations=False, queue_bytes=None, decompose=None):
     from ppq_amd.calibration import RuntimeCalibrationPass
     p = RuntimeCalibrationPass(method=method, check_steps=False, async_observe=async_observe, use_hip_graph=hip_graph,
                                batch_observations=batch_observations, reuse_activations=reuse_activations,
-                               queue_bytes=queue_bytes, overlap_statistics=OVERLAP_STATS and not hip_graph)
+                               queue_bytes=queue_bytes)
     if TRACE_STEPS is not None:          # --trace-steps: host timestamp + device event after every forward
         inner = p._forward
 
@@ -549,16 +546,13 @@ def main():
     ap.add_argument('--reuse-activations', type=int, default=0,
                     help='OPT-IN, off for the headline number: keep the phase-1 activations in HBM and bin them in phase 2 instead of running the forward again')
     ap.add_argument('--queue-mib', type=int, default=0, help='debug: ObservationQueue flush threshold (MiB), 0 = default')
-    ap.add_argument('--overlap-stats', type=int, default=0, help='issue each forward\'s statistics launch on a side stream so that it '
-                    'overlaps the next forward (same work, same results)')
     ap.add_argument('--channels-last', type=int, default=0, help='activations and conv weights in channels-last (NHWC) memory format')
     ap.add_argument('--cache-params', type=int, default=0, help='keep fake-quantised weights resident between forwards')
     ap.add_argument('--miopen-find', type=int, default=1, help='torch.backends.cudnn.benchmark (MIOpen find mode)')
     args = ap.parse_args()
 
-    global WORKLOAD, OVERLAP_STATS
+    global WORKLOAD
     WORKLOAD = args.workload
-    OVERLAP_STATS = bool(args.overlap_stats)
     if WORKLOADS[WORKLOAD][1] is not None: args.method = WORKLOADS[WORKLOAD][1]
     if WORKLOAD != 'resnet50':              # the reference-CPU legs and the batch-1 variant describe config 2 only
         args.no_cpu_baseline = args.no_cpu_ops = True

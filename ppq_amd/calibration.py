@@ -56,7 +56,7 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
                  process_group=None, check_steps: bool = True, async_observe: bool = False,
                  use_hip_graph: bool = False, batch_observations: bool = True,
                  reuse_activations: bool = False, reuse_budget_bytes: int = 64 << 30,
-                 queue_bytes: int = None, overlap_statistics: bool = False) -> None:
+                 queue_bytes: int = None) -> None:
         super().__init__(name='PPQ Runtime Calibration Pass')
         self._method = method
         self._observers: Dict[str, OperationObserver] = {}
@@ -72,8 +72,6 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         self._reuse_activations = reuse_activations
         self._queue_bytes = queue_bytes
         self._reuse_budget = reuse_budget_bytes
-        self._overlap_statistics = overlap_statistics
-        self._stats_stream = None
         self._replay: list = []            # per phase-1 batch: [(hist observer, activation tensor)]
         self._replay_bytes = 0
         self.replay_peak_bytes = 0          # most activation bytes ever kept resident for a phase-2 replay
@@ -199,9 +197,6 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         if self._side_stream is not None:          # join the observer stream before reading statistics
             import torch
             torch.cuda.current_stream().wait_stream(self._side_stream)
-        if self._stats_stream is not None:         # overlap_statistics: the last forward's statistics launch may still be running
-            import torch
-            torch.cuda.current_stream().wait_stream(self._stats_stream)
         if merge_observers(observers, group=self._process_group):
             from . import distributed
             self.merge_stats.append(dict(distributed.last_merge_stats))
@@ -252,10 +247,6 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         if self._batch_observations and self._side_stream is None:
             from .observer import ObservationQueue
             self._queue = ObservationQueue() if self._queue_bytes is None else ObservationQueue(self._queue_bytes)
-        if (self._queue is not None and self._overlap_statistics and not self._use_hip_graph and not self._reuse_activations
-                and torch.cuda.is_available()):
-            self._stats_stream = torch.cuda.Stream()
-            self._queue.stream = self._stats_stream
         for ob in self._all_tensor_observers(): ob.queue = self._queue
 
         self._replay, self._replay_bytes = [], 0

@@ -120,12 +120,6 @@ class ObservationQueue:
         self._max = max_pending_bytes
         self.launches = 0
         self.recorder: Optional[list] = None   # RuntimeCalibrationPass(reuse_activations=True): (observer, tensor) of phase 1
-        # RuntimeCalibrationPass(overlap_statistics=True): every flush is issued on this side stream (it first waits for the
-        # current stream, i.e. for the forward that produced the tensors), so the HBM-bound statistics launch of forward i runs
-        # while the compute-bound convolutions of forward i + 1 already occupy the main stream.  The launches only READ the queued
-        # tensors (kept alive for the allocator with record_stream) and write observer buffers that nothing else touches before
-        # the render, which joins the stream.
-        self.stream = None
 
     def __len__(self):
         return (len(self._minmax) + len(self._minmax_c) + sum(len(v) for v in self._hist.values())
@@ -161,20 +155,6 @@ class ObservationQueue:
         return dest
 
     def flush(self) -> None:
-        if self.stream is None or not len(self): return self._flush()
-        self.stream.wait_stream(torch.cuda.current_stream())
-        for v in self._pending_tensors(): v.record_stream(self.stream)
-        with torch.cuda.stream(self.stream): self._flush()
-
-    def _pending_tensors(self):
-        for v, _ in self._minmax: yield v
-        for it in self._minmax_c: yield it[0]
-        for items in self._hist.values():
-            for it in items: yield it[0]
-        for items in self._quantile.values():
-            for it in items: yield it[0]
-
-    def _flush(self) -> None:
         if self._quantile:
             pending, self._quantile = self._quantile, {}
             for (q, _), items in pending.items():
@@ -226,9 +206,7 @@ class BaseTensorObserver:
 
     def _drain(self) -> None:
         """Statistics are about to be read: make sure nothing of this pass is still queued."""
-        if self.queue is not None and len(self.queue):
-            self.queue.flush()
-            if self.queue.stream is not None: torch.cuda.current_stream().wait_stream(self.queue.stream)     # the reader is on this stream
+        if self.queue is not None and len(self.queue): self.queue.flush()
 
     def observe(self, value):
         raise NotImplementedError('Implement this function first.')
