@@ -248,18 +248,26 @@ def op_table(bins: int = 2048, tensors=('A', 'B', 'Bx32')) -> list:
     with torch.no_grad():
         for name in tensors:
             x = torch.randn(*shapes[name], generator=g)
+            # Bx32 rotates over 6 copies (1.2 GB between two uses of a buffer), like tools/microbench.py on the GPU: a single
+            # 205 MB tensor stays resident in the host's L3 and the row would report cache, not DRAM, bandwidth
+            pool = [x] + ([x.clone() for _ in range(5)] if name == 'Bx32' else [])
+            turn = [0]
+
+            def nxt(pool=pool, turn=turn):
+                turn[0] += 1
+                return pool[turn[0] % len(pool)]
             n, C = x.numel(), x.shape[1]
             s1 = torch.tensor(float(x.abs().max()) * 2 / 255); o1 = torch.tensor(0.0)
             sc = torch.rand(C, generator=g) * 0.05 + 0.01; oc = torch.randint(0, 255, [C], generator=g).float()
             hs = float(x.abs().max()) / bins
             lo, hi = float(x.min()), float(x.max())
             hist = torch.zeros(bins, dtype=torch.int32)
-            cases = [('fq_linear_t', 8, lambda: fq_linear_t(x, s1, o1, -128, 127)),
-                     ('fq_linear_c', 8, lambda: fq_linear_c(x, sc, oc, 1, 0, 255)),
-                     ('hist_sym_t', 4, lambda: hist_sym(x, hist, hs)),
-                     ('hist_asym_t', 4, lambda: hist_asym(x, hist, lo, hi)),
-                     ('minmax_t', 4, lambda: minmax_t(x)),
-                     ('minmax_c', 4, lambda: minmax_c(x, 1))]
+            cases = [('fq_linear_t', 8, lambda: fq_linear_t(nxt(), s1, o1, -128, 127)),
+                     ('fq_linear_c', 8, lambda: fq_linear_c(nxt(), sc, oc, 1, 0, 255)),
+                     ('hist_sym_t', 4, lambda: hist_sym(nxt(), hist, hs)),
+                     ('hist_asym_t', 4, lambda: hist_asym(nxt(), hist, lo, hi)),
+                     ('minmax_t', 4, lambda: minmax_t(nxt())),
+                     ('minmax_c', 4, lambda: minmax_c(nxt(), 1))]
             if name != 'Bx32': cases.append(('percentile', 4, lambda: percentile(x)))
             for op, bpe, fn in cases:
                 ms = _median_ms(fn)
