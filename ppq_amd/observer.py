@@ -65,6 +65,39 @@ def minmax_to_scale_offset(min_val: float, max_val: float, config,
     return scale, offset
 
 
+def minmax_to_scale_offset_channels(mins: np.ndarray, maxs: np.ndarray, config,
+                                    scale_threshold: float = OBSERVER_MIN_SCALE) -> Tuple[list, list]:
+    """``[minmax_to_scale_offset(a, b, config) for a, b in zip(mins, maxs)]`` for float32 per-channel ranges -- what the
+    per-channel render loops over (range.py:122-129; 26 560 channels for ResNet-50's weights) -- evaluated on whole arrays.
+    Same arithmetic, operation by operation, as the scalar function sees it with numpy float32 scalars under numpy >= 2:
+    the clamps to 0, ``max_val - min_val`` and ``-min_val / scale`` in FLOAT32 (NEP 50: the Python-float scale is cast to the
+    array's type), everything else in double, the offset rounded half-even on the exact value (``Decimal.quantize`` ==
+    ``rint`` there).  POWER_OF_2 configs keep the scalar loop (``math.log2`` vs ``numpy.log2`` may differ in the last place).
+    Bit-identical to the loop: tests/test_host_cpu.py::test_vectorised_channel_render_equals_the_scalar_loop."""
+    if config.policy.has_property(P.POWER_OF_2) or mins.dtype != np.float32 or maxs.dtype != np.float32:
+        pairs = [minmax_to_scale_offset(a, b, config, scale_threshold) for a, b in zip(mins, maxs)]
+        return [p[0] for p in pairs], [p[1] for p in pairs]
+    if OBSERVER_MIN_SCALE_MANUL_OVERRIDE in config.detail:
+        scale_threshold = config.detail[OBSERVER_MIN_SCALE_MANUL_OVERRIDE]
+    zero = np.float32(0)
+    lo = np.where(mins > 0, zero, mins)                       # NaN compares false: stays, as in `if min_val > 0`
+    hi = np.where(maxs < 0, zero, maxs)
+    levels = config.quant_max - config.quant_min
+    if config.policy.has_property(P.ASYMMETRICAL):
+        with np.errstate(over='ignore', divide='ignore', invalid='ignore'):
+            scale = (hi - lo).astype(np.float64) / levels      # float32 subtraction (may overflow to inf, as the scalar does), double division
+            scale = np.where(scale_threshold > scale, scale_threshold, scale)      # max(scale, threshold): the first wins ties / NaN
+            offset = np.rint(((-lo) / scale.astype(np.float32)).astype(np.float64))
+        return scale.tolist(), [int(v) for v in offset.tolist()]
+    if config.policy.has_property(P.SYMMETRICAL):
+        a, b = np.abs(hi), np.abs(lo)
+        m = np.where(b > a, b, a)                              # max(abs(max_val), abs(min_val)): the first unless the second is greater
+        scale = 2 * m.astype(np.float64) / levels
+        scale = np.where(scale_threshold > scale, scale_threshold, scale)
+        return scale.tolist(), [0] * int(scale.size)
+    raise TypeError('Tensor Min Max Observer Excepts either ASYMMETRICAL or SYMMETRICAL quantization config.')
+
+
 _DEFERRED_SETS: Optional[list] = None      # render_observers: collect, then ONE host-to-device copy
 
 
@@ -346,10 +379,8 @@ class TorchMinMaxObserver(BaseTensorObserver):
             scale, offset = minmax_to_scale_offset(min_val=float(r[0]), max_val=float(r[1]), config=cfg)
             _set_per_tensor(cfg, scale, offset, device)
         elif cfg.policy.has_property(P.PER_CHANNEL):
-            scales, offsets = [], []
-            for min_val, max_val in zip(r[0], r[1]):         # numpy float32 scalars, as in range.py:125-129
-                scale, offset = minmax_to_scale_offset(min_val=min_val, max_val=max_val, config=cfg)
-                scales.append(scale); offsets.append(offset)
+            # (the reference loops over numpy float32 scalars, range.py:125-129; the same arithmetic on whole arrays)
+            scales, offsets = minmax_to_scale_offset_channels(np.ascontiguousarray(r[0]), np.ascontiguousarray(r[1]), cfg)
             if _DEFERRED_SETS is not None:                      # render_observers: one host-to-device copy for all configs
                 _DEFERRED_SETS.append((cfg, scales, offsets, device))
                 return

@@ -878,3 +878,33 @@ def test_config_dominance_and_master_follow_the_reference_union_find():
     assert e.state == S.PASSIVE_INIT
     with pytest.raises(ValueError): a.master_by = a
     with pytest.raises(TypeError): a.dominated_by = 3
+
+
+def test_vectorised_channel_render_equals_the_scalar_loop():
+    """observer.minmax_to_scale_offset_channels (whole arrays) == the reference's per-channel loop over numpy float32 scalars
+    (range.py:122-129 -> minmax_to_scale_offset) element for element: scales compared as the float32 values the render stores AND
+    as doubles, offsets as integers -- symmetric / asymmetric, int8 / uint8 / int4, ranges that are all-positive, all-negative,
+    zero, denormal, huge, below the scale threshold, with a manual threshold override; POWER_OF_2 takes the scalar path."""
+    from ppq_amd import LinearQuantizationConfig
+    from ppq_amd.core import OBSERVER_MIN_SCALE_MANUL_OVERRIDE
+    from ppq_amd.observer import minmax_to_scale_offset, minmax_to_scale_offset_channels
+    rng = np.random.default_rng(0)
+    n = 20000
+    a = (rng.standard_normal(n) * 10 ** rng.uniform(-9, 6, n)).astype(np.float32)
+    b = (rng.standard_normal(n) * 10 ** rng.uniform(-9, 6, n)).astype(np.float32)
+    mins, maxs = np.minimum(a, b), np.maximum(a, b)
+    special = np.array([0, -0.0, 1e-45, -1e-45, 3e38, -3e38, 1e-9, -1e-9, 127.5, -127.5, 0.5, -0.5, 255, 1, 2, 3], np.float32)
+    mins = np.concatenate([mins, special, special, np.zeros_like(special), -np.abs(special)])
+    maxs = np.concatenate([maxs, special, np.zeros_like(special), special, np.abs(special)])
+    for sym, qmin, qmax, pow2, override in ((True, -128, 127, False, None), (False, 0, 255, False, None), (True, -8, 7, False, None),
+                                           (False, -128, 127, False, None), (True, -128, 127, False, 1e-3), (False, 0, 255, False, 1e-3),
+                                           (True, -128, 127, True, None)):
+        cfg = LinearQuantizationConfig(symmetrical=sym, quant_min=qmin, quant_max=qmax, power_of_2=pow2, channel_axis=0)
+        if override is not None: cfg.detail[OBSERVER_MIN_SCALE_MANUL_OVERRIDE] = override
+        want = [minmax_to_scale_offset(x, y, cfg) for x, y in zip(mins, maxs)]
+        got_s, got_o = minmax_to_scale_offset_channels(mins, maxs, cfg)
+        assert len(got_s) == len(want) == len(got_o)
+        ws = np.array([w[0] for w in want], np.float64); gs = np.array(got_s, np.float64)
+        assert np.array_equal(ws, gs), (sym, qmin, np.nonzero(ws != gs)[0][:5])
+        assert np.array_equal(ws.astype(np.float32), gs.astype(np.float32))
+        assert [int(w[1]) for w in want] == [int(v) for v in got_o], (sym, qmin)
