@@ -305,8 +305,11 @@ def test_prefix_cache_block_inputs_equal_the_full_forward_collection():
     """blocks.PrefixCache (quantised block inputs computed incrementally, TorchExecutor.forward_cached) against collect()'s full
     forward from the graph inputs (training.py:224-298), block after block on the YOLOv6-s-like graph (fan-outs, Concat, 6
     outputs), with the block's weights and scales CHANGED between two blocks the way training changes them: every block input of
-    every batch is the full forward's (bit for bit up to the vendor convolutions' own run-to-run rounding), and nothing stale
-    survives an invalidation (a stale input would differ everywhere, not on a handful of rounding ties)."""
+    every batch is bit for bit the full forward's.
+    The vendor convolutions must be repeatable for that statement to be testable: MIOpen answers the first calls of a shape with
+    whatever algorithm its search has reached (tools/prefix_diag.py: two IDENTICAL full forwards differed by up to 14 INT8 steps on a
+    fresh box, then settled), so the executor is warmed first and deterministic algorithms are requested; a comparison is only
+    counted when the full forward reproduces itself at that moment, and nearly all of them must be."""
     from ppq_amd import harness
     from ppq_amd.blocks import PrefixCache, collect, split_graph_into_blocks
     from ppq_amd.calibration import RuntimeCalibrationPass
@@ -320,31 +323,36 @@ def test_prefix_cache_block_inputs_equal_the_full_forward_collection():
     RuntimeCalibrationPass(check_steps=False).optimize(graph, dataloader=batches, executor=ex, calib_steps=2)
     blocks = split_graph_into_blocks(graph, graph.topological_sort(), 5)
     assert len(blocks) >= 20
-    prefix = PrefixCache(graph, ex, batches)
-    fake_targets = [{} for _ in batches]
-    for k, block in enumerate(blocks):
-        got = prefix.inputs_of(block)
-        want, _ = collect(graph, block, ex, batches, fp_outputs=fake_targets)
-        for a, b in zip(got, want):
-            assert set(a) == set(b)
-            for n in a:
-                # The two sides run the SAME operations on the same tensors, but at different times: MIOpen's FP32 convolutions are
-                # not bitwise repeatable run to run (atomics; DESIGN 6 notes the same of the headline's two forwards), and a sum
-                # that lands on the other side of a rounding tie moves a fake-quantised value by one step.  So: equal except for a
-                # handful of elements, each off by at most two INT8 steps of the tensor.
-                if torch.equal(a[n], b[n]): continue
-                step = float(b[n].abs().max()) / 127.0
-                diff = (a[n] - b[n]).abs()
-                assert float(diff.max()) <= 2.02 * step and float((diff > 0).float().mean()) <= 2e-3, \
-                    (k, str(block), n, float(diff.max()), step, float((diff > 0).float().mean()))
-        with torch.no_grad():                                   # "train" the block: weights and activation scales move
-            for op in block.rps:
-                for v in op.inputs:
-                    if v.is_parameter and isinstance(v.value, torch.Tensor) and v.value.dim() == 4: v.value.mul_(1.0 + 0.01 * (k % 3))
-                if hasattr(op, 'config'):
-                    for c, v in op.config_with_variable:
-                        if not v.is_parameter and isinstance(c.scale, torch.Tensor) and c.state.value == 4: c.scale.mul_(1.02)
-        prefix.invalidate(block)
+    was = torch.backends.cudnn.deterministic
+    torch.backends.cudnn.deterministic = True
+    try:
+        for _ in range(3):
+            for b in batches: ex.forward(b)                       # let MIOpen settle on its kernels for every shape of the graph
+        prefix = PrefixCache(graph, ex, batches)
+        fake_targets = [{} for _ in batches]
+        compared = inconclusive = 0
+        for k, block in enumerate(blocks):
+            got = prefix.inputs_of(block)
+            want, _ = collect(graph, block, ex, batches, fp_outputs=fake_targets)
+            again, _ = collect(graph, block, ex, batches, fp_outputs=fake_targets)
+            for a, b, c in zip(got, want, again):
+                assert set(a) == set(b)
+                for n in a:
+                    if not torch.equal(b[n], c[n]): inconclusive += 1; continue       # the yardstick itself moved
+                    compared += 1
+                    assert torch.equal(a[n], b[n]), (k, str(block), n, float((a[n] - b[n]).abs().max()))
+            with torch.no_grad():                                   # "train" the block: weights and activation scales move
+                for op in block.rps:
+                    for v in op.inputs:
+                        if v.is_parameter and isinstance(v.value, torch.Tensor) and v.value.dim() == 4: v.value.mul_(1.0 + 0.01 * (k % 3))
+                    if hasattr(op, 'config'):
+                        for c, v in op.config_with_variable:
+                            if not v.is_parameter and isinstance(c.scale, torch.Tensor) and c.state.value == 4 and c.dominated_by is c:
+                                c.scale.mul_(1.02)
+            prefix.invalidate(block)
+    finally:
+        torch.backends.cudnn.deterministic = was
+    assert compared >= 40 and inconclusive <= compared // 4, (compared, inconclusive)
 
 
 def test_passive_bias_policy_rides_a_passive_delegator_through_lsq():
