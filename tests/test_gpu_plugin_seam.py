@@ -34,11 +34,37 @@ def _scales(graph):
     return out
 
 
-def _assert_equal(name, got, want):
+def _assert_equal(name, got, want, hist_observers=None):
+    """Scales to 1e-6 relative, offsets exactly.  ONE documented exception, KL only (``hist_observers``: variable name -> this
+    package's histogram observer): the reference searches on the CPU in float32 torch sums whose order depends on the host's
+    SIMD width, the kernel sums in its own fixed order; once a histogram holds more than 2^24 counts those float32 sums are
+    inexact and the two KL values of a candidate agree to ~1e-7 only -- so when two NEIGHBOURING candidates are tied to that
+    precision the arg-min may fall on either (seen on about one lease in eight, one config of ResNet-50's 72).  Such a config
+    passes only if the reference's own arithmetic (oracle.kl_search, pinned to the reference) rates the two candidates within
+    1e-5 relative of each other; at most two per graph."""
     assert set(got) == set(want), (name, sorted(set(got) ^ set(want)))
     bad = {k: (got[k], want[k]) for k in want
            if not (torch.allclose(got[k][0], want[k][0], rtol=1e-6, atol=0) and torch.equal(got[k][1], want[k][1]))}
-    assert not bad, (name, len(bad), list(bad.items())[:3])
+    ties = {}
+    if bad and hist_observers:
+        from oracle import ppq_oracle as O
+        for k in list(bad):
+            ob = hist_observers.get(k)
+            if ob is None or not torch.equal(got[k][1], want[k][1]): continue
+            hs = float(ob._hist_scale)
+            _, _, losses, _ = O.kl_search(ob.histogram().cpu().numpy(), hs, return_losses=True)
+            kl = {d['bin_range']: d['kl'] for d in losses}
+            ra, rb = (int(round(float(t[0]) * 128 / hs)) for t in (got[k], want[k]))
+            if ra in kl and rb in kl and abs(ra - rb) == 128 and abs(kl[ra] - kl[rb]) <= 1e-5 * abs(kl[rb]):
+                ties[k] = (ra, rb, kl[ra], kl[rb]); del bad[k]
+    assert not bad and len(ties) <= 2, (name, len(bad), list(bad.items())[:3], ties)
+
+
+def _hist_observers(observers):
+    """variable name -> this package's KL histogram observer (the ones that reached phase 2)."""
+    from ppq_amd.observer import TorchHistObserver
+    return {getattr(ob._watch_on, 'name', None): ob for ob in observers
+            if isinstance(ob, TorchHistObserver) and ob._hist_scale is not None and ob.histogram() is not None}
 
 
 @pytest.fixture(autouse=True)
@@ -96,9 +122,15 @@ def test_observers_and_pass_plugged_into_the_reference(topology, batch, size, me
         # A. the reference's pass, this package's observers from the reference's table
         replay.reset_activation_configs(); built.clear()
         ppq_amd.install_plugins_into_ppq()
+        made = []
+        made_build = ref_observer.TensorObserverFactroy.build_observer.__func__
+
+        def keeping_build(cls, variable, config):
+            ob = made_build(cls, variable, config); made.append(ob); return ob
+        ref_observer.TensorObserverFactroy.build_observer = classmethod(keeping_build)
         RefPass(method=method).optimize(graph=rg, dataloader=batches, executor=replay, calib_steps=8, collate_fn=None)
         assert built and all(t.__module__ == our_observer.__name__ for t in built), set(built)
-        _assert_equal('A: reference pass + HIP observers', _scales(rg), want)
+        _assert_equal('A: reference pass + HIP observers', _scales(rg), want, _hist_observers(made) if method == 'kl' else None)
     finally:
         ref_observer.TensorObserverFactroy.build_observer = classmethod(ref_build)
 
@@ -107,7 +139,8 @@ def test_observers_and_pass_plugged_into_the_reference(topology, batch, size, me
     ours = OurPass(method=method)
     PFL.Pipeline([ours]).optimize(graph=rg, dataloader=batches, executor=replay, calib_steps=8, collate_fn=None, verbose=False)
     assert ours._queue is not None and ours._queue.launches > 0            # the multi-tensor launches carried it
-    _assert_equal('B: HIP pass in the reference pipeline', _scales(rg), want)
+    _assert_equal('B: HIP pass in the reference pipeline', _scales(rg), want,
+                  _hist_observers(ours._all_tensor_observers()) if method == 'kl' else None)
     assert replay.recorded_forwards == 8                                   # nothing ran the network again
 
     # C. this package's pass on its own harness graph, shown the reference executor's activations
@@ -115,8 +148,10 @@ def test_observers_and_pass_plugged_into_the_reference(topology, batch, size, me
     harness.quantize_graph(hg, method, symmetrical=symmetric, hist_bins=2048)
     hex_ = harness.TorchExecutor(hg, DEV)
     harness.ParameterQuantizePass().optimize(hg)
-    OurPass(method=method).optimize(hg, dataloader=batches, executor=replay.for_graph(hg), calib_steps=8)
-    _assert_equal('C: HIP pass on the harness graph', _scales(hg), want)
+    ours_c = OurPass(method=method)
+    ours_c.optimize(hg, dataloader=batches, executor=replay.for_graph(hg), calib_steps=8)
+    _assert_equal('C: HIP pass on the harness graph', _scales(hg), want,
+                  _hist_observers(ours_c._all_tensor_observers()) if method == 'kl' else None)
     assert replay.recorded_forwards == 8
 
 
