@@ -36,12 +36,14 @@ def _scales(graph):
 
 def _assert_equal(name, got, want, hist_observers=None):
     """Scales to 1e-6 relative, offsets exactly.  ONE documented exception, KL only (``hist_observers``: variable name -> this
-    package's histogram observer): the reference searches on the CPU in float32 torch sums whose order depends on the host's
-    SIMD width, the kernel sums in its own fixed order; once a histogram holds more than 2^24 counts those float32 sums are
-    inexact and the two KL values of a candidate agree to ~1e-7 only -- so when two NEIGHBOURING candidates are tied to that
-    precision the arg-min may fall on either (seen on about one lease in eight, one config of ResNet-50's 72).  Such a config
-    passes only if the reference's own arithmetic (oracle.kl_search, pinned to the reference) rates the two candidates within
-    1e-5 relative of each other; at most two per graph."""
+    package's histogram observer): the reference normalises the candidate distributions with float32 ``torch.sum`` on the CPU,
+    whose summation order depends on the host's SIMD width; the kernel sums in its own fixed order.  A normaliser that differs by
+    one float32 rounding (eps ~ 6e-8) shifts a KL value by 0.43 eps ABSOLUTE, and KL values are small (1e-3 .. 1e-2), so the two
+    implementations agree to 1e-16 on some histograms and to ~6e-5 RELATIVE on others (tools/kl_accuracy.py: worst 6.4e-5 over 40
+    histograms, arg-min equal on all 40) -- and when two NEIGHBOURING candidates are closer than that, the arg-min may fall on
+    either (seen on two fresh leases in about twenty, one config of ResNet-50's 72; any other host CPU would do the same to the
+    reference itself).  Such a config passes only if the reference's own arithmetic (oracle.kl_search, pinned to the reference)
+    rates the two candidates within 2e-4 relative of each other; at most two per graph."""
     assert set(got) == set(want), (name, sorted(set(got) ^ set(want)))
     bad = {k: (got[k], want[k]) for k in want
            if not (torch.allclose(got[k][0], want[k][0], rtol=1e-6, atol=0) and torch.equal(got[k][1], want[k][1]))}
@@ -55,7 +57,7 @@ def _assert_equal(name, got, want, hist_observers=None):
             _, _, losses, _ = O.kl_search(ob.histogram().cpu().numpy(), hs, return_losses=True)
             kl = {d['bin_range']: d['kl'] for d in losses}
             ra, rb = (int(round(float(t[0]) * 128 / hs)) for t in (got[k], want[k]))
-            if ra in kl and rb in kl and abs(ra - rb) == 128 and abs(kl[ra] - kl[rb]) <= 1e-5 * abs(kl[rb]):
+            if ra in kl and rb in kl and abs(ra - rb) == 128 and abs(kl[ra] - kl[rb]) <= 2e-4 * abs(kl[rb]):
                 ties[k] = (ra, rb, kl[ra], kl[rb]); del bad[k]
     if ties: print(f'[kl near-tie admitted] {name}: {ties}')
     assert not bad and len(ties) <= 2, (name, len(bad), list(bad.items())[:3], ties)
