@@ -405,8 +405,9 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
             for cfg in delegators: executor.remove_quantize_delegate(cfg)
             self.disable_block_gradient(block)
             return 0.0, 0.0
-        # parameters whose config carries no delegator (FP32 bias: this harness has no PassiveParameterQuantizePass,
-        # where the reference would hold a PASSIVE config + delegator backup) are trained too -- keep their own backup
+        # parameters whose config carries no delegator (an FP32 bias when the quantizer leaves biases unquantised -- with
+        # quantize_graph(passive_bias=True) + PassiveParameterQuantizePass the bias config is PASSIVE and its delegator holds
+        # the backup, as in the reference) are trained too -- keep their own backup
         covered = {id(d.var.value) for d in delegators.values() if d.is_parameter}
         loose = [(t, t.detach().clone()) for t in uniq if id(t) not in covered
                  and not any(t is c.scale or t is c.offset for c in delegators)]

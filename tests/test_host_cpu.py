@@ -908,3 +908,45 @@ def test_vectorised_channel_render_equals_the_scalar_loop():
         assert np.array_equal(ws, gs), (sym, qmin, np.nonzero(ws != gs)[0][:5])
         assert np.array_equal(ws.astype(np.float32), gs.astype(np.float32))
         assert [int(w[1]) for w in want] == [int(v) for v in got_o], (sym, qmin)
+
+
+def test_prefix_cache_keeps_the_frontier_only_and_the_values_of_a_full_forward(monkeypatch):
+    """blocks.PrefixCache on the CPU (a stand-in fake-quant function: the cache logic is host code): block after block of the
+    YOLOv6-s-like graph, the inputs it hands out equal a full forward's bit for bit after each block's weights were changed,
+    every operation runs ONCE per batch overall, and after each ``invalidate`` the cache holds a cut of the graph -- not the
+    whole prefix (what ``prune`` is for)."""
+    from ppq_amd import blocks, harness
+    g = harness.yolov6s_graph(seed=0)
+    harness.quantize_graph(g, 'minmax')
+    ex = harness.TorchExecutor(g, 'cpu')
+    ex._default_quant_fn = lambda t, c: torch.round(t * 64.0) / 64.0          # deterministic, state-free
+    runs = {}
+    real = harness._forward
+
+    def counted(op, x):
+        runs[op.name] = runs.get(op.name, 0) + 1
+        return real(op, x)
+    gen = torch.Generator().manual_seed(0)
+    batches = [torch.rand(1, 3, 64, 64, generator=gen) for _ in range(2)]
+    blks = blocks.split_graph_into_blocks(g, g.topological_sort(), 5)
+    assert len(blks) > 10
+    prefix = blocks.PrefixCache(g, ex, batches)
+    n_act = sum(1 for v in g.variables.values() if not v.is_parameter)
+    held = []
+    for k, b in enumerate(blks):
+        monkeypatch.setattr(harness, '_forward', counted)
+        got = prefix.inputs_of(b)
+        monkeypatch.setattr(harness, '_forward', real)
+        names = list(got[0])
+        for i, batch in enumerate(batches):
+            want = [batch if n in g.inputs else ex.forward(batch, [n])[0] for n in names]
+            for n, w in zip(names, want): assert torch.equal(got[i][n], w), (k, n)
+        with torch.no_grad():                                                  # "train" the block
+            for op in b.rps:
+                for v in op.inputs:
+                    if v.is_parameter and v.value.is_floating_point(): v.value.mul_(1.01)
+        prefix.invalidate(b)
+        held.append(max(len(c) for c in prefix.values))
+    assert max(runs.values()) == len(batches), 'an operation of the prefix ran more than once per batch'
+    assert max(held) <= 12 < n_act // 4, (max(held), n_act)            # skip connections into the neck stay alive, the rest goes
+    assert prefix.resident_bytes() > 0
