@@ -137,7 +137,8 @@ def set_activated(config) -> None:
 
 class TensorQuantizationConfig:
     """The fields of ppq.core.TensorQuantizationConfig (ppq/core/quant.py:367-896) that the hot
-    path reads or writes.  PPQ's dominance union-find is reduced to "every config dominates itself"."""
+    path reads or writes, including the dominance union-find (``dominated_by`` / ``master_by``, quant.py:596-713): scale
+    and offset of an OVERLAPPED or PASSIVE config resolve through its root, as the reference's properties do."""
     _counter = 0
 
     def __init__(self, policy: QuantizationPolicy, rounding: RoundingPolicy = RoundingPolicy.ROUND_HALF_EVEN,
