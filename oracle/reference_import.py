@@ -104,12 +104,13 @@ def to_reference_graph(hgraph):
 
 
 def quantize_reference_graph(g, device: str, sample: torch.Tensor, bins: int = 2048, method: Optional[str] = 'kl',
-                             mutate=None, platform: str = 'TRT_INT8'):
+                             mutate=None, platform: str = 'TRT_INT8', parameter_pass=None):
     """The reference's own front half of quantize_native_model (api/interface.py:453-543) with the
     TensorRT INT8 quantizer: dispatch, per-op TQCs, QuantizeSimplifyPass, QuantizeFusionPass,
     ParameterQuantizePass.  Activation configs get `method` and the BASELINE's 2048-bin override
     (range.py:152-153); `method=None` keeps the quantizer's own algorithm (TRT_FP8: 'floating').  `platform`: a
-    TargetPlatform name.  Returns (graph, executor) ready for RuntimeCalibrationPass."""
+    TargetPlatform name; `parameter_pass`: a pass instance to run in place of the reference's ParameterQuantizePass.
+    Returns (graph, executor) ready for RuntimeCalibrationPass."""
     import ppq.lib as PFL
     from ppq import TargetPlatform, TorchExecutor
     from ppq.api import dispatch_graph
@@ -131,7 +132,7 @@ def quantize_reference_graph(g, device: str, sample: torch.Tensor, bins: int = 2
             if mutate is not None: mutate(cfg, v)
     ex = TorchExecutor(g, device=device)
     PFL.Pipeline([QuantizeSimplifyPass(), QuantizeFusionPass(activation_type=quantizer.activation_fusion_types),
-                  ParameterQuantizePass()]).optimize(graph=g, dataloader=[sample], executor=ex, calib_steps=8,
+                  ParameterQuantizePass() if parameter_pass is None else parameter_pass]).optimize(graph=g, dataloader=[sample], executor=ex, calib_steps=8,
                                                      collate_fn=None, verbose=False)
     return g, ex
 

@@ -11,8 +11,7 @@ observers touch, with the reference's names and call protocol --
   (quantize inputs -> pre_forward_hook -> op -> quantize outputs -> post_forward_hook)
 * a TensorRT-style INT8 policy (``quantize_graph``)                        quantizer/TensorRTQuantizer.py
   + the state edits of QuantizeFusionPass / QuantizeSimplifyPass           optim/refine.py
-* ``ParameterQuantizePass`` / ``ParameterBakingPass``                      optim/parameters.py:156-215,
-                                                                           optim/baking.py:11-47
+* ``ParameterQuantizePass`` / ``ParameterBakingPass``                      now ppq_amd/parameters.py (re-exported here)
 * ``resnet50_graph`` -- the ResNet-50 topology (53 Conv + 1 Gemm, BN pre-folded) with seeded
   He-initialised weights, standing in for the ONNX model that cannot be loaded here (no `onnx`).
 
@@ -26,7 +25,6 @@ import torch.nn.functional as F
 
 from .core import LinearQuantizationConfig, QuantizationStates, TensorQuantizationConfig, is_initial
 from .core import QuantizationProperty as P
-from .observer import TensorObserverFactroy
 from .qfunction import PPQuantFunction
 
 PASSIVE_OPERATIONS = {'MaxPool', 'GlobalMaxPool', 'Reshape', 'Flatten', 'Identity', 'Dropout', 'Slice', 'Pad', 'Resize',
@@ -471,33 +469,7 @@ def quantize_graph(graph: BaseGraph, activation_algorithm: str = 'kl', per_chann
             else: op.config.output_quantization_config[0].state = QuantizationStates.OVERLAPPED
 
 
-class ParameterQuantizePass:
-    """optim/parameters.py:156-215: observe + render every INITIAL parameter config."""
-    def optimize(self, graph: BaseGraph, **kwargs) -> None:
-        from .observer import ObservationQueue, render_observers
-        observers, queue = [], ObservationQueue()
-        for op in graph.operations.values():
-            if not isinstance(op, QuantableOperation): continue
-            for config, var in op.config_with_variable:
-                if var.is_parameter and is_initial(config):
-                    ob = TensorObserverFactroy.build_observer(var, config)
-                    ob.queue = queue                   # the statistics of ALL parameters: one launch per kind (per-channel
-                    ob.observe(var.value)              # ranges -> ppqhip_minmax_c_multi), flushed by the first render
-                    observers.append(ob)
-        queue.flush()
-        self.launches = queue.launches
-        render_observers(observers)
-        for ob in observers: ob.queue = None
-
-
-class ParameterBakingPass:
-    """optim/baking.py:11-47: fake-quantise every activated parameter once and mark it BAKED."""
-    def __init__(self, quantize_function: Callable = PPQuantFunction):
-        self._quantize_function = quantize_function
-
-    def optimize(self, graph: BaseGraph, **kwargs) -> None:
-        for op in graph.operations.values():
-            if isinstance(op, QuantableOperation): op.baking_parameters(self._quantize_function)
+from .parameters import ParameterBakingPass, ParameterQuantizePass  # noqa: E402,F401  (kept under their old names here)
 
 
 # ------------------------------------------------------------------------------------ topologies

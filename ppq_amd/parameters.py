@@ -1,16 +1,27 @@
-"""Parameter-side passes next to the calibration pass (immediate neighbours of RuntimeCalibrationPass).
+"""Parameter-side passes next to the calibration pass (immediate neighbours of RuntimeCalibrationPass; 8f-3).
+
+``ParameterQuantizePass`` mirrors ppq/quantization/optim/parameters.py:156-215: every INITIAL parameter config is observed and
+rendered.  The reference reaches the weights with a dummy forward through per-operation hooks (one observer call, i.e. two
+reductions, per weight); here the observers of ALL parameters ride one ``ObservationQueue`` -- per-channel ranges are ONE
+``ppqhip_minmax_c_multi`` launch for the whole graph -- and one batched render.  Same scales (tests/test_gpu_reference.py).
+
+``ParameterBakingPass`` mirrors ppq/quantization/optim/baking.py:11-47 (+ ``QuantableOperation.baking_parameters``,
+IR/quantize.py:98-111): every ACTIVATED / PASSIVE parameter is replaced by its fake-quantised value and its config becomes
+BAKED / PASSIVE_BAKED.  The LINEAR ones are fake-quantised by ONE ``ppqhip_fq_linear_multi`` launch per rounding policy.
 
 ``PassiveParameterQuantizePass`` mirrors ppq/quantization/optim/parameters.py:13-153: parameters that may not own a scale --
 the bias of Conv / ConvTranspose / Gemm (scale = input scale x weight scale, offset 0), the bounds of Clip and the pad value of
 Pad (mastered by the operation's input config).  Pure host logic: it only wires configs; the tensors keep living on the device
-and the products are device tensor ops.  Works on this package's harness graph and, duck-typed, on the reference's own
-``BaseGraph`` (``ppq.lib.Pipeline`` accepts it after ``install_plugins_into_ppq()``).
+and the products are device tensor ops.
+
+All three work on this package's harness graph and, duck-typed, on the reference's own ``BaseGraph`` (``ppq.lib.Pipeline``
+accepts them after ``install_plugins_into_ppq()``).
 """
 import torch
 
 from .calibration import QuantizationOptimizationPass
 from .core import QuantizationProperty as P
-from .core import QuantizationStates, QuantizationVisibility, state_value
+from .core import QuantizationStates, QuantizationVisibility, is_initial, rounding_value, state_value
 
 _S = QuantizationStates
 _QUANTIZED_INPUT = {_S.PASSIVE.value, _S.ACTIVATED.value, _S.BAKED.value, _S.OVERLAPPED.value}
@@ -21,6 +32,98 @@ def _state_of(cfg, wanted):
     """The member named like ``wanted`` of the enum class ``cfg.state`` comes from (ours, or the reference's)."""
     cls = type(cfg.state)
     return getattr(cls, wanted.name) if hasattr(cls, wanted.name) else wanted
+
+
+class ParameterQuantizePass(QuantizationOptimizationPass):
+    """optim/parameters.py:156-215.  ``method`` overrides the observer algorithm of every parameter config (:186-188);
+    ``dataloader`` / ``executor`` are accepted for the reference's call protocol and not needed: the parameters are read
+    where they lie (the reference's dummy forward exists only to reach them through its hooks)."""
+    def __init__(self, method: str = None):
+        super().__init__(name='PPQ Parameter Quantization Pass')
+        self._method = method
+        self.launches = 0                      # statistics launches of the last optimize() (all per-channel weights: ONE)
+
+    def optimize(self, graph, dataloader=None, executor=None, **kwargs) -> None:
+        from .observer import ObservationQueue, TensorObserverFactroy, render_observers
+        observers, queue = [], ObservationQueue()
+        for op in graph.operations.values():
+            if not hasattr(op, 'config'): continue
+            for config, var in op.config_with_variable:
+                if not var.is_parameter: continue
+                if self._method is not None: config.observer_algorithm = self._method
+                if not is_initial(config): continue
+                ob = TensorObserverFactroy.build_observer(var, config)
+                ob.queue = queue                       # the statistics of ALL parameters: one launch per kind (per-channel
+                ob.observe(var.value)                  # ranges -> ppqhip_minmax_c_multi), flushed by the first render
+                observers.append(ob)
+        queue.flush()
+        self.launches = queue.launches
+        render_observers(observers)
+        for ob in observers: ob.queue = None
+
+
+class ParameterBakingPass(QuantizationOptimizationPass):
+    """optim/baking.py:11-47 + IR/quantize.py:98-111.  ``fused``: the LINEAR, non-dynamic configs whose tensors the
+    multi-tensor plan can point at are fake-quantised together (``ffi.LinearQuantizePlan``, one launch per rounding policy;
+    values identical to the per-tensor function, tests/test_gpu_calibration.py); everything else -- FP8, dynamic, a delegated
+    or oddly laid out tensor -- goes through ``quantize_function`` one by one, as in the reference."""
+    def __init__(self, quantize_function=None, fused: bool = True) -> None:
+        super().__init__(name='PPQ Parameter Baking Pass')
+        if quantize_function is None:
+            from .qfunction import PPQuantFunction
+            quantize_function = PPQuantFunction
+        self._quantize_function = quantize_function
+        self._fused = fused
+        self.launches = 0                      # multi-tensor launches of the last optimize()
+        self.per_tensor = 0                    # parameters that went through quantize_function instead
+
+    @ staticmethod
+    def _baked_state(config):
+        cls = type(config.state)
+        name = 'BAKED' if state_value(config.state) == _S.ACTIVATED.value else 'PASSIVE_BAKED'
+        return getattr(cls, name) if hasattr(cls, name) else getattr(_S, name)
+
+    def optimize(self, graph, **kwargs) -> None:
+        from .ffi import LinearQuantizePlan
+        from .qfunction import PPQuantFunction
+        todo = []
+        for op in graph.operations.values():
+            if not hasattr(op, 'config'): continue
+            for config, var in op.config_with_variable:
+                if var.is_parameter and state_value(config.state) in (_S.ACTIVATED.value, _S.PASSIVE.value):
+                    assert len(var.dest_ops) == 1, (
+                        f', Parameter {var.name} has {len(var.dest_ops)} destinations, Baking parameter that has more than 1 '
+                        'destinations will incur unexpected problems, PPQ does not support parameters with more than 1 related '
+                        'operation, reform your graph first.')
+                    todo.append((config, var))
+        groups, single = {}, []
+        for config, var in todo:
+            pol, v = config.policy, var.value
+            axis = config.channel_axis if pol.has_property(P.PER_CHANNEL) else None
+            fusable = (self._fused and self._quantize_function is PPQuantFunction and isinstance(v, torch.Tensor) and v.is_cuda
+                       and v.dtype == torch.float32 and v.numel() > 0 and not v.requires_grad
+                       and pol.has_property(P.LINEAR) and not pol.has_property(P.DYNAMIC)
+                       and isinstance(config.scale, torch.Tensor) and isinstance(config.offset, torch.Tensor)
+                       and config.scale.dtype == torch.float32 and config.offset.dtype == torch.float32
+                       and config.scale.device == v.device and config.offset.device == v.device
+                       and LinearQuantizePlan.accepts(v, config.scale, config.offset, axis))
+            if fusable: groups.setdefault((rounding_value(config.rounding), v.device), []).append((config, var, axis))
+            else: single.append((config, var))
+        self.launches, self.per_tensor = 0, len(single)
+        for (rnd, _), items in groups.items():
+            if len(items) == 1:
+                single.append(items[0][:2]); self.per_tensor += 1
+                continue
+            plan = LinearQuantizePlan([(var.value, c.scale, c.offset, axis, c.quant_min, c.quant_max) for c, var, axis in items],
+                                      rounding=rnd)
+            outs = plan.run()
+            self.launches += 1
+            for (c, var, _), out in zip(items, outs):
+                var.value = out                     # a view of the plan's arena: the baked parameters of a graph share ONE allocation
+                c.state = self._baked_state(c)
+        for c, var in single:
+            var.value = self._quantize_function(var.value, c)
+            c.state = self._baked_state(c)
 
 
 class PassiveParameterQuantizePass(QuantizationOptimizationPass):

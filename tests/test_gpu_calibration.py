@@ -304,7 +304,16 @@ def test_runtime_calibration_pass_small_graph(method):
     assert torch.allclose(codes * cfg.scale, y, atol=0, rtol=1e-6) and codes.max() <= 127
     # baking the parameters first is a pure optimisation: identical outputs
     out_before = ex.forward(batches[0])[0].clone()
-    harness.ParameterBakingPass().optimize(graph)
+    from ppq_amd.qfunction import PPQuantFunction
+    weights = [(c, v) for op in graph.operations.values() if hasattr(op, 'config') for c, v in op.config_with_variable
+               if v.is_parameter and c.state.value in (4, 5)]                      # ACTIVATED / PASSIVE
+    expected = {v.name: PPQuantFunction(v.value, c) for c, v in weights}
+    baking = harness.ParameterBakingPass()
+    baking.optimize(graph)
+    assert len(weights) >= 3 and baking.launches == 1 and baking.per_tensor == 0      # all weights: ONE multi-tensor launch
+    for c, v in weights:
+        assert c.state.value in (2, 7), c.state                                   # BAKED / PASSIVE_BAKED
+        assert torch.equal(v.value, expected[v.name]) and v.value.is_contiguous()
     assert torch.equal(ex.forward(batches[0])[0], out_before)
 
 

@@ -102,6 +102,50 @@ def test_reference_executor_and_calibration_pass_on_hip(topology, batch, size, m
     assert all(abs(ours[k] - ref_scales[k]) <= 0.15 * ref_scales[k] for k in ours)
 
 
+def test_parameter_passes_are_drop_ins_inside_the_reference_pipeline():
+    """ppq_amd.parameters.ParameterQuantizePass / ParameterBakingPass in place of the reference's own passes
+    (optim/parameters.py:156-215, optim/baking.py:11-47), inside the reference's ppq.lib.Pipeline on its own BaseGraph +
+    TorchExecutor: every parameter config ends in the same state with bit-identical scale and offset, the statistics of all
+    weights were ONE multi-tensor launch; after baking, every parameter holds the same bits, the configs are BAKED alike,
+    and the reference executor computes the same outputs."""
+    import ppq_amd
+    from ppq_amd import harness
+    from ppq_amd.parameters import ParameterBakingPass, ParameterQuantizePass
+    RI.load()
+    ppq_amd.install_plugins_into_ppq(observers=False)            # kernels + the pass ABC registration; PPQ keeps its own observers
+    from ppq.quantization.optim import ParameterBakingPass as RefBaking
+    sample = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(3)).to(DEV)
+    ra, exa = RI.quantize_reference_graph(RI.to_reference_graph(harness.small_cnn_graph(seed=0)), DEV, sample, method='minmax')
+    ours = ParameterQuantizePass()
+    rb, exb = RI.quantize_reference_graph(RI.to_reference_graph(harness.small_cnn_graph(seed=0)), DEV, sample, method='minmax',
+                                          parameter_pass=ours)
+    assert ours.launches == 1, ours.launches                                       # all per-channel weights: one launch
+
+    def parameter_configs(g):
+        return [(op.name, v.name, c, v) for op in g.operations.values() if hasattr(op, 'config')
+                for c, v in op.config_with_variable if v.is_parameter]
+    pa, pb = parameter_configs(ra), parameter_configs(rb)
+    assert len(pa) == len(pb) >= 6
+    calibrated = 0
+    for (oa, na, ca, _), (ob, nb, cb, _) in zip(pa, pb):
+        assert (oa, na) == (ob, nb) and ca.state == cb.state, (oa, na, ca.state, cb.state)
+        if ca.scale is not None:
+            assert torch.equal(ca.scale, cb.scale) and torch.equal(ca.offset, cb.offset), (oa, na)
+            calibrated += 1
+    assert calibrated >= 3
+    RI.calibrate(ra, exa, [sample] * 8, method='minmax')
+    RI.calibrate(rb, exb, [sample] * 8, method='minmax')
+    RefBaking().optimize(ra)
+    baking = ParameterBakingPass()
+    baking.optimize(rb)
+    assert baking.launches == 1, (baking.launches, baking.per_tensor)
+    for (oa, na, ca, va), (_, _, cb, vb) in zip(parameter_configs(ra), parameter_configs(rb)):
+        assert ca.state == cb.state, (oa, na, ca.state, cb.state)
+        assert torch.equal(va.value, vb.value), (oa, na)
+    ya, yb = exa.forward(sample), exb.forward(sample)
+    for a, b in zip(ya, yb): assert torch.equal(a, b)
+
+
 def test_reference_lsq_pass_on_hip_vs_this_package():
     """the reference's OWN LearnedStepSizePass (block split, collect, LSQDelegator -> CuLSQ_LT / CuLSQ_LC ->
     CUDA.LinearQuantize_T_B / _C_B = the HIP backward kernels) on the GPU, against ppq_amd.lsq on the same topology,
