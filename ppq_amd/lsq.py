@@ -221,11 +221,16 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
     trainable tensors of a block travel in ONE flat all-reduce per step (a few MB at most -- latency bound on
     xGMI, so never one collective per tensor); block losses are averaged so every rank takes the same keep /
     withdraw decision.  ``report`` = [(block, pre_loss, post_loss)]."""
-    def __init__(self, steps: int = 500, lr: float = 5e-5, gamma: float = 0.0, optimizer=None, process_group=None,
-                 block_size: int = 5, interested_layers: List[str] = None, is_scale_trainable: bool = True,
-                 group_weights: bool = True, use_hip_graph: bool = True):
-        super().__init__(name='PPQ LSQ Optimization')
+    def __init__(self, name: str = 'PPQ LSQ Optimization', interested_layers: List[str] = None, steps: int = 500,
+                 gamma: float = 0.0, is_scale_trainable: bool = True, lr: float = 5e-5, block_size: int = 5,
+                 expire_device: str = 'cpu', collecting_device: str = 'cuda', loss_fn=None, optimizer=None, *,
+                 process_group=None, group_weights: bool = True, use_hip_graph: bool = True):
+        """The positional parameters are the reference's, in its order (training.py:700-713).  ``expire_device`` /
+        ``collecting_device`` are accepted and unused: nothing is parked on the host, the block caches stay on the executor's
+        device (288 GB of HBM).  ``loss_fn(y_pred, y_real)``: default = the reference's ``torch_mean_square_error``."""
+        super().__init__(name=name)
         self.steps, self.lr, self.gamma, self.optimizer = steps, lr, gamma, optimizer
+        if loss_fn is not None: self._loss = loss_fn
         self.process_group = process_group
         self.block_size = block_size
         self.interested_layers = interested_layers or []

@@ -950,3 +950,29 @@ def test_prefix_cache_keeps_the_frontier_only_and_the_values_of_a_full_forward(m
     assert max(runs.values()) == len(batches), 'an operation of the prefix ran more than once per batch'
     assert max(held) <= 12 < n_act // 4, (max(held), n_act)            # skip connections into the neck stay alive, the rest goes
     assert prefix.resident_bytes() > 0
+
+
+def test_pass_constructors_take_the_reference_parameters_in_its_order():
+    """Every mirrored optimisation pass can be constructed with the reference's own positional / keyword arguments: its
+    parameter names are a prefix of this package's, in the same order with the same simple defaults (what this package adds
+    comes after them or is keyword-only), and ``optimize`` accepts the keywords ppq.lib.Pipeline passes."""
+    import inspect
+    from oracle import reference_import as RI
+    if RI.find_reference() is None: pytest.skip('reference not present on this machine')
+    RI.load()
+    import ppq.quantization.optim as RO
+    from ppq_amd import bias_correction, calibration, lsq, parameters
+    mirrors = [('RuntimeCalibrationPass', calibration), ('IsotoneCalibrationPass', calibration), ('PPLDSPTIReCalibrationPass', calibration),
+               ('LearnedStepSizePass', lsq), ('BiasCorrectionPass', bias_correction), ('PassiveParameterQuantizePass', parameters),
+               ('ParameterQuantizePass', parameters), ('ParameterBakingPass', parameters)]
+    for name, module in mirrors:
+        ref = [p for p in inspect.signature(getattr(RO, name).__init__).parameters.values() if p.name != 'self']
+        ours = [p for p in inspect.signature(getattr(module, name).__init__).parameters.values() if p.name != 'self']
+        assert [p.name for p in ours[:len(ref)]] == [p.name for p in ref], (name, [p.name for p in ours], [p.name for p in ref])
+        for r, o in zip(ref, ours):
+            assert o.kind == inspect.Parameter.POSITIONAL_OR_KEYWORD, (name, o.name)
+            if isinstance(r.default, (int, float, str, bool)) or r.default is None:
+                assert o.default == r.default, (name, r.name, r.default, o.default)
+        opt = inspect.signature(getattr(module, name).optimize).parameters
+        assert any(p.kind == inspect.Parameter.VAR_KEYWORD for p in opt.values()), name      # Pipeline: optimize(graph=..., **kwargs)
+        assert list(opt)[1] == 'graph', name
