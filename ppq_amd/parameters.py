@@ -63,10 +63,11 @@ class ParameterQuantizePass(QuantizationOptimizationPass):
 
 
 class ParameterBakingPass(QuantizationOptimizationPass):
-    """optim/baking.py:11-47 + IR/quantize.py:98-111.  ``fused``: the LINEAR, non-dynamic configs whose tensors the
-    multi-tensor plan can point at are fake-quantised together (``ffi.LinearQuantizePlan``, one launch per rounding policy;
-    values identical to the per-tensor function, tests/test_gpu_calibration.py); everything else -- FP8, dynamic, a delegated
-    or oddly laid out tensor -- goes through ``quantize_function`` one by one, as in the reference."""
+    """optim/baking.py:11-47 + IR/quantize.py:98-111.  ``fused``: the non-dynamic LINEAR (and FP8) configs whose tensors the
+    multi-tensor plans can point at are fake-quantised together (``ffi.LinearQuantizePlan`` / ``FloatingQuantizePlan``, one
+    launch per rounding policy; values identical to the per-tensor function, tests/test_gpu_calibration.py); everything else --
+    dynamic, a custom ``quantize_function``, an oddly laid out tensor -- goes through ``quantize_function`` one by one, as in
+    the reference."""
     def __init__(self, quantize_function=None, fused: bool = True) -> None:
         super().__init__(name='PPQ Parameter Baking Pass')
         if quantize_function is None:
@@ -84,7 +85,7 @@ class ParameterBakingPass(QuantizationOptimizationPass):
         return getattr(cls, name) if hasattr(cls, name) else getattr(_S, name)
 
     def optimize(self, graph, **kwargs) -> None:
-        from .ffi import LinearQuantizePlan
+        from .ffi import FloatingQuantizePlan, LinearQuantizePlan
         from .qfunction import PPQuantFunction
         todo = []
         for op in graph.operations.values():
@@ -100,22 +101,27 @@ class ParameterBakingPass(QuantizationOptimizationPass):
         for config, var in todo:
             pol, v = config.policy, var.value
             axis = config.channel_axis if pol.has_property(P.PER_CHANNEL) else None
+            floating = pol.has_property(P.FLOATING)
             fusable = (self._fused and self._quantize_function is PPQuantFunction and isinstance(v, torch.Tensor) and v.is_cuda
                        and v.dtype == torch.float32 and v.numel() > 0 and not v.requires_grad
-                       and pol.has_property(P.LINEAR) and not pol.has_property(P.DYNAMIC)
+                       and (pol.has_property(P.LINEAR) or floating) and not pol.has_property(P.DYNAMIC)
                        and isinstance(config.scale, torch.Tensor) and isinstance(config.offset, torch.Tensor)
                        and config.scale.dtype == torch.float32 and config.offset.dtype == torch.float32
                        and config.scale.device == v.device and config.offset.device == v.device
                        and LinearQuantizePlan.accepts(v, config.scale, config.offset, axis))
-            if fusable: groups.setdefault((rounding_value(config.rounding), v.device), []).append((config, var, axis))
+            if fusable: groups.setdefault((rounding_value(config.rounding), v.device, floating), []).append((config, var, axis))
             else: single.append((config, var))
         self.launches, self.per_tensor = 0, len(single)
-        for (rnd, _), items in groups.items():
+        for (rnd, _, floating), items in groups.items():
             if len(items) == 1:
                 single.append(items[0][:2]); self.per_tensor += 1
                 continue
-            plan = LinearQuantizePlan([(var.value, c.scale, c.offset, axis, c.quant_min, c.quant_max) for c, var, axis in items],
-                                      rounding=rnd)
+            if floating:                            # TRT_FP8 policy: the per-channel FP8 weights, ppqhip_fq_float_multi
+                plan = FloatingQuantizePlan([(var.value, c.scale, c.offset, axis, c.exponent_bits, c.mantissa_bits, c.quant_min,
+                                              c.quant_max) for c, var, axis in items], rounding=rnd)
+            else:
+                plan = LinearQuantizePlan([(var.value, c.scale, c.offset, axis, c.quant_min, c.quant_max) for c, var, axis in items],
+                                          rounding=rnd)
             outs = plan.run()
             self.launches += 1
             for (c, var, _), out in zip(items, outs):

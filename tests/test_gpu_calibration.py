@@ -489,6 +489,15 @@ def test_fp8_calibration_transformer_block():
     cfg = seen['cfg']
     want = O.fq_float_t(seen['raw'].cpu().numpy(), cfg.scale.cpu().numpy().reshape(1), cfg.offset.cpu().numpy().reshape(1))
     assert np.array_equal(seen['q'].cpu().numpy().view(np.uint32), want.view(np.uint32))
+    # baking the two FP8 weights: ONE ppqhip_fq_float_multi launch, the bits of the per-tensor function, same network output
+    out_before = ex.forward(batches[0])[0].clone()
+    weights = [(c, v) for op in graph.operations.values() for c, v in op.config_with_variable if v.is_parameter and c.state.value == 4]
+    expected = {v.name: ex.quantize_function(v.value, c).clone() for c, v in weights}
+    baking = harness.ParameterBakingPass()
+    baking.optimize(graph)
+    assert (baking.launches, baking.per_tensor) == (1, 0)
+    for c, v in weights: assert c.state.value == 2 and torch.equal(v.value, expected[v.name])
+    assert torch.equal(ex.forward(batches[0])[0], out_before)
 
 
 @pytest.mark.parametrize('shape,axis', [((8, 64, 28, 28), 1), ((4, 512, 7, 7), 1), ((3, 5, 17), 1), ((32, 1000), 1),
