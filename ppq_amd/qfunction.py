@@ -19,6 +19,12 @@ from .core import QuantizationStates, rounding_value, state_value
 from .ffi import CUDA
 
 
+class BaseQuantFunction:
+    """qfunction/base.py:6-12: the callable protocol ``fn(tensor, config) -> tensor`` executors and delegators follow."""
+    def __call__(self, input_tensor, quantization_config, **kwargs):
+        raise NotImplementedError('Implement this first.')
+
+
 def _activated(config) -> bool:
     return state_value(config.state) in (QuantizationStates.ACTIVATED.value, QuantizationStates.PASSIVE.value)
 
@@ -100,32 +106,59 @@ def PPQLinearQuantFunction(tensor: torch.Tensor, config) -> torch.Tensor:
                                                config.quant_min, config.quant_max, config.rounding)
 
 
-def PPQDyamicLinearQuantFunction(tensor: torch.Tensor, config) -> torch.Tensor:
-    """qfunction/linear.py:99-198: min/max of THIS tensor -> scale/offset -> fake quant.  The range
-    reduction runs in the minmax kernels; the scale/offset arithmetic is minmax_to_scale_offset."""
-    from .observer import minmax_to_scale_offset
-    if not _activated(config): return tensor
-    if not config.policy.has_property(P.LINEAR):
-        raise ValueError('Critical Quantization Error! Non-linear config detected.')
-    if not config.policy.has_property(P.DYNAMIC):
-        raise ValueError('Quantization Policy Do Not Have Dynamic Flag!')
-    dev = tensor.device
-    if config.policy.has_property(P.PER_CHANNEL):
+class TensorwiseDynamicLinearQuantImpl(Function):
+    """qfunction/linear.py:99-127: min / max of THIS tensor -> scale / offset -> fake quant (straight-through backward).
+    The range reduction is the min/max kernel; the scale / offset arithmetic is ``minmax_to_scale_offset`` on Python floats,
+    as in the reference (``tensor.min().item()``)."""
+    @ staticmethod
+    def forward(ctx, tensor: torch.Tensor, config) -> torch.Tensor:
+        from .observer import minmax_to_scale_offset
+        dev = tensor.device
+        mm = torch.tensor([float('inf'), float('-inf')], device=dev)
+        CUDA.MinMax_T(tensor, mm)
+        mn, mx = mm.tolist()
+        s, o = minmax_to_scale_offset(mn, mx, config)
+        return CUDA.LinearQuantize_T(tensor=tensor, scales=torch.tensor([s], dtype=torch.float32, device=dev),
+                                     offsets=torch.tensor([o], dtype=torch.float32, device=dev), minimum=config.quant_min,
+                                     maximum=config.quant_max, rounding=rounding_value(config.rounding))
+
+    @ staticmethod
+    def backward(ctx, dy: torch.Tensor):
+        return dy, None
+
+
+class ChannelwiseDynamicLinearQuantImpl(Function):
+    """qfunction/linear.py:130-172: the same per channel (``MinMax_C`` + the reference's loop over the channels' Python-float
+    ranges -- double arithmetic, NOT the float32 array arithmetic of the observers' per-channel render)."""
+    @ staticmethod
+    def forward(ctx, tensor: torch.Tensor, config) -> torch.Tensor:
+        from .observer import minmax_to_scale_offset
+        dev = tensor.device
         C = tensor.shape[config.channel_axis]
         mins = torch.full([C], float('inf'), device=dev); maxs = torch.full([C], float('-inf'), device=dev)
         CUDA.MinMax_C(tensor, config.channel_axis, mins, maxs)
         so = [minmax_to_scale_offset(a, b, config) for a, b in zip(mins.tolist(), maxs.tolist())]
         scales = torch.tensor([v[0] for v in so], dtype=torch.float32, device=dev)
         offsets = torch.tensor([v[1] for v in so], dtype=torch.float32, device=dev)
-        return ChannelwiseLinearQuantImpl.apply(tensor, scales, offsets, config.channel_axis, config.quant_min,
-                                                config.quant_max, config.rounding)
-    mm = torch.tensor([float('inf'), float('-inf')], device=dev)
-    CUDA.MinMax_T(tensor, mm)
-    mn, mx = mm.tolist()
-    s, o = minmax_to_scale_offset(mn, mx, config)
-    return TensorwiseLinearQuantImpl.apply(tensor, torch.tensor([s], dtype=torch.float32, device=dev),
-                                           torch.tensor([o], dtype=torch.float32, device=dev), config.quant_min,
-                                           config.quant_max, config.rounding)
+        return CUDA.LinearQuantize_C(tensor=tensor, scales=scales, offsets=offsets, channel_axis=config.channel_axis,
+                                     minimum=config.quant_min, maximum=config.quant_max, rounding=rounding_value(config.rounding))
+
+    @ staticmethod
+    def backward(ctx, dy: torch.Tensor):
+        return dy, None
+
+
+def PPQDyamicLinearQuantFunction(tensor: torch.Tensor, config) -> torch.Tensor:
+    """qfunction/linear.py:174-198."""
+    if not _activated(config): return tensor
+    if not config.policy.has_property(P.LINEAR):
+        raise ValueError('Critical Quantization Error! Non-linear config detected.')
+    if not config.policy.has_property(P.DYNAMIC):
+        raise ValueError('Quantization Policy Do Not Have Dynamic Flag!')
+    if config.policy.has_property(P.PER_CHANNEL):
+        return ChannelwiseDynamicLinearQuantImpl.apply(tensor, config)
+    elif config.policy.has_property(P.PER_TENSOR):
+        return TensorwiseDynamicLinearQuantImpl.apply(tensor, config)
 
 
 def PPQFloatingQuantFunction(tensor: torch.Tensor, config) -> torch.Tensor:
