@@ -87,6 +87,10 @@ class QuantizationPolicy:
     def has_property(self, property: QuantizationProperty) -> bool:
         return (self._policy & property.value) != 0
 
+    def to_dict(self) -> dict:
+        """quant.py:298-306: property name -> present."""
+        return {prop.name: self.has_property(prop) for prop in QuantizationProperty}
+
     def __eq__(self, o: object) -> bool:
         return isinstance(o, QuantizationPolicy) and self._policy == o._policy
 
@@ -104,10 +108,18 @@ class QuantizationStates(Enum):
     PASSIVE = 5
     PASSIVE_BAKED = 7
     FP32 = 8
+    SOI = -1                  # legacy names the reference keeps (quant.py:352-354); nothing on this path sets them
+    DEQUANTIZED = -2
+    DEACTIVED = -3
 
     @ classmethod
     def is_activated(cls, state) -> bool:
         return state_value(state) in (cls.ACTIVATED.value, cls.PASSIVE.value)
+
+    @ classmethod
+    def can_export(cls, state) -> bool:
+        """quant.py:361-364."""
+        return state_value(state) not in (cls.INITIAL.value, cls.PASSIVE_INIT.value, cls.DEQUANTIZED.value, cls.DEACTIVED.value)
 
 
 class QuantizationVisibility(Enum):
@@ -144,7 +156,8 @@ class TensorQuantizationConfig:
     def __init__(self, policy: QuantizationPolicy, rounding: RoundingPolicy = RoundingPolicy.ROUND_HALF_EVEN,
                  num_of_bits: int = 8, quant_min: int = -127, quant_max: int = 128, exponent_bits: int = 0,
                  scale: Any = None, offset: Any = None, observer_algorithm: str = None, detail: Any = None,
-                 channel_axis: int = None, state: QuantizationStates = QuantizationStates.INITIAL):
+                 channel_axis: int = None, state: QuantizationStates = QuantizationStates.INITIAL,
+                 visibility: 'QuantizationVisibility' = QuantizationVisibility.EXPORT_WHEN_ACTIVE):
         assert 2 <= num_of_bits <= 32, 'Cannot quantize a tensor with less than 2 or more than 32 bits.'
         assert 0 <= exponent_bits <= 8, 'Exponent bits must be in [0, 8].'
         self.policy = policy
@@ -160,7 +173,7 @@ class TensorQuantizationConfig:
         self.observer_algorithm = observer_algorithm
         self.detail = {} if detail is None else detail
         self._dominator = self                               # union-find root pointer (quant.py:596)
-        self.visibility = QuantizationVisibility.EXPORT_WHEN_ACTIVE
+        self.visibility = visibility
         TensorQuantizationConfig._counter += 1
         self._hash = TensorQuantizationConfig._counter
 
@@ -220,6 +233,41 @@ class TensorQuantizationConfig:
 
     @ offset.setter
     def offset(self, value: Any): self._offset = value
+
+    def can_export(self, export_overlapped: bool = False) -> bool:
+        """quant.py:601-613: does an exporter write this config?  (``EXPORT_OVERLAPPED_CONFIG`` is False, common.py:115.)"""
+        if self.visibility == QuantizationVisibility.INTERNAL: return False
+        live = state_value(self.state) in (QuantizationStates.ACTIVATED.value, QuantizationStates.PASSIVE.value,
+                                           QuantizationStates.BAKED.value, QuantizationStates.PASSIVE_BAKED.value)
+        if export_overlapped and state_value(self.state) == QuantizationStates.OVERLAPPED.value: live = True
+        if not (live or self.visibility == QuantizationVisibility.FORCE_EXPORT): return False
+        return isinstance(self.scale, torch.Tensor) and isinstance(self.offset, torch.Tensor)
+
+    def is_same_scheme(self, o: object) -> bool:
+        """quant.py:634-644: same grid (range, policy, bit widths, channel axis, rounding), whatever the scales are."""
+        if not isinstance(o, TensorQuantizationConfig):
+            raise TypeError('Can only compare TensorQuantizationConfig object with another TensorQuantizationConfig object.')
+        mine = (self.quant_max, self.quant_min, self.policy, self.num_of_bits, self.exponent_bits, self.channel_axis)
+        theirs = (o.quant_max, o.quant_min, o.policy, o.num_of_bits, o.exponent_bits, o.channel_axis)
+        return mine == theirs and rounding_value(self.rounding) == rounding_value(o.rounding)
+
+    def is_revisable(self) -> bool:
+        """quant.py:714-723: its own root, and in a state a pass may still rewrite."""
+        S = QuantizationStates
+        return self.dominated_by is self and state_value(self.state) in (
+            S.ACTIVATED.value, S.FP32.value, S.INITIAL.value, S.PASSIVE.value, S.PASSIVE_INIT.value)
+
+    def copy(self) -> 'TensorQuantizationConfig':
+        """quant.py:865-896: a new config (new identity) with the same fields; tensors cloned, ``detail`` copied one level
+        deep, an OVERLAPPED copy keeps pointing at the original's dominator."""
+        def dup(t): return t.clone() if isinstance(t, torch.Tensor) else t
+        twin = TensorQuantizationConfig(policy=self.policy, rounding=self.rounding, num_of_bits=self.num_of_bits,
+                                        quant_min=self.quant_min, quant_max=self.quant_max, exponent_bits=self.exponent_bits,
+                                        scale=dup(self.scale), offset=dup(self.offset), observer_algorithm=self.observer_algorithm,
+                                        detail=dict(self.detail), channel_axis=self.channel_axis, state=self.state,
+                                        visibility=self.visibility)
+        if state_value(self.state) == QuantizationStates.OVERLAPPED.value: twin._dominator = self._dominator
+        return twin
 
     def __hash__(self) -> int: return self._hash
     def __eq__(self, o: object) -> bool: return isinstance(o, TensorQuantizationConfig) and o._hash == self._hash

@@ -976,3 +976,51 @@ def test_pass_constructors_take_the_reference_parameters_in_its_order():
         opt = inspect.signature(getattr(module, name).optimize).parameters
         assert any(p.kind == inspect.Parameter.VAR_KEYWORD for p in opt.values()), name      # Pipeline: optimize(graph=..., **kwargs)
         assert list(opt)[1] == 'graph', name
+
+
+def test_config_helper_methods_answer_like_the_reference():
+    """TensorQuantizationConfig.can_export / is_same_scheme / is_revisable / copy, QuantizationPolicy.to_dict and
+    QuantizationStates.can_export (ppq/core/quant.py:298-306, 361-364, 601-644, 714-723, 865-896) against the reference's own
+    classes over every (state, visibility, scale set / unset) combination."""
+    from oracle import reference_import as RI
+    if RI.find_reference() is None: pytest.skip('reference not present on this machine')
+    RI.load()
+    import ppq.core as rc
+    from ppq_amd import core as oc
+
+    def make(m, state, vis, with_scale, axis=None, bits=8):
+        P = m.QuantizationProperty
+        pol = m.QuantizationPolicy(P.LINEAR.value + P.SYMMETRICAL.value + (P.PER_CHANNEL.value if axis is not None else P.PER_TENSOR.value))
+        c = m.TensorQuantizationConfig(policy=pol, rounding=m.RoundingPolicy.ROUND_HALF_EVEN, num_of_bits=bits, quant_min=-128,
+                                       quant_max=127, scale=torch.ones(2) if with_scale else None,
+                                       offset=torch.zeros(2) if with_scale else None, observer_algorithm='minmax',
+                                       channel_axis=axis, state=getattr(m.QuantizationStates, state),
+                                       visibility=getattr(m.QuantizationVisibility, vis))
+        return c
+    states = ['INITIAL', 'ACTIVATED', 'BAKED', 'OVERLAPPED', 'PASSIVE_INIT', 'PASSIVE', 'PASSIVE_BAKED', 'FP32', 'SOI', 'DEQUANTIZED', 'DEACTIVED']
+    assert {m.name: m.value for m in rc.QuantizationStates} == {m.name: m.value for m in oc.QuantizationStates}
+    for state in states:
+        assert rc.QuantizationStates.can_export(getattr(rc.QuantizationStates, state)) == \
+            oc.QuantizationStates.can_export(getattr(oc.QuantizationStates, state)), state
+        for vis in ('FORCE_EXPORT', 'EXPORT_WHEN_ACTIVE', 'INTERNAL'):
+            for with_scale in (False, True):
+                r, o = make(rc, state, vis, with_scale), make(oc, state, vis, with_scale)
+                for overlapped in (False, True):
+                    assert r.can_export(overlapped) == o.can_export(overlapped), (state, vis, with_scale, overlapped)
+                assert r.is_revisable() == o.is_revisable(), state
+                rt, ot = r.copy(), o.copy()
+                assert (rt == r) == (ot == o) and not (ot == o)                      # a copy is a NEW config
+                assert ot.state == o.state and ot.visibility == o.visibility and ot.detail == o.detail and ot.detail is not o.detail
+                if with_scale:                # cloned -- except an OVERLAPPED copy, which reads its dominator (the original), in both
+                    assert torch.equal(ot.scale, o.scale) and (ot.scale is o.scale) == (rt.scale is r.scale) == (state == 'OVERLAPPED')
+    a = make(oc, 'ACTIVATED', 'EXPORT_WHEN_ACTIVE', True)
+    ra = make(rc, 'ACTIVATED', 'EXPORT_WHEN_ACTIVE', True)
+    for kw in ({}, {'axis': 1}, {'bits': 4}):
+        assert a.is_same_scheme(make(oc, 'INITIAL', 'INTERNAL', False, **kw)) == ra.is_same_scheme(make(rc, 'INITIAL', 'INTERNAL', False, **kw)), kw
+    with pytest.raises(TypeError): a.is_same_scheme(3)
+    assert a.policy.to_dict() == ra.policy.to_dict()
+    # an OVERLAPPED copy keeps reading its dominator's scale, like the reference's
+    b = make(oc, 'ACTIVATED', 'EXPORT_WHEN_ACTIVE', True)
+    o = make(oc, 'ACTIVATED', 'EXPORT_WHEN_ACTIVE', False)
+    o.dominated_by = b
+    assert o.copy().scale is b.scale and not o.is_revisable() and b.is_revisable()
