@@ -6,8 +6,9 @@ operator surface.  Importing this package loads ``libppq_hip.so`` and fails loud
 from . import _lib  # noqa: F401  (raises ImportError when the HIP library has not been built)
 from .core import (PPQ_CONFIG, FloatingQuantizationConfig, LinearQuantizationConfig, QuantizationPolicy,
                    QuantizationProperty, QuantizationStates, RoundingPolicy, TensorQuantizationConfig)
-from .ffi import CUDA, CUDA_COMPLIER, HIP_EXTENSION, install_into_ppq, install_plugins_into_ppq, uninstall_from_ppq
+from .ffi import (CUDA, CUDA_COMPLIER, ENABLE_CUDA_KERNEL, HIP_EXTENSION, install_into_ppq, install_plugins_into_ppq,
+                  uninstall_from_ppq)
 
-__all__ = ['CUDA', 'CUDA_COMPLIER', 'HIP_EXTENSION', 'install_into_ppq', 'install_plugins_into_ppq', 'uninstall_from_ppq', 'PPQ_CONFIG', 'RoundingPolicy',
+__all__ = ['CUDA', 'CUDA_COMPLIER', 'ENABLE_CUDA_KERNEL', 'HIP_EXTENSION', 'install_into_ppq', 'install_plugins_into_ppq', 'uninstall_from_ppq', 'PPQ_CONFIG', 'RoundingPolicy',
            'QuantizationProperty', 'QuantizationPolicy', 'QuantizationStates', 'TensorQuantizationConfig',
            'LinearQuantizationConfig', 'FloatingQuantizationConfig']

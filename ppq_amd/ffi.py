@@ -908,13 +908,38 @@ class ComplieHelper:
 CUDA_COMPLIER = ComplieHelper()
 
 
+class ENABLE_CUDA_KERNEL:
+    """ppq/api/interface.py:915-935 for code written against this package alone: inside the block
+    ``PPQ_CONFIG.USING_CUDA_KERNEL`` is True (it always is here -- there is no torch arithmetic branch to fall back to), the
+    previous value comes back on exit."""
+    def __init__(self) -> None:
+        CUDA_COMPLIER.complie()
+        self._state = False
+
+    def __enter__(self):
+        from .core import PPQ_CONFIG
+        self._state = PPQ_CONFIG.USING_CUDA_KERNEL
+        PPQ_CONFIG.USING_CUDA_KERNEL = True
+
+    def __exit__(self, *args):
+        from .core import PPQ_CONFIG
+        PPQ_CONFIG.USING_CUDA_KERNEL = self._state
+
+
 def install_into_ppq() -> None:
-    """Route an importable, unmodified PPQ through these kernels: the two lines a PPQ user adds.
-    (`CUDA_COMPLIER.complie()` must NOT be called -- it would JIT-build ppq/csrc with nvcc.)"""
+    """Route an importable, unmodified PPQ through these kernels: the two lines a PPQ user adds.  ``CUDA_COMPLIER.complie()``
+    -- which would JIT-build ppq/csrc with nvcc -- is shadowed on the singleton, so ``with ENABLE_CUDA_KERNEL():`` keeps
+    working in scripts written for the reference."""
     from ppq.core import PPQ_CONFIG as REF_CONFIG
     from ppq.core.ffi import CUDA_COMPLIER as REF_COMPLIER
     REF_COMPLIER.__CUDA_EXTENTION__ = HIP_EXTENSION
     REF_CONFIG.USING_CUDA_KERNEL = True
+    # existing scripts wrap their calls in ``with ENABLE_CUDA_KERNEL():`` (api/interface.py:915-935), whose constructor calls
+    # CUDA_COMPLIER.complie(): shadow the method ON THE SINGLETON INSTANCE so that it re-selects this library instead of
+    # JIT-building ppq/csrc (no reference file is touched; uninstall_from_ppq removes the shadow)
+    def complie() -> None:
+        REF_COMPLIER.__CUDA_EXTENTION__ = HIP_EXTENSION
+    REF_COMPLIER.complie = complie
     # the reference's percentile observer calls the stateless CUDA.Quantile(value, q) once per batch (observer/range.py:349):
     # declare the observer the owner of those calls, so that batch k + 1 filters with the thresholds that worked for batch k
     from ppq.quantization.observer.range import TorchPercentileObserver as RefPercentile
@@ -942,6 +967,7 @@ def uninstall_from_ppq() -> None:
     from ppq.core.ffi import CUDA_COMPLIER as REF_COMPLIER
     REF_COMPLIER.__CUDA_EXTENTION__ = None
     REF_CONFIG.USING_CUDA_KERNEL = False
+    REF_COMPLIER.__dict__.pop('complie', None)           # the class's own complie() is visible again
     if 'percentile_observe' in _SAVED_KERNEL_STATE:
         from ppq.quantization.observer.range import TorchPercentileObserver as RefPercentile
         RefPercentile.observe = _SAVED_KERNEL_STATE.pop('percentile_observe')

@@ -185,10 +185,22 @@ assert calls[3][0] == 'Histogram_T' and calls[3][1][1:3] == (0.5, False) and cal
 assert calls[4][0] == 'Histogram_Asymmetric_T' and calls[4][1][:2] == (-1.0, 1.0) and calls[4][1][3] is True
 assert calls[5][0] == 'QuantizeTensor_FC' and calls[5][1][3:] == (5, 2, -57344.0, 57344.0, 1, 0)
 assert calls[6] == ('Quantile_T', (t, 0.99))
+# the idiom of scripts written for the reference: ENABLE_CUDA_KERNEL() calls CUDA_COMPLIER.complie() (api/interface.py:925-928),
+# which would JIT-build ppq/csrc -- after install it re-selects this library instead, and uninstall gives the method back
+from ppq.api.interface import ENABLE_CUDA_KERNEL
+from ppq.core.ffi import CUDA_COMPLIER, ComplieHelper
+PPQ_CONFIG.USING_CUDA_KERNEL = False
+with ENABLE_CUDA_KERNEL():
+    assert PPQ_CONFIG.USING_CUDA_KERNEL is True and CUDA_COMPLIER.CUDA_EXTENSION is ext
+    CUDA.LinearQuantize_T(t, s, o, -8, 7, 0)
+assert PPQ_CONFIG.USING_CUDA_KERNEL is False and len(calls) == 8
+ppq_amd.uninstall_from_ppq()
+assert 'complie' not in vars(CUDA_COMPLIER) and CUDA_COMPLIER.complie.__func__ is ComplieHelper.complie
+with ppq_amd.ENABLE_CUDA_KERNEL(): assert ppq_amd.PPQ_CONFIG.USING_CUDA_KERNEL is True
 print('ROUTED', len(calls))
 ''' % ROOT
     out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
-    assert 'ROUTED 7' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    assert 'ROUTED 8' in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
 def test_harness_graph_and_pass_plumbing():
