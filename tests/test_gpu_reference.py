@@ -102,6 +102,68 @@ def test_reference_executor_and_calibration_pass_on_hip(topology, batch, size, m
     assert all(abs(ours[k] - ref_scales[k]) <= 0.15 * ref_scales[k] for k in ours)
 
 
+def test_user_script_quantize_native_model_under_enable_cuda_kernel():
+    """A script written for the reference, unchanged apart from the import + install lines: ``with ENABLE_CUDA_KERNEL():
+    quantize_native_model(...)`` (api/interface.py:453-543, 915-935) -- dispatch, the TensorRT quantizer and its WHOLE default
+    pipeline (simplify, fusion, parameter quantisation, runtime calibration, passive parameters, alignment, baking) -- on the
+    GPU with these kernels, against the same call on the reference's own torch-CPU path (no kernels): the same config states
+    everywhere, the baked weights bit-identical (weights only meet the fake-quant kernels), every activation scale equal to
+    1e-5 (min-max of convolution outputs computed by two different BLAS / MIOpen back ends)."""
+    import ppq_amd
+    from ppq_amd import harness
+    RI.load()
+    from ppq import QuantizationSettingFactory, TargetPlatform
+    from ppq.api import ENABLE_CUDA_KERNEL, quantize_native_model
+    from ppq.core import PPQ_CONFIG
+
+    def run(device):
+        g = RI.to_reference_graph(harness.small_cnn_graph(seed=0))
+        setting = QuantizationSettingFactory.default_setting()
+        setting.quantize_activation_setting.calib_algorithm = 'minmax'
+        gen = torch.Generator().manual_seed(0)
+        data = [torch.rand(2, 3, 32, 32, generator=gen) for _ in range(8)]
+        return quantize_native_model(model=g, calib_dataloader=data, calib_steps=8, input_shape=[2, 3, 32, 32],
+                                     platform=TargetPlatform.TRT_INT8, setting=setting, collate_fn=lambda b: b.to(device),
+                                     device=device, verbose=0)
+    ppq_amd.uninstall_from_ppq()
+    assert PPQ_CONFIG.USING_CUDA_KERNEL is False
+    cpu = run('cpu')
+    ppq_amd.install_into_ppq()
+    calls = {}
+    ext = ppq_amd.HIP_EXTENSION
+    for name in ('QuantizeTensor_LC', 'QuantizeTensor_LT'):
+        def make(fn, name=name):
+            def w(*a, **k):
+                calls[name] = calls.get(name, 0) + 1
+                return fn(*a, **k)
+            return w
+        setattr(ext, name, make(getattr(type(ext), name)))
+    try:
+        PPQ_CONFIG.USING_CUDA_KERNEL = False
+        with ENABLE_CUDA_KERNEL():                               # its constructor calls CUDA_COMPLIER.complie()
+            gpu = run(DEV)
+        assert PPQ_CONFIG.USING_CUDA_KERNEL is False
+    finally:
+        for name in ('QuantizeTensor_LC', 'QuantizeTensor_LT'): delattr(ext, name)
+        ppq_amd.install_into_ppq()
+    assert calls.get('QuantizeTensor_LC', 0) >= 3, calls          # the weights, every calibration forward + the baking pass
+    compared = baked = 0
+    for (na, oa), (nb, ob) in zip(cpu.operations.items(), gpu.operations.items()):
+        assert na == nb
+        if not hasattr(oa, 'config'): continue
+        for (ca, va), (cb, vb) in zip(oa.config_with_variable, ob.config_with_variable):
+            assert ca.state == cb.state, (na, va.name, ca.state, cb.state)
+            if ca.scale is None: continue
+            a, b = ca.scale.detach().cpu().double().reshape(-1), cb.scale.detach().cpu().double().reshape(-1)
+            assert a.shape == b.shape and bool(((a - b).abs() <= 1e-5 * a.abs()).all()), (na, va.name)
+            assert torch.equal(ca.offset.detach().cpu().reshape(-1), cb.offset.detach().cpu().reshape(-1)), (na, va.name)
+            compared += 1
+            if va.is_parameter and ca.state.name == 'BAKED':
+                assert torch.equal(va.value.detach().cpu(), vb.value.detach().cpu()), (na, va.name)
+                baked += 1
+    assert compared >= 15 and baked == 3, (compared, baked)
+
+
 def test_parameter_passes_are_drop_ins_inside_the_reference_pipeline():
     """ppq_amd.parameters.ParameterQuantizePass / ParameterBakingPass in place of the reference's own passes
     (optim/parameters.py:156-215, optim/baking.py:11-47), inside the reference's ppq.lib.Pipeline on its own BaseGraph +
