@@ -102,29 +102,35 @@ def test_reference_executor_and_calibration_pass_on_hip(topology, batch, size, m
     assert all(abs(ours[k] - ref_scales[k]) <= 0.15 * ref_scales[k] for k in ours)
 
 
-def test_user_script_quantize_native_model_under_enable_cuda_kernel():
+@pytest.mark.parametrize('platform', ['TRT_INT8', 'PPL_CUDA_INT8', 'PPL_DSP_INT8', 'FPGA_INT8', 'PPL_DSP_TI_INT8', 'METAX_INT8_C'])
+def test_user_script_quantize_native_model_under_enable_cuda_kernel(platform):
     """A script written for the reference, unchanged apart from the import + install lines: ``with ENABLE_CUDA_KERNEL():
-    quantize_native_model(...)`` (api/interface.py:453-543, 915-935) -- dispatch, the TensorRT quantizer and its WHOLE default
-    pipeline (simplify, fusion, parameter quantisation, runtime calibration, passive parameters, alignment, baking) -- on the
-    GPU with these kernels, against the same call on the reference's own torch-CPU path (no kernels): the same config states
-    everywhere, the baked weights bit-identical (weights only meet the fake-quant kernels), every activation scale equal to
-    1e-5 (min-max of convolution outputs computed by two different BLAS / MIOpen back ends)."""
+    quantize_native_model(...)`` (api/interface.py:453-543, 915-935) -- dispatch, the platform's quantizer and its WHOLE default
+    pipeline (simplify, fusion, parameter quantisation, runtime calibration, TI re-calibration, passive parameters, alignment,
+    baking) -- on the GPU with these kernels, against the same call on the reference's own torch-CPU path (no kernels).
+    Platforms: per-channel symmetric (TRT), + passive INT32 bias (PPL_CUDA), per-tensor ASYMMETRIC (PPL_DSP), POWER-OF-2
+    (FPGA), the TI re-calibration pass (PPL_DSP_TI), METAX.  The same config states everywhere; the baked WEIGHTS bit-identical
+    (they only meet the fake-quant kernels); every activation scale equal to 1e-5 (min-max of convolution outputs computed by
+    two different BLAS / MIOpen back ends), offsets equal (asymmetric: within one step); a baked passive bias within one step
+    of its grid (its scale is input scale x weight scale)."""
     import ppq_amd
     from ppq_amd import harness
     RI.load()
     from ppq import QuantizationSettingFactory, TargetPlatform
     from ppq.api import ENABLE_CUDA_KERNEL, quantize_native_model
-    from ppq.core import PPQ_CONFIG
+    from ppq.core import PPQ_CONFIG, QuantizationProperty
 
     def run(device):
         g = RI.to_reference_graph(harness.small_cnn_graph(seed=0))
         setting = QuantizationSettingFactory.default_setting()
+        # (the default 'percentile' is the one algorithm whose CPU and CUDA paths index differently IN THE REFERENCE,
+        #  int(n q) vs rn(n q), observer/range.py:341 vs sort.cu:13)
         setting.quantize_activation_setting.calib_algorithm = 'minmax'
         gen = torch.Generator().manual_seed(0)
         data = [torch.rand(2, 3, 32, 32, generator=gen) for _ in range(8)]
         return quantize_native_model(model=g, calib_dataloader=data, calib_steps=8, input_shape=[2, 3, 32, 32],
-                                     platform=TargetPlatform.TRT_INT8, setting=setting, collate_fn=lambda b: b.to(device),
-                                     device=device, verbose=0)
+                                     platform=getattr(TargetPlatform, platform), setting=setting,
+                                     collate_fn=lambda b: b.to(device), device=device, verbose=0)
     ppq_amd.uninstall_from_ppq()
     assert PPQ_CONFIG.USING_CUDA_KERNEL is False
     cpu = run('cpu')
@@ -146,7 +152,7 @@ def test_user_script_quantize_native_model_under_enable_cuda_kernel():
     finally:
         for name in ('QuantizeTensor_LC', 'QuantizeTensor_LT'): delattr(ext, name)
         ppq_amd.install_into_ppq()
-    assert calls.get('QuantizeTensor_LC', 0) >= 3, calls          # the weights, every calibration forward + the baking pass
+    assert sum(calls.values()) >= 3, calls                       # the weights: every calibration forward + the baking pass
     compared = baked = 0
     for (na, oa), (nb, ob) in zip(cpu.operations.items(), gpu.operations.items()):
         assert na == nb
@@ -155,13 +161,18 @@ def test_user_script_quantize_native_model_under_enable_cuda_kernel():
             assert ca.state == cb.state, (na, va.name, ca.state, cb.state)
             if ca.scale is None: continue
             a, b = ca.scale.detach().cpu().double().reshape(-1), cb.scale.detach().cpu().double().reshape(-1)
-            assert a.shape == b.shape and bool(((a - b).abs() <= 1e-5 * a.abs()).all()), (na, va.name)
-            assert torch.equal(ca.offset.detach().cpu().reshape(-1), cb.offset.detach().cpu().reshape(-1)), (na, va.name)
+            assert a.shape == b.shape and bool(((a - b).abs() <= 1e-5 * a.abs()).all()), (na, va.name, a, b)
+            oa_, ob_ = ca.offset.detach().cpu().double().reshape(-1), cb.offset.detach().cpu().double().reshape(-1)
+            slack = 1.0 if ca.policy.has_property(QuantizationProperty.ASYMMETRICAL) else 0.0
+            assert bool(((oa_ - ob_).abs() <= slack).all()), (na, va.name, oa_, ob_)
             compared += 1
             if va.is_parameter and ca.state.name == 'BAKED':
                 assert torch.equal(va.value.detach().cpu(), vb.value.detach().cpu()), (na, va.name)
                 baked += 1
-    assert compared >= 15 and baked == 3, (compared, baked)
+            if va.is_parameter and ca.state.name == 'PASSIVE_BAKED':
+                step = float(a.max()) * 1.01
+                assert float((va.value.detach().cpu() - vb.value.detach().cpu()).abs().max()) <= step, (na, va.name)
+    assert compared >= 12 and baked >= 2, (compared, baked)
 
 
 def test_parameter_passes_are_drop_ins_inside_the_reference_pipeline():
