@@ -149,10 +149,23 @@ def test_user_script_quantize_native_model_under_enable_cuda_kernel(platform):
         with ENABLE_CUDA_KERNEL():                               # its constructor calls CUDA_COMPLIER.complie()
             gpu = run(DEV)
         assert PPQ_CONFIG.USING_CUDA_KERNEL is False
+        # ... and the simulation the user runs next (error analysis, evaluation): the quantised network on one batch
+        from ppq import TorchExecutor
+        x = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(5))
+        before = dict(calls)
+        with ENABLE_CUDA_KERNEL(): y_gpu = TorchExecutor(gpu, device=DEV).forward(x.to(DEV))[0].cpu()
+        simulated = sum(calls.values()) - sum(before.values())
     finally:
         for name in ('QuantizeTensor_LC', 'QuantizeTensor_LT'): delattr(ext, name)
-        ppq_amd.install_into_ppq()
-    assert sum(calls.values()) >= 3, calls                       # the weights: every calibration forward + the baking pass
+        ppq_amd.uninstall_from_ppq()
+    y_cpu = TorchExecutor(cpu, device='cpu').forward(x)[0]
+    ppq_amd.install_into_ppq()
+    assert sum(calls.values()) >= 3 and simulated >= 3, (calls, simulated)   # weights while calibrating / baking; activations simulating
+    fc = cpu.operations['fc']                                    # (FPGA_INT8 leaves the Gemm in FP32)
+    out_cfg = fc.config.output_quantization_config[0] if hasattr(fc, 'config') else None
+    grid = float(out_cfg.scale.max()) if out_cfg is not None and out_cfg.state.name == 'ACTIVATED' else 0.02 * float(y_cpu.abs().max())
+    # an activation that sits on a rounding tie may land one step apart in the two back ends and travel on: a few output steps
+    assert float((y_cpu - y_gpu).abs().max()) <= 4 * grid, (float((y_cpu - y_gpu).abs().max()), grid)
     compared = baked = 0
     for (na, oa), (nb, ob) in zip(cpu.operations.items(), gpu.operations.items()):
         assert na == nb
