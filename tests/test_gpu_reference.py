@@ -188,6 +188,75 @@ def test_user_script_quantize_native_model_under_enable_cuda_kernel(platform):
     assert compared >= 12 and baked >= 2, (compared, baked)
 
 
+def test_user_script_with_lsq_and_bias_correction_settings():
+    """The same user script with ``setting.lsq_optimization`` and ``setting.bias_correct`` switched on (quantizer/base.py:
+    305-325 puts the reference's LearnedStepSizePass and BiasCorrectionPass into the pipeline): on the GPU the reference's own
+    LSQDelegator reaches ``CUDA.LinearQuantize_T_B / _C_B`` -- these backward kernels -- inside the whole flow.  Against the
+    same script on the reference's torch-CPU path: the same config states, scales of the same shape, finite and positive; the
+    simulated outputs of the two finetuned networks stay within 10 % of the output range of each other (two independently
+    trained networks: equality is not expected) and both track the FP32 network."""
+    import ppq_amd
+    from ppq_amd import harness
+    RI.load()
+    from ppq import QuantizationSettingFactory, TargetPlatform, TorchExecutor
+    from ppq.api import ENABLE_CUDA_KERNEL, quantize_native_model
+    from ppq.core import PPQ_CONFIG
+
+    def run(device):
+        torch.manual_seed(0)
+        g = RI.to_reference_graph(harness.small_cnn_graph(seed=0))
+        setting = QuantizationSettingFactory.default_setting()
+        setting.quantize_activation_setting.calib_algorithm = 'minmax'
+        setting.lsq_optimization = True
+        setting.lsq_optimization_setting.steps = 16
+        setting.lsq_optimization_setting.lr = 1e-4
+        setting.lsq_optimization_setting.collecting_device = device
+        setting.bias_correct = True
+        setting.bias_correct_setting.steps = 8
+        setting.bias_correct_setting.collecting_device = device
+        gen = torch.Generator().manual_seed(0)
+        data = [torch.rand(2, 3, 32, 32, generator=gen) for _ in range(8)]
+        return quantize_native_model(model=g, calib_dataloader=data, calib_steps=8, input_shape=[2, 3, 32, 32],
+                                     platform=TargetPlatform.TRT_INT8, setting=setting, collate_fn=lambda b: b.to(device),
+                                     device=device, verbose=0)
+    ppq_amd.uninstall_from_ppq()
+    cpu = run('cpu')
+    x = torch.rand(2, 3, 32, 32, generator=torch.Generator().manual_seed(5))
+    y_cpu = TorchExecutor(cpu, device='cpu').forward(x)[0]
+    ppq_amd.install_into_ppq()
+    calls = {}
+    ext = ppq_amd.HIP_EXTENSION
+    for name in ('QuantizeTensor_LC_B', 'QuantizeTensor_LT_B'):
+        def make(fn, name=name):
+            def w(*a, **k):
+                calls[name] = calls.get(name, 0) + 1
+                return fn(*a, **k)
+            return w
+        setattr(ext, name, make(getattr(type(ext), name)))
+    try:
+        PPQ_CONFIG.USING_CUDA_KERNEL = False
+        with ENABLE_CUDA_KERNEL():
+            gpu = run(DEV)
+            y_gpu = TorchExecutor(gpu, device=DEV).forward(x.to(DEV))[0].cpu()
+    finally:
+        for name in ('QuantizeTensor_LC_B', 'QuantizeTensor_LT_B'): delattr(ext, name)
+        ppq_amd.install_into_ppq()
+    assert calls.get('QuantizeTensor_LC_B', 0) >= 16 and calls.get('QuantizeTensor_LT_B', 0) >= 16, calls
+    for (na, oa), (nb, ob) in zip(cpu.operations.items(), gpu.operations.items()):
+        assert na == nb
+        if not hasattr(oa, 'config'): continue
+        for (ca, va), (cb, vb) in zip(oa.config_with_variable, ob.config_with_variable):
+            assert ca.state == cb.state, (na, va.name, ca.state, cb.state)
+            if ca.scale is None: continue
+            assert ca.scale.shape == cb.scale.shape and bool(torch.isfinite(cb.scale).all()) and bool((cb.scale > 0).all()), (na, va.name)
+            assert not cb.scale.requires_grad and (not va.is_parameter or not vb.value.requires_grad)
+    fp = harness.small_cnn_graph(seed=0)
+    y_fp = harness.TorchExecutor(fp, 'cpu').forward(x)[0]
+    span = float(y_fp.abs().max())
+    assert float((y_cpu - y_gpu).abs().max()) <= 0.10 * span, (float((y_cpu - y_gpu).abs().max()), span)
+    assert float((y_gpu - y_fp).abs().max()) <= 0.25 * span and float((y_cpu - y_fp).abs().max()) <= 0.25 * span
+
+
 def test_parameter_passes_are_drop_ins_inside_the_reference_pipeline():
     """ppq_amd.parameters.ParameterQuantizePass / ParameterBakingPass in place of the reference's own passes
     (optim/parameters.py:156-215, optim/baking.py:11-47), inside the reference's ppq.lib.Pipeline on its own BaseGraph +
