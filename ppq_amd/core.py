@@ -191,12 +191,16 @@ class TensorQuantizationConfig:
 
     @ dominated_by.setter
     def dominated_by(self, o) -> None:
-        """quant.py:677-691: the trees of self and o are joined under o's root; this config becomes OVERLAPPED."""
+        """quant.py:677-691: the trees of self and o are joined under o's root; this config becomes OVERLAPPED.  Refused like
+        the reference refuses: a non-config trips its ``assert`` (AssertionError), self-domination and a config whose root is
+        this very config (the son would dominate its father) raise ValueError."""
         if not isinstance(o, TensorQuantizationConfig):
-            raise TypeError('Error with TQC.dominated_by = o: o must be another Tensor Quantization Config, '
-                            f'however {type(o)} was given.')
+            raise AssertionError('Can only set this attribute with another tensor config.')
         if o._hash == self._hash: raise ValueError('Error with TQC.dominated_by = o: o must not equal to TQC its self.')
         root, dominator = self.dominated_by, o.dominated_by
+        if dominator is self:
+            raise ValueError('Can not Assign Dominator like this, Circular reference was detected. '
+                             'Son TQC can not dominate its Father.')
         if root is not dominator:
             root._dominator = dominator
             self._dominator = dominator

@@ -889,7 +889,9 @@ def test_config_dominance_and_master_follow_the_reference_union_find():
     e.master_by = LinearQuantizationConfig()
     assert e.state == S.PASSIVE_INIT
     with pytest.raises(ValueError): a.master_by = a
-    with pytest.raises(TypeError): a.dominated_by = 3
+    with pytest.raises(AssertionError): a.dominated_by = 3           # the reference asserts here (quant.py:679)
+    with pytest.raises(ValueError): a.dominated_by = c                # c's root is a: the son can not dominate its father
+    with pytest.raises(TypeError): a.master_by = 3
 
 
 def test_vectorised_channel_render_equals_the_scalar_loop():
@@ -1036,3 +1038,46 @@ def test_config_helper_methods_answer_like_the_reference():
     o = make(oc, 'ACTIVATED', 'EXPORT_WHEN_ACTIVE', False)
     o.dominated_by = b
     assert o.copy().scale is b.scale and not o.is_revisable() and b.is_revisable()
+
+
+def test_random_dominance_sequences_match_the_reference_config_class():
+    """The union-find of TensorQuantizationConfig driven by the same random sequence of ``dominated_by =`` / ``master_by =``
+    assignments on this package's configs and on the reference's own (core/quant.py:596-749): after every step the roots,
+    states and the scale each config resolves to are the same, and the same assignments are refused."""
+    import random
+    from oracle import reference_import as RI
+    if RI.find_reference() is None: pytest.skip('reference not present on this machine')
+    RI.load()
+    import ppq.core as rc
+    from ppq_amd import core as oc
+    for seed in range(30):
+        rnd = random.Random(seed)
+        n = rnd.randint(3, 9)
+
+        def make(m):
+            P = m.QuantizationProperty
+            pol = m.QuantizationPolicy(P.LINEAR.value + P.SYMMETRICAL.value + P.PER_TENSOR.value)
+            return [m.TensorQuantizationConfig(policy=pol, rounding=m.RoundingPolicy.ROUND_HALF_EVEN, num_of_bits=8, quant_min=-128,
+                                               quant_max=127, scale=torch.tensor([float(k + 1)]) if k % 2 == 0 else None,
+                                               offset=torch.tensor([0.0]) if k % 2 == 0 else None, observer_algorithm='minmax')
+                    for k in range(n)]
+        ref, ours = make(rc), make(oc)
+        for step in range(3 * n):
+            i, j = rnd.randrange(n), rnd.randrange(n)
+            attr = 'dominated_by' if rnd.random() < 0.7 else 'master_by'
+            # master_by has no cycle check in the reference (two configs mastering each other recurse for ever, in both
+            # implementations alike): keep the sequences to the assignments its passes make -- a master that is not below
+            if attr == 'master_by' and (i == j or ours[j].dominated_by is ours[i] or ours[i].dominated_by is not ours[i]): attr = 'dominated_by'
+            outcomes = []
+            for cfgs in (ref, ours):
+                try:
+                    setattr(cfgs[i], attr, cfgs[j]); outcomes.append('ok')
+                except (ValueError, TypeError, AssertionError) as e:
+                    outcomes.append(type(e).__name__)
+            assert outcomes[0] == outcomes[1], (seed, step, attr, i, j, outcomes)
+            for k in range(n):
+                r_root, o_root = ref[k].dominated_by, ours[k].dominated_by
+                assert ref.index(r_root) == ours.index(o_root), (seed, step, k)
+                assert ref[k].state.name == ours[k].state.name, (seed, step, k, ref[k].state, ours[k].state)
+                rs, os_ = ref[k].scale, ours[k].scale
+                assert (rs is None) == (os_ is None) and (rs is None or torch.equal(rs, os_)), (seed, step, k)
