@@ -1081,3 +1081,47 @@ def test_random_dominance_sequences_match_the_reference_config_class():
                 assert ref[k].state.name == ours[k].state.name, (seed, step, k, ref[k].state, ours[k].state)
                 rs, os_ = ref[k].scale, ours[k].scale
                 assert (rs is None) == (os_ is None) and (rs is None or torch.equal(rs, os_)), (seed, step, k)
+
+
+def test_policy_validity_and_observer_factory_dispatch_match_the_reference():
+    """Every combination of quantisation properties is accepted / refused by QuantizationPolicy exactly as the reference's
+    class does (core/quant.py:256-287), and for every valid policy x observer algorithm name (incl. capitalised, unknown and
+    missing ones) TensorObserverFactroy.build_observer returns an observer of the same class name or raises the same exception
+    type (observer/__init__.py:15-38, the constructors' policy checks in range.py / floating.py / order.py)."""
+    import itertools
+    from oracle import reference_import as RI
+    if RI.find_reference() is None: pytest.skip('reference not present on this machine')
+    RI.load()
+    import ppq.core as rc
+    import ppq.quantization.observer as ro
+    from ppq_amd import core as oc
+    from ppq_amd import observer as oo
+
+    class Var:
+        name, is_parameter, value = 'v', False, None
+
+    def bits(m, gran, sym, kind, pow2, dyn):
+        P = m.QuantizationProperty
+        return (getattr(P, kind).value + getattr(P, sym).value + getattr(P, gran).value + (P.POWER_OF_2.value if pow2 else 0)
+                + (P.DYNAMIC.value if dyn else 0))
+    checked = 0
+    for gran, sym, kind, pow2, dyn in itertools.product(['PER_TENSOR', 'PER_CHANNEL'], ['SYMMETRICAL', 'ASYMMETRICAL'],
+                                                        ['LINEAR', 'FLOATING'], [False, True], [False, True]):
+        verdict = []
+        for m in (rc, oc):
+            try: m.QuantizationPolicy(bits(m, gran, sym, kind, pow2, dyn)); verdict.append('ok')
+            except Exception as e: verdict.append(type(e).__name__)
+        assert verdict[0] == verdict[1], (gran, sym, kind, pow2, dyn, verdict)
+        if verdict[0] != 'ok': continue
+        for alg in ['minmax', 'kl', 'percentile', 'mse', 'isotone', 'constant', 'floating', 'Minmax', 'KL', 'nonsense', None]:
+            out = []
+            for m, o in ((rc, ro), (oc, oo)):
+                cfg = m.TensorQuantizationConfig(policy=m.QuantizationPolicy(bits(m, gran, sym, kind, pow2, dyn)),
+                                                 rounding=m.RoundingPolicy.ROUND_HALF_EVEN, num_of_bits=8, quant_min=-128, quant_max=127,
+                                                 observer_algorithm=alg, channel_axis=0 if gran == 'PER_CHANNEL' else None,
+                                                 exponent_bits=4 if kind == 'FLOATING' else 0)
+                try: out.append(type(o.TensorObserverFactroy.build_observer(Var(), cfg)).__name__)
+                except Exception as e: out.append('!' + type(e).__name__)
+            assert out[0] == out[1], (gran, sym, kind, pow2, dyn, alg, out)
+            checked += 1
+    assert checked >= 150
