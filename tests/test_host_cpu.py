@@ -1125,3 +1125,65 @@ def test_policy_validity_and_observer_factory_dispatch_match_the_reference():
             assert out[0] == out[1], (gran, sym, kind, pow2, dyn, alg, out)
             checked += 1
     assert checked >= 150
+
+
+def test_lsq_delegator_trainability_rules_match_the_reference():
+    """LSQDelegator.__init__ / trainable_tensors / withdraw (algorithm/training.py:318-376) is host logic: for every state x
+    policy (symmetric / asymmetric, power-of-2, floating) x {parameter, activation} x the three trainable flags x a dominated
+    config, this package's delegator decides what is trainable, what is backed up and what ``withdraw`` restores exactly as
+    the reference's does (same flags, same tensors by position, same restored values)."""
+    import itertools
+    from oracle import reference_import as RI
+    if RI.find_reference() is None: pytest.skip('reference not present on this machine')
+    RI.load()
+    import ppq.core as rc
+    from ppq.quantization.algorithm.training import LSQDelegator as RefDelegator
+    from ppq_amd import core as oc
+    from ppq_amd.lsq import LSQDelegator as OurDelegator
+
+    class Var:
+        def __init__(self, is_parameter): self.name, self.is_parameter, self.value = 'v', is_parameter, torch.arange(6.).reshape(2, 3)
+
+    def config(m, state, sym, kind, pow2, dominated, with_scale):
+        P = m.QuantizationProperty
+        p = getattr(P, kind).value + getattr(P, sym).value + P.PER_TENSOR.value + (P.POWER_OF_2.value if pow2 else 0)
+        c = m.TensorQuantizationConfig(policy=m.QuantizationPolicy(p), rounding=m.RoundingPolicy.ROUND_HALF_EVEN, num_of_bits=8,
+                                       quant_min=-128, quant_max=127, exponent_bits=4 if kind == 'FLOATING' else 0,
+                                       scale=torch.tensor([0.5]) if with_scale else None, offset=torch.tensor([3.0]) if with_scale else None,
+                                       observer_algorithm='minmax', state=getattr(m.QuantizationStates, state))
+        if dominated:
+            boss = m.TensorQuantizationConfig(policy=m.QuantizationPolicy(p), rounding=m.RoundingPolicy.ROUND_HALF_EVEN, num_of_bits=8,
+                                              quant_min=-128, quant_max=127, exponent_bits=4 if kind == 'FLOATING' else 0,
+                                              scale=torch.tensor([0.25]), offset=torch.tensor([1.0]), observer_algorithm='minmax',
+                                              state=m.QuantizationStates.ACTIVATED)
+            c.dominated_by = boss
+        return c
+    n = 0
+    for state, (sym, kind, pow2), is_param, dominated, with_scale, flags in itertools.product(
+            ['INITIAL', 'ACTIVATED', 'BAKED', 'PASSIVE', 'PASSIVE_INIT', 'FP32'],
+            [('SYMMETRICAL', 'LINEAR', False), ('ASYMMETRICAL', 'LINEAR', False), ('SYMMETRICAL', 'LINEAR', True),
+             ('SYMMETRICAL', 'FLOATING', True)], [False, True], [False, True], [False, True],
+            [(True, True, True), (False, True, True), (True, False, True), (True, True, False)]):
+        made = []
+        for m, D in ((rc, RefDelegator), (oc, OurDelegator)):
+            cfg, var = config(m, state, sym, kind, pow2, dominated, with_scale), Var(is_param)
+            d = D(cfg, var, is_parameter_trainable=flags[0], is_scale_trainable=flags[1], is_offset_trainable=flags[2])
+            made.append((d, cfg, var))
+        (r, rcfg, rvar), (o, ocfg, ovar) = made
+        key = (state, sym, kind, pow2, is_param, dominated, with_scale, flags)
+        assert (r.is_scale_trainable, r.is_offset_trainable, r.passive, r.is_parameter) == \
+               (o.is_scale_trainable, o.is_offset_trainable, o.passive, o.is_parameter), key
+        for a in ('scale_backup', 'offset_backup', 'param_backup'):
+            x, y = getattr(r, a), getattr(o, a)
+            assert (x is None) == (y is None) and (x is None or torch.equal(x, y)), (key, a)
+
+        def role(t, cfg, var): return 'offset' if t is cfg.offset else 'scale' if t is cfg.scale else 'value' if t is var.value else '?'
+        assert [role(t, rcfg, rvar) for t in r.trainable_tensors()] == [role(t, ocfg, ovar) for t in o.trainable_tensors()], key
+        for d, cfg, var in made:                                  # "train", then withdraw
+            with torch.no_grad():
+                for t in d.trainable_tensors(): t.add_(1.0)
+            d.withdraw(); d.finalize()
+        for t_r, t_o in ((rcfg.scale, ocfg.scale), (rcfg.offset, ocfg.offset), (rvar.value, ovar.value)):
+            assert (t_r is None) == (t_o is None) and (t_r is None or torch.equal(t_r, t_o)), key
+        n += 1
+    assert n == 6 * 4 * 2 * 2 * 2 * 4
