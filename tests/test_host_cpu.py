@@ -616,18 +616,20 @@ def test_isotone_observer_data_parallel_gather_equals_union():
         assert issued == 2 and scale == float(cfg.scale) and offset == float(cfg.offset), (rank, issued, scale, float(cfg.scale))
 
 
-def test_harness_quantizer_assigns_the_reference_config_states_on_resnet50():
+@pytest.mark.parametrize('topology,configs,n_weights', [('resnet50_graph', 368, 54), ('small_cnn_graph', 23, 3)])
+def test_harness_quantizer_assigns_the_reference_config_states_on_resnet50(topology, configs, n_weights):
     """harness.quantize_graph (TensorRT-style policy + the state edits of QuantizeSimplifyPass / QuantizeFusionPass) vs the
-    reference's own dispatcher + TensorRT quantizer + those passes on the ResNet-50 topology: the same 368 (operation, variable)
-    configs with the same state, policy bits, range and channel axis -- except that the reference driver has already run
-    its ParameterQuantizePass (54 weight configs ACTIVATED there, still INITIAL here)."""
+    reference's own dispatcher + TensorRT quantizer + those passes on the ResNet-50 topology (and the small CNN of the tests):
+    the same 368 (operation, variable) configs with the same state, policy bits, range and channel axis -- except that the
+    reference driver has already run its ParameterQuantizePass (54 weight configs ACTIVATED there, still INITIAL here)."""
     import torch
     from oracle import reference_import as RI
     if RI.find_reference() is None: pytest.skip('reference not present on this machine')
     from ppq_amd import harness
     RI.load()
-    rg, _ = RI.quantize_reference_graph(RI.to_reference_graph(harness.resnet50_graph(seed=0)), 'cpu', torch.rand(1, 3, 64, 64), method='kl')
-    hg = harness.resnet50_graph(seed=0)
+    build = getattr(harness, topology)
+    rg, _ = RI.quantize_reference_graph(RI.to_reference_graph(build(seed=0)), 'cpu', torch.rand(1, 3, 64, 64), method='kl')
+    hg = build(seed=0)
     harness.quantize_graph(hg, 'kl', hist_bins=2048)
 
     def table(graph):
@@ -639,7 +641,7 @@ def test_harness_quantizer_assigns_the_reference_config_states_on_resnet50():
                                              c.channel_axis if v.is_parameter and i == 1 else None, v.is_parameter)
         return out
     ours, ref = table(hg), table(rg)
-    assert set(ours) == set(ref) and len(ours) == 368
+    assert set(ours) == set(ref) and len(ours) == configs
     weights = 0
     for k, o in ours.items():
         r = ref[k]
@@ -649,7 +651,7 @@ def test_harness_quantizer_assigns_the_reference_config_states_on_resnet50():
         else:
             assert o[0] == r[0], (k, o, r)
             if o[0] != 'FP32': assert o[1:] == r[1:], (k, o, r)
-    assert weights == 54
+    assert weights == n_weights
 
 
 def test_block_builder_on_random_dags_vs_the_reference_walk():
