@@ -1189,3 +1189,46 @@ def test_lsq_delegator_trainability_rules_match_the_reference():
             assert (t_r is None) == (t_o is None) and (t_r is None or torch.equal(t_r, t_o)), key
         n += 1
     assert n == 6 * 4 * 2 * 2 * 2 * 4
+
+
+def test_ctypes_prototypes_agree_with_the_header_parameter_by_parameter():
+    """include/ppq_hip.h is the contract, ppq_amd/_lib.PROTOTYPES the binding: for every declared entry point the binding has
+    the same number of parameters, and each is of the same KIND (pointer / integer / float / double) in the same position, with
+    the same kind of return value -- an argument added on one side only would shift everything behind it."""
+    import ctypes
+    import re
+    from ppq_amd import _lib
+    text = open(os.path.join(ROOT, 'include', 'ppq_hip.h')).read()
+    text = re.sub(r'/\*.*?\*/', ' ', text, flags=re.S)
+    text = re.sub(r'//[^\n]*', ' ', text)
+    decls = re.findall(r'\b(int64_t|int|float|double|void|const\s+char\s*\*)\s+(ppqhip_\w+)\s*\(([^;{}]*?)\)\s*;', text)
+    assert len(decls) >= 55
+
+    def kind_of_c(param: str) -> str:
+        p = param.strip()
+        if '*' in p: return 'ptr'
+        base = re.sub(r'\b\w+$', '', p).strip() or p              # drop the parameter name
+        base = base.replace('const', '').strip()
+        if base in ('float',): return 'f32'
+        if base in ('double',): return 'f64'
+        if base in ('int', 'int64_t', 'uint32_t', 'int32_t', 'unsigned', 'unsigned int'): return 'int'
+        raise AssertionError(f'unrecognised parameter {param!r}')
+
+    def kind_of_ctypes(t) -> str:
+        if t is None: return 'void'
+        if t in (ctypes.c_void_p, ctypes.c_char_p) or hasattr(t, 'contents') or issubclass(t, ctypes._Pointer): return 'ptr'
+        if t is ctypes.c_float: return 'f32'
+        if t is ctypes.c_double: return 'f64'
+        if t in (ctypes.c_int, ctypes.c_int64, ctypes.c_uint32, ctypes.c_int32): return 'int'
+        raise AssertionError(f'unrecognised ctypes type {t!r}')
+    seen = set()
+    for ret, name, params in decls:
+        assert name in _lib.PROTOTYPES, f'{name} is declared in the header but has no ctypes prototype'
+        res, args = _lib.PROTOTYPES[name]
+        plist = [p for p in params.split(',') if p.strip() and p.strip() != 'void']
+        assert len(plist) == len(args), (name, len(plist), len(args))
+        assert [kind_of_c(p) for p in plist] == [kind_of_ctypes(a) for a in args], name
+        want = 'ptr' if '*' in ret else {'int': 'int', 'int64_t': 'int', 'float': 'f32', 'double': 'f64', 'void': 'void'}[ret]
+        assert kind_of_ctypes(res) == want, (name, ret, res)
+        seen.add(name)
+    assert seen == set(_lib.PROTOTYPES), sorted(set(_lib.PROTOTYPES) - seen)
