@@ -347,7 +347,7 @@ class PPLDSPTIReCalibrationPass(RuntimeCalibrationPass):
 
 
 class IsotoneCalibrationPass(RuntimeCalibrationPass):
-    """optim/calibration.py:325-423.  Marks classification outputs for the order-preserving 'isotone' observer -- by default the
+    """optim/calibration.py:325-422.  Marks classification outputs for the order-preserving 'isotone' observer -- by default the
     output of every Softmax that owns its config, otherwise the variables named in ``variables`` with ``axis`` as the class
     axis -- and then CALIBRATES them: like the reference's, this pass ends in ``RuntimeCalibrationPass.optimize`` (method None,
     so the 'Isotone' marks are kept, every other INITIAL config is observed with its own algorithm)."""

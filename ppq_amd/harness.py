@@ -226,7 +226,7 @@ class TorchExecutor:
 
     def partial_graph_forward(self, operations: List[Operation], feed_dict: Dict[str, torch.Tensor],
                               output_names: List[str], with_gradient: bool = False) -> List[torch.Tensor]:
-        """ppq/executor/torch.py:654-730: run only `operations` (already in execution order) on the
+        """ppq/executor/torch.py:654-682: run only `operations` (already in execution order) on the
         given feeds -- the block forward of the training based passes.  Like ``forward`` it records no autograd
         graph unless ``with_gradient`` (the finetuning passes' training step) asks for one."""
         if not with_gradient:

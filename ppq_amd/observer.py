@@ -230,7 +230,7 @@ class ObservationQueue:
 
 
 class BaseTensorObserver:
-    """ppq/quantization/observer/base.py:9-33."""
+    """ppq/quantization/observer/base.py:9-30."""
     queue: Optional[ObservationQueue] = None      # set by RuntimeCalibrationPass(batch_observations=True)
 
     def __init__(self, watch_on, quant_cfg):

@@ -1198,7 +1198,7 @@ def test_isotone_observer_never_worse_than_minmax_at_keeping_the_argmax(symmetri
 
 
 def test_isotone_calibration_pass_marks_softmax_outputs_and_calibrates_them():
-    """optim/calibration.py:325-423: IsotoneCalibrationPass rewrites the Softmax output configs (INITIAL, 'Isotone', axis) AND,
+    """optim/calibration.py:325-422: IsotoneCalibrationPass rewrites the Softmax output configs (INITIAL, 'Isotone', axis) AND,
     like the reference's (its optimize ends in super().optimize, :423), calibrates: the marked configs are rendered by the
     isotone observer inside this very pass, every other config by the algorithm it already had."""
     from ppq_amd import harness
