@@ -19,7 +19,7 @@
  *     shape); dtype errors (ValueTypeException, common.cuh:32-39) cannot occur behind a typed C
  *     ABI and are raised by the Python binding instead;
  *   - `rounding` uses the values of ppq.core.RoundingPolicy (quant.py:123-142) /
- *     common.cuh:16-23: 0 HALF_EVEN, 1 HALF_UP, 2 HALF_DOWN, 3 HALF_TOWARDS_ZERO,
+ *     common.cuh:17-24: 0 HALF_EVEN, 1 HALF_UP, 2 HALF_DOWN, 3 HALF_TOWARDS_ZERO,
  *     4 HALF_FAR_FORM_ZERO, 5 TO_NEAR_INT, 6 UP, 7 DOWN;
  *   - per-channel ops address a contiguous tensor as [outer, num_channel, elem_per_channel]:
  *     channel(i) = (i / elem_per_channel) % num_channel (linear.cu:146, floating.cu:94).
@@ -353,18 +353,18 @@ int ppqhip_kl_losses(const int32_t* hist, int64_t num_hist, int64_t num_bins, in
                      double* losses, void* stream);
 
 /* training helpers (exported by the reference, no caller in ppq/) ------------------------------ */
-/* replace TensorClip_T / TensorClip_C, train.cu:84-113 / :51-82. */
+/* replace TensorClip_T / TensorClip_C, train.cu:80-113 / :35-78 (kernel + host wrapper each). */
 int ppqhip_tensor_clip_t(const float* value, const float* reference, const float* limit,
                          float* out, int64_t n, void* stream);
 int ppqhip_tensor_clip_c(const float* value, const float* reference, const float* limit,
                          float* out, int64_t n, int64_t num_channel, int64_t elem_per_channel,
                          void* stream);
-/* replace RoundingLoss_LT / _LC (train.cu:143-175, :242-275): out[0] is OVERWRITTEN.
+/* replace RoundingLoss_LT / _LC (train.cu:115-168, :220-280): out[0] is OVERWRITTEN.
  * num_channel = 0 selects the per-tensor form. */
 int ppqhip_rounding_loss(const float* x, const float* scale, const float* offset, float* out,
                          int64_t n, int64_t num_channel, int64_t elem_per_channel,
                          int clip_min, int clip_max, int rounding, void* stream);
-/* replace RoundingLoss_LT_B / _LC_B (train.cu:196-214, :311-338); dy is one device float. */
+/* replace RoundingLoss_LT_B / _LC_B (train.cu:170-218, :282-338); dy is one device float. */
 int ppqhip_rounding_loss_bwd(const float* x, const float* dy, const float* scale,
                              const float* offset, float* dx, int64_t n, int64_t num_channel,
                              int64_t elem_per_channel, int clip_min, int clip_max, int rounding,

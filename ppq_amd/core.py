@@ -39,7 +39,7 @@ PPQ_CONFIG = _Config()
 
 
 class RoundingPolicy(Enum):
-    """ppq/core/quant.py:123-142 (C values: ppq/csrc/cuda/common.cuh:16-23)."""
+    """ppq/core/quant.py:123-142 (C values: ppq/csrc/cuda/common.cuh:17-24)."""
     ROUND_HALF_EVEN = 0
     ROUND_HALF_UP = 1
     ROUND_HALF_DOWN = 2

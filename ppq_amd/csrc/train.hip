@@ -23,7 +23,7 @@ __global__ __launch_bounds__(kBlock) void tensor_clip_kernel(const float* __rest
     }
 }
 
-// _RoundingLoss_LT / _LC, train.cu:115-141 / :216-240.  The kernels round the offset with
+// _RoundingLoss_LT / _LC, train.cu:115-141 / :220-247.  The kernels round the offset with
 // nearbyint (not round) and compare against s * (clip - o) with the int offset (LT) or the raw
 // float offset (LC).
 __device__ __forceinline__ float rl_elem(float v, float s, float oraw, int per_channel, int qmin, int qmax,
