@@ -46,7 +46,7 @@ class Variable:
 
 
 class OperationQuantizationConfig:
-    """ppq/core/quant.py:899-940."""
+    """ppq/core/quant.py:952-1013."""
     def __init__(self, input_quantization_configs, output_quantization_configs):
         self.input_quantization_config: List[TensorQuantizationConfig] = input_quantization_configs
         self.output_quantization_config: List[TensorQuantizationConfig] = output_quantization_configs
