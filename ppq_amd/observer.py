@@ -987,6 +987,19 @@ OBSERVER_TABLE = {
 }
 
 
+def register_calibration_observer(algorithm: str, observer: type) -> None:
+    """ppq/lib/extension.py:76-93: put a user's observer class into OBSERVER_TABLE (an existing entry is replaced without
+    warning, as there).  The factory looks algorithms up in lower case (observer/__init__.py:28-38), so the key is stored that
+    way.  The reference demands a subclass of ``OperationObserver`` here although the table holds TENSOR observers
+    (``build_observer`` instantiates the entry with ``(watch_on, quant_cfg)``): this mirror asks for what the table needs, a
+    ``BaseTensorObserver`` subclass."""
+    if not isinstance(observer, type):
+        raise TypeError(f'You can only register an observer CLASS as custimized ppq observer, however {type(observer)} is given. ')
+    if not issubclass(observer, BaseTensorObserver):
+        raise TypeError('Regitsing observer must be a subclass of BaseTensorObserver.')
+    OBSERVER_TABLE[str(algorithm).lower()] = observer
+
+
 class TensorObserverFactroy:
     """observer/__init__.py:25-37."""
     def __init__(self) -> None:

@@ -1232,3 +1232,25 @@ def test_ctypes_prototypes_agree_with_the_header_parameter_by_parameter():
         assert kind_of_ctypes(res) == want, (name, ret, res)
         seen.add(name)
     assert seen == set(_lib.PROTOTYPES), sorted(set(_lib.PROTOTYPES) - seen)
+
+
+def test_register_calibration_observer_extends_the_factory():
+    """ppq/lib/extension.py:76-93 mirrored: a user observer class registered under a name is what the factory builds for
+    configs naming that algorithm (case-insensitively); non-classes and non-observers are refused with TypeError."""
+    from ppq_amd import LinearQuantizationConfig
+    from ppq_amd import observer as O
+
+    class Mine(O.BaseTensorObserver):
+        def observe(self, value): pass
+        def render_quantization_config(self): pass
+    saved = dict(O.OBSERVER_TABLE)
+    try:
+        O.register_calibration_observer('MyAlgo', Mine)
+        cfg = LinearQuantizationConfig(calibration='myalgo')
+        assert type(O.TensorObserverFactroy.build_observer('v', cfg)) is Mine
+        cfg.observer_algorithm = 'MYALGO'
+        assert type(O.TensorObserverFactroy.build_observer('v', cfg)) is Mine
+        with pytest.raises(TypeError): O.register_calibration_observer('x', Mine('v', cfg))
+        with pytest.raises(TypeError): O.register_calibration_observer('x', dict)
+    finally:
+        O.OBSERVER_TABLE.clear(); O.OBSERVER_TABLE.update(saved)
