@@ -1239,3 +1239,30 @@ def test_isotone_calibration_pass_marks_softmax_outputs_and_calibrates_them():
     with pytest.raises(ValueError):
         IsotoneCalibrationPass(variables=['no such variable']).optimize(graph, dataloader=batches, executor=ex)
 
+
+
+def test_lib_quant_stubs_observe_render_and_quantise():
+    """ppq_amd.lib.TensorQuant / ParameterQuant (ppq/lib/quant.py:58-103): observe -> render -> forward gives exactly what the
+    observer + PPQuantFunction give when driven by hand -- per-tensor activations (minmax, kl) and a per-channel weight -- and a
+    delegator, once set, takes the call over."""
+    import ppq_amd.lib as PFL
+    from ppq_amd.qfunction import PPQuantFunction
+    g = torch.Generator().manual_seed(3)
+    batches = [torch.randn(4, 8, 16, 16, generator=g).to(DEV) for _ in range(4)]
+    for algo in ('minmax', 'kl'):
+        cfg_a, cfg_b = (PFL.LinearQuantizationConfig(calibration=algo) for _ in range(2))
+        stub, ob = PFL.TensorQuant(cfg_a), PFL.Observer(cfg_b)
+        for phase in range(2 if algo == 'kl' else 1):
+            for b in batches: stub.observe(b); ob.observe(b)
+            stub.render(); ob.render_quantization_config()
+        assert cfg_a.state.value == 4 and torch.equal(cfg_a.scale, cfg_b.scale) and torch.equal(cfg_a.offset, cfg_b.offset)
+        assert torch.equal(stub(batches[0]), PPQuantFunction(batches[0], cfg_b))
+    w = torch.randn(16, 8, 3, 3, generator=g).to(DEV)
+    cfg_w = PFL.LinearQuantizationConfig(channel_axis=0, calibration='minmax')
+    pq = PFL.ParameterQuant(cfg_w, w)
+    assert cfg_w.state.value == 4 and cfg_w.scale.shape == (16,)
+    want = w.abs().amax(dim=(1, 2, 3)).double() * 2 / (cfg_w.quant_max - cfg_w.quant_min)
+    assert torch.allclose(cfg_w.scale.double(), want, rtol=1e-6)
+    assert torch.equal(pq(w), PPQuantFunction(w, cfg_w))
+    pq.delegator = lambda t, c: t * 0
+    assert float(pq(w).abs().max()) == 0.0

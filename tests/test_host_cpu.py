@@ -1254,3 +1254,33 @@ def test_register_calibration_observer_extends_the_factory():
         with pytest.raises(TypeError): O.register_calibration_observer('x', dict)
     finally:
         O.OBSERVER_TABLE.clear(); O.OBSERVER_TABLE.update(saved)
+
+
+def test_lib_pipeline_and_quant_stub_host_logic():
+    """ppq_amd.lib (the on-path slice of ppq.lib): Pipeline runs its passes in order with the caller's keywords, ``at_front``
+    prepends, non-passes are refused; a quant stub refuses to render before it saw data, ParameterQuant refuses a non-tensor;
+    PFL.Observer builds what the config names."""
+    import ppq_amd.lib as PFL
+    from ppq_amd.calibration import QuantizationOptimizationPass
+    from ppq_amd.observer import TorchHistObserver
+    log = []
+
+    class Step(QuantizationOptimizationPass):
+        def __init__(self, tag): super().__init__(name=f'step {tag}'); self.tag = tag
+        def optimize(self, graph, **kwargs): log.append((self.tag, graph, sorted(kwargs)))
+    a, b, c = Step('a'), Step('b'), Step('c')
+    pipe = PFL.Pipeline([a, b])
+    assert pipe.append_optimization_to_pipeline(c, at_front=True) is pipe and len(pipe) == 3 and a in pipe
+    pipe.optimize(graph='G', verbose=False, dataloader=[1], executor=None, calib_steps=8)
+    assert [t for t, _, _ in log] == ['c', 'a', 'b'] and all(g == 'G' and k == ['calib_steps', 'dataloader', 'executor'] for _, g, k in log)
+    assert pipe.report().count('\n') == 3 and 'step c' in pipe.report().splitlines()[0]
+    with pytest.raises(AssertionError): PFL.Pipeline([a, 'not a pass'])
+    with pytest.raises(AssertionError): 3 in pipe
+    cfg = PFL.LinearQuantizationConfig(calibration='kl')
+    assert isinstance(PFL.Observer(cfg), TorchHistObserver)
+    stub = PFL.TensorQuant(cfg)
+    with pytest.raises(PermissionError): stub.render()
+    with pytest.raises(TypeError): PFL.ParameterQuant(cfg, [1.0, 2.0])
+    seen = []
+    stub.delegator = lambda t, c: seen.append(c) or t + 1
+    assert float(stub(torch.zeros(1))) == 1.0 and seen == [cfg] and stub.delegator is not None
