@@ -34,6 +34,13 @@ def _state_of(cfg, wanted):
     return getattr(cls, wanted.name) if hasattr(cls, wanted.name) else wanted
 
 
+def _visibility_of(cfg, wanted):
+    """The member named like ``wanted`` of the enum class ``cfg.visibility`` comes from: a config of the reference's keeps
+    members of the reference's enum, so that its own ``can_export`` (an ``==`` against ITS ``INTERNAL``) still recognises them."""
+    cls = type(getattr(cfg, 'visibility', wanted))
+    return getattr(cls, wanted.name) if hasattr(cls, wanted.name) else wanted
+
+
 class ParameterQuantizePass(QuantizationOptimizationPass):
     """optim/parameters.py:156-215.  ``method`` overrides the observer algorithm of every parameter config (:186-188);
     ``dataloader`` / ``executor`` are accepted for the reference's call protocol and not needed: the parameters are read
@@ -179,12 +186,12 @@ class PassiveParameterQuantizePass(QuantizationOptimizationPass):
                 self._require_quantized_input(op, cfgs[0], 'clip value')
                 for cfg in cfgs[1:]:
                     cfg.master_by = cfgs[0]
-                    cfg.visibility = self.clip_visiblity
+                    cfg.visibility = _visibility_of(cfg, self.clip_visiblity)
             if self.process_pad and op.type == 'Pad' and len(op.inputs) == 3:
                 self._require_quantized_input(op, cfgs[0], 'pad value')
                 if len(cfgs) > 1:
                     cfgs[-1].master_by = cfgs[0]
-                    cfgs[-1].visibility = self.pad_visiblity
+                    cfgs[-1].visibility = _visibility_of(cfgs[-1], self.pad_visiblity)
         self.unresolved = [(op.name, var.name) for op in graph.operations.values() if hasattr(op, 'config')
                            for cfg, var in op.config_with_variable if state_value(cfg.state) == _S.PASSIVE_INIT.value]
         for op_name, var_name in self.unresolved:

@@ -1284,3 +1284,63 @@ def test_lib_pipeline_and_quant_stub_host_logic():
     seen = []
     stub.delegator = lambda t, c: seen.append(c) or t + 1
     assert float(stub(torch.zeros(1))) == 1.0 and seen == [cfg] and stub.delegator is not None
+
+
+def test_passive_parameter_pass_on_clip_and_pad_matches_the_reference_on_seven_platforms():
+    """PassiveParameterQuantizePass's Clip / Pad / bias branches (optim/parameters.py:13-153) on a Conv -> Clip(min, max) ->
+    Pad(pads, value) -> Relu graph built with the reference's graph API and quantised by SEVEN of its quantizers: the reference's
+    pass on one copy, this package's (duck-typed) on the other -- the same states, scales and visibilities (members of the
+    REFERENCE's enum, so that its exporters' ``can_export`` answers the same), and the same PermissionError when the input of
+    the Clip / the Pad / the Conv has not been quantised."""
+    from oracle import reference_import as RI
+    if RI.find_reference() is None: pytest.skip('reference not present on this machine')
+    RI.load()
+    import ppq.lib as PFL
+    from ppq import BaseGraph, QuantizationProperty, TargetPlatform
+    from ppq.core import NetworkFramework
+    from ppq.core import QuantizationStates as RS
+    from ppq.quantization.optim import PassiveParameterQuantizePass as Ref
+    from ppq_amd.parameters import PassiveParameterQuantizePass as Ours
+
+    def prepared(platform, unquantised):
+        g = BaseGraph(name='t', built_from=NetworkFramework.ONNX)
+        gen = torch.Generator().manual_seed(0)
+
+        def v(n, val=None, p=False): return g.create_variable(name=n, value=val, is_parameter=p)
+        x, w, b, y = v('x'), v('w', torch.randn(4, 3, 3, 3, generator=gen), True), v('b', torch.randn(1, 4, generator=gen), True), v('y')
+        g.create_operation(op_type='Conv', name='conv', attributes={'kernel_shape': [3, 3], 'strides': [1, 1], 'pads': [1, 1, 1, 1],
+                                                                    'dilations': [1, 1], 'group': 1}, inputs=[x, w, b], outputs=[y])
+        lo, hi, c = v('lo', torch.tensor(0.0), True), v('hi', torch.tensor(6.0), True), v('c')
+        g.create_operation(op_type='Clip', name='clip', attributes={}, inputs=[y, lo, hi], outputs=[c])
+        pads, val, p = v('pads', torch.tensor([0, 0, 1, 1, 0, 0, 1, 1]), True), v('val', torch.tensor(0.0), True), v('p')
+        g.create_operation(op_type='Pad', name='pad', attributes={'mode': 'constant'}, inputs=[c, pads, val], outputs=[p])
+        r = v('r')
+        g.create_operation(op_type='Relu', name='relu', attributes={}, inputs=[p], outputs=[r])
+        g.mark_variable_as_graph_input(x); g.mark_variable_as_graph_output(r)
+        quantizer = PFL.Quantizer(platform=platform, graph=g)
+        for op in list(g.operations.values()):
+            op.platform = platform
+            quantizer.quantize_operation(op.name, platform=platform)
+        for op in g.operations.values():                            # a stand-in calibration
+            for k, (cfg, _) in enumerate(op.config_with_variable):
+                if cfg.state == RS.INITIAL and not (unquantised == op.type and k == 0):
+                    n = 4 if cfg.policy.has_property(QuantizationProperty.PER_CHANNEL) else 1
+                    cfg.scale, cfg.offset, cfg.state = torch.full([n], 0.1 * (k + 1)), torch.zeros(n), RS.ACTIVATED
+        return g
+    passive = 0
+    for name in ('PPL_CUDA_INT8', 'PPL_DSP_INT8', 'SNPE_INT8', 'TRT_INT8', 'OPENVINO_INT8', 'METAX_INT8_C', 'QNN_DSP_INT8'):
+        for unquantised in (None, 'Clip', 'Pad', 'Conv'):
+            a, b = (prepared(getattr(TargetPlatform, name), unquantised) for _ in range(2))
+            outcome = []
+            for pass_, g in ((Ref(), a), (Ours(), b)):
+                try: pass_.optimize(g); outcome.append(None)
+                except PermissionError as e: outcome.append(str(e))
+            assert outcome[0] == outcome[1], (name, unquantised, outcome)
+            for (na, oa), (_, ob) in zip(a.operations.items(), b.operations.items()):
+                for (ca, va), (cb, vb) in zip(oa.config_with_variable, ob.config_with_variable):
+                    key = (name, unquantised, na, va.name)
+                    assert ca.state is cb.state and ca.visibility is cb.visibility and ca.can_export() == cb.can_export(), key
+                    assert (ca.scale is None) == (cb.scale is None) and (ca.scale is None or torch.equal(ca.scale, cb.scale)), key
+                    assert va.value is None or va.value.shape == vb.value.shape, key
+                    passive += ca.state == RS.PASSIVE
+    assert passive >= 40
