@@ -17,8 +17,8 @@ from typing import Callable, Iterable, List, Tuple
 
 import torch
 
-from .blocks import (PrefixCache, collect, collect_all_fp_outputs, compute_block_loss, split_graph_into_blocks,
-                     torch_mean_square_error)
+from .blocks import (PrefixCache, block_forward, collect, collect_all_fp_outputs, compute_block_loss, split_graph_into_blocks,
+                     supports_prefix_cache, torch_mean_square_error)
 from .calibration import QuantizationOptimizationPass
 from .ffi import CUDA
 
@@ -60,12 +60,12 @@ class BiasCorrectionPass(QuantizationOptimizationPass):
         quantable = [op for op in block.rps if hasattr(op, 'config')]
         for op in quantable: op.dequantize()                              # phase 1: FP32 block outputs
         for qt_input in qt_inputs:
-            outs = executor.partial_graph_forward(block.rps, qt_input, interested_outputs)
+            outs = block_forward(executor, block.rps, qt_input, interested_outputs)
             for name, value in zip(interested_outputs, outs):
                 fp_cache[name].append(collect_bias(value, graph.variables[name].source_op.type))
         for op in quantable: op.restore_quantize_state()                  # phase 2: quantised block outputs
         for qt_input in qt_inputs:
-            outs = executor.partial_graph_forward(block.rps, qt_input, interested_outputs)
+            outs = block_forward(executor, block.rps, qt_input, interested_outputs)
             for name, value in zip(interested_outputs, outs):
                 qt_cache[name].append(collect_bias(value, graph.variables[name].source_op.type))
         for name in interested_outputs:
@@ -93,12 +93,12 @@ class BiasCorrectionPass(QuantizationOptimizationPass):
         # time only) and quantised block inputs computed incrementally (blocks.PrefixCache: a corrected block invalidates what it
         # feeds) -- the reference runs two full forwards per block and batch (training.py:224-298); same values
         all_fp = collect_all_fp_outputs(graph, blocks, executor, batches)
-        prefix = PrefixCache(graph, executor, batches) if all_fp is not None else None
+        prefix = PrefixCache(graph, executor, batches) if (all_fp is not None and supports_prefix_cache(executor)) else None
         for k, block in enumerate(blocks):
-            if prefix is not None:
-                qt_inputs, fp_outputs = prefix.inputs_of(block), all_fp[k]
-                all_fp[k] = None
-            else: qt_inputs, fp_outputs = collect(graph, block, executor, batches)
+            targets = all_fp[k] if all_fp is not None else None
+            if all_fp is not None: all_fp[k] = None
+            if prefix is not None: qt_inputs, fp_outputs = prefix.inputs_of(block), targets
+            else: qt_inputs, fp_outputs = collect(graph, block, executor, batches, fp_outputs=targets)
             pre_loss, post_loss = self.correct_bias(qt_inputs, fp_outputs, block, executor, graph)
             if prefix is not None: prefix.invalidate(block)
             self.report.append((block.sp.name, pre_loss, post_loss))

@@ -99,6 +99,32 @@ def split_graph_into_blocks(graph, executing_order: Optional[list] = None, block
     return [b for b in blocks if any(o.name in interested_layers for o in b.rps)]
 
 
+_TAKES_WITH_GRADIENT: Dict[type, bool] = {}
+
+
+def block_forward(executor, operations, feed_dict, output_names, with_gradient: bool = False):
+    """``executor.partial_graph_forward`` for this package's executor (which takes ``with_gradient``) AND for the reference's
+    (executor/torch.py:654-682: no such parameter -- it records autograd history whenever grad mode is on), so that the
+    block-wise passes run on either."""
+    fn = executor.partial_graph_forward
+    native = _TAKES_WITH_GRADIENT.get(type(executor))
+    if native is None:
+        import inspect
+        native = _TAKES_WITH_GRADIENT[type(executor)] = 'with_gradient' in inspect.signature(fn).parameters
+    if native: return fn(operations, feed_dict, output_names, with_gradient=with_gradient)
+    device = getattr(executor, '_device', None)                  # the reference's own passes move the feeds themselves
+    if device is not None: feed_dict = {k: v.to(device) for k, v in feed_dict.items()}        # (training.py:782)
+    if with_gradient:
+        with torch.enable_grad(): return fn(operations, feed_dict, output_names)
+    with torch.no_grad(): return fn(operations, feed_dict, output_names)
+
+
+def supports_prefix_cache(executor) -> bool:
+    """PrefixCache needs ``forward_cached`` (this package's executor); on the reference's executor the passes collect the
+    block inputs with a forward per block, as the reference does."""
+    return hasattr(executor, 'forward_cached')
+
+
 def torch_mean_square_error(y_pred: torch.Tensor, y_real: torch.Tensor) -> torch.Tensor:
     """ppq/quantization/measure/norm.py: mean over the batch of the per-sample mean squared error."""
     return torch.mean(torch.mean(torch.square(y_pred.flatten(1) - y_real.flatten(1)), dim=-1))
@@ -217,7 +243,7 @@ def compute_block_loss(block: TrainableBlock, qt_inputs, fp_outputs, executor, l
     names = [v.name for v in block.ep.outputs]
     terms = {n: [] for n in names}
     for qt_input, fp_output in zip(qt_inputs, fp_outputs):
-        outs = executor.partial_graph_forward(block.rps, qt_input, names)
+        outs = block_forward(executor, block.rps, qt_input, names)
         for n, y in zip(names, outs): terms[n].append(loss_fn(y, fp_output[n]).reshape(1))
     # ONE device-to-host copy for all batches (the reference synchronises per batch, training.py:326-330); the sums are
     # formed on the host in the reference's order, in double like its Python floats

@@ -991,7 +991,9 @@ def install_plugins_into_ppq(observers: bool = True) -> None:
       ``ppq.TorchExecutor.forward(hooks=...)`` fires it;
     * ``ppq.quantization.optim.base.QuantizationOptimizationPass`` is an ABC and PPQ's pipeline admits a pass by
       ``isinstance`` (optim/base.py:60-82): this package's pass base class is registered, so
-      ``ppq_amd.calibration.RuntimeCalibrationPass`` (and the LSQ / bias-correction passes) go into ``ppq.lib.Pipeline``;
+      ``ppq_amd.calibration.RuntimeCalibrationPass`` (and the parameter / LSQ / bias-correction passes) go into
+      ``ppq.lib.Pipeline``; ``TorchQuantizeDelegator`` likewise admits this package's ``LSQDelegator`` to
+      ``TorchExecutor.register_quantize_delegate``;
     * with ``observers=True`` PPQ's ``OBSERVER_TABLE`` (observer/__init__.py:15-23) is updated with the HIP-backed
       observers, so PPQ's OWN ``RuntimeCalibrationPass`` builds them; its two-phase test is by exact type
       (optim/calibration.py:196: ``type(ob) not in {TorchHistObserver, TorchMSEObserver}``), so the two names that module
@@ -1001,9 +1003,12 @@ def install_plugins_into_ppq(observers: bool = True) -> None:
     from ppq.executor.base import QuantOPRuntimeHook
     from ppq.quantization.optim.base import QuantizationOptimizationPass as RefPass
 
-    from . import calibration, observer
+    from ppq.executor.torch import TorchQuantizeDelegator
+
+    from . import calibration, lsq, observer
     QuantOPRuntimeHook.register(observer.CalibrationHook)
     RefPass.register(calibration.QuantizationOptimizationPass)
+    TorchQuantizeDelegator.register(lsq.LSQDelegator)      # register_quantize_delegate admits by isinstance (torch.py:317-320)
     if observers:
         import ppq.quantization.observer as ref_observer
         import ppq.quantization.optim.calibration as ref_calibration

@@ -15,7 +15,7 @@ from torch.autograd import Function
 
 from .core import QuantizationProperty as P
 from .core import QuantizationStates, rounding_value, state_value
-from .blocks import COMPUTING_OP
+from .blocks import COMPUTING_OP, block_forward
 from .calibration import QuantizationOptimizationPass
 from .ffi import CUDA
 from .qfunction import PPQuantFunction, _as_1d
@@ -429,7 +429,7 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
             opt.zero_grad()
             for g in groups: g.prepare()
             with torch.enable_grad():
-                outs = executor.partial_graph_forward(block.rps, qt_input, names, with_gradient=True)
+                outs = block_forward(executor, block.rps, qt_input, names, with_gradient=True)
                 loss = sum(self._loss(y, fp_output[n]) for n, y in zip(names, outs))
                 if self.gamma:
                     for op in block.rps:                                  # training.py:793-798 (the STE gradient passes)
@@ -478,11 +478,12 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
         # quantisation time -- what earlier blocks train does not move the targets of later ones, so the targets of EVERY
         # block come from ONE dequantised forward per batch (the reference runs that forward again for each block,
         # training.py:224-298: same values, 27 x the work on the YOLOv6-s-like graph; 288 GB of HBM hold them all)
-        from .blocks import PrefixCache, collect_all_fp_outputs
+        from .blocks import PrefixCache, collect_all_fp_outputs, supports_prefix_cache
         with self._phase('collect_fp_targets'):
             all_fp = collect_all_fp_outputs(graph, blocks, executor, batches) if self.incremental_inputs else None
         # quantised block inputs: incrementally (blocks.PrefixCache) -- the prefix of the graph runs once per batch overall
-        prefix = PrefixCache(graph, executor, batches) if self.incremental_inputs else None
+        # (on the reference's own executor, which has no forward_cached: a forward per block, as the reference does)
+        prefix = PrefixCache(graph, executor, batches) if (self.incremental_inputs and supports_prefix_cache(executor)) else None
         for k, block in enumerate(blocks):
             with self._phase('collect_block_inputs'):
                 targets = all_fp[k] if all_fp is not None else None       # None: too large to keep for all blocks -> per block

