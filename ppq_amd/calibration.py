@@ -375,9 +375,11 @@ class IsotoneCalibrationPass(RuntimeCalibrationPass):
                 self._mark(cfg, axis)
                 if self.verbose: print(f'Calibration Method of Op {op.name} has been changed to Isotone[axis={axis}].')
         else:
-            if not isinstance(self.variables, list) or not all(isinstance(v, str) for v in self.variables):
+            if not isinstance(self.variables, list):
                 raise TypeError('Isotone Calibration Pass needs a list of variable name as its input.')
-            for name in self.variables:
+            for name in self.variables:                                        # checked one by one, as the reference does:
+                if not isinstance(name, str):                                  # names before a bad entry ARE marked
+                    raise TypeError('Isotone Calibration Pass needs a list of variable name as its input.')
                 if name not in graph.variables: raise ValueError(f'Variable {name} not in current graph.')
                 var = graph.variables[name]
                 op = var.source_op

@@ -1344,3 +1344,56 @@ def test_passive_parameter_pass_on_clip_and_pad_matches_the_reference_on_seven_p
                     assert va.value is None or va.value.shape == vb.value.shape, key
                     passive += ca.state == RS.PASSIVE
     assert passive >= 40
+
+
+def test_isotone_pass_marks_the_same_configs_as_the_reference(monkeypatch):
+    """IsotoneCalibrationPass's marking step (optim/calibration.py:325-422; the calibration it ends in is stubbed out on both
+    sides) on a Gemm -> Softmax -> Softmax graph built with the reference's graph API under four of its quantizers: default
+    (every Softmax output that is its own root), named variables with an axis, a missing name, a non-list and a list with a
+    non-string -- same states / algorithms / axes on every config afterwards (incl. what was marked BEFORE a bad entry raised),
+    same exception type and text."""
+    from oracle import reference_import as RI
+    if RI.find_reference() is None: pytest.skip('reference not present on this machine')
+    RI.load()
+    import ppq.lib as PFL
+    import ppq.quantization.optim.calibration as rcal
+    from ppq import BaseGraph, TargetPlatform
+    from ppq.core import NetworkFramework
+    from ppq.core import QuantizationStates as RS
+    from ppq_amd import calibration as ocal
+    monkeypatch.setattr(rcal.RuntimeCalibrationPass, 'optimize', lambda self, graph, **kw: None)
+    monkeypatch.setattr(ocal.RuntimeCalibrationPass, 'optimize', lambda self, graph, **kw: None)
+
+    def build(platform):
+        g = BaseGraph(name='t', built_from=NetworkFramework.ONNX)
+
+        def v(n, val=None, p=False): return g.create_variable(name=n, value=val, is_parameter=p)
+        x, w, b, y, s, s2 = v('x'), v('w', torch.randn(10, 8), True), v('b', torch.randn(10), True), v('y'), v('s'), v('s2')
+        g.create_operation(op_type='Gemm', name='fc', attributes={'alpha': 1.0, 'beta': 1.0, 'transA': 0, 'transB': 1}, inputs=[x, w, b], outputs=[y])
+        g.create_operation(op_type='Softmax', name='sm', attributes={'axis': 1}, inputs=[y], outputs=[s])
+        g.create_operation(op_type='Softmax', name='sm2', attributes={}, inputs=[s], outputs=[s2])
+        g.mark_variable_as_graph_input(x); g.mark_variable_as_graph_output(s2)
+        quantizer = PFL.Quantizer(platform=platform, graph=g)
+        for op in list(g.operations.values()):
+            op.platform = platform
+            quantizer.quantize_operation(op.name, platform=platform)
+        for op in g.operations.values():
+            for c, _ in op.config_with_variable:
+                if c.state == RS.INITIAL: c.state, c.scale, c.offset = RS.ACTIVATED, torch.tensor([0.1]), torch.tensor([0.0])
+        return g
+
+    def table(g):
+        return [(op.name, var.name, c.state.name, c.observer_algorithm, c.detail.get('OBSERVER_ISOTONE_OBSERVER_AXIS'))
+                for op in g.operations.values() for c, var in op.config_with_variable]
+    marked = 0
+    for name in ('PPL_CUDA_INT8', 'SNPE_INT8', 'TRT_INT8', 'OPENVINO_INT8'):
+        for kw in ({}, {'variables': ['y'], 'axis': 0}, {'variables': ['s', 'y'], 'axis': -1}, {'variables': ['nope']},
+                   {'variables': 's'}, {'variables': ['s', 3]}):
+            a, b = build(getattr(TargetPlatform, name)), build(getattr(TargetPlatform, name))
+            out = []
+            for cls, g in ((rcal.IsotoneCalibrationPass, a), (ocal.IsotoneCalibrationPass, b)):
+                try: cls(verbose=False, **kw).optimize(g); out.append(None)
+                except (TypeError, ValueError) as e: out.append((type(e).__name__, str(e)))
+            assert out[0] == out[1] and table(a) == table(b), (name, kw, out)
+            marked += sum(1 for row in table(b) if row[3] == 'Isotone')
+    assert marked >= 20
