@@ -40,7 +40,8 @@ typedef enum {
     PPQHIP_ERR_HIP = -3            /* a HIP runtime call failed (launch error, bad pointer ...) */
 } ppqhip_status;
 
-#define PPQHIP_ABI_VERSION 3   /* 2: quantile hints (round 3); 3: *_multi LSQ / min-max entry points, quantile sequence (round 4) */
+#define PPQHIP_ABI_VERSION 4   /* 2: quantile hints (round 3); 3: *_multi LSQ / min-max entry points, quantile sequence (round 4);
+                                * 4: ppqhip_minmax_c_multi carries its job table in the kernel arguments (no device table / upload) */
 
 /* library / device introspection ------------------------------------------------------------- */
 const char* ppqhip_last_error(void);
@@ -268,8 +269,8 @@ int ppqhip_minmax_c(const float* x, int64_t n, int64_t num_channel, int64_t elem
  * ppqhip_minmax_c (bit-identical: min / max are order independent).  `fresh` != 0: mins / maxs are OVERWRITTEN instead of
  * accumulated (the caller need not seed them with +-inf); allowed only when n == num_channel * elem_per_channel (channel
  * axis outermost) and elem_per_channel <= 8192, i.e. one wave owns a channel -- refused otherwise.
- * `device_table`: caller-owned device memory of ppqhip_minmax_c_multi_table_bytes(num_jobs) bytes; upload = 1 on the first
- * call and whenever `jobs` changed (see ppqhip_fq_linear_multi). */
+ * The job table travels in the kernel arguments (<= 64 jobs per launch, more are chunked): no host-to-device copy, no host
+ * synchronisation, legal inside a HIP-graph capture -- the tensors of a calibration forward are fresh every call. */
 typedef struct ppqhip_minmax_c_job {
     const float* x;
     float* mins;
@@ -277,8 +278,7 @@ typedef struct ppqhip_minmax_c_job {
     int64_t n, num_channel, elem_per_channel;
     int32_t fresh, reserved;
 } ppqhip_minmax_c_job;
-int64_t ppqhip_minmax_c_multi_table_bytes(int num_jobs);
-int ppqhip_minmax_c_multi(const ppqhip_minmax_c_job* jobs, int num_jobs, void* device_table, int upload, void* stream);
+int ppqhip_minmax_c_multi(const ppqhip_minmax_c_job* jobs, int num_jobs, void* stream);
 
 /* per-channel sums in double, deterministic order: sums[c] += sum of channel c.  The DC term of
  * BiasCorrectionPass.collect_bias (ppq/quantization/optim/training.py:438-448: torch.mean over

@@ -19,7 +19,7 @@ c_int = ctypes.c_int
 c_flt = ctypes.c_float
 c_vp = ctypes.c_void_p
 
-ABI_VERSION = 3              # == PPQHIP_ABI_VERSION of include/ppq_hip.h; a library of any other version is refused below
+ABI_VERSION = 4              # == PPQHIP_ABI_VERSION of include/ppq_hip.h; a library of any other version is refused below
 
 
 class ProfEntry(ctypes.Structure):
@@ -58,8 +58,7 @@ PROTOTYPES = {
     'ppqhip_minmax_workspace_bytes': (c_i64, [c_i64]),
     'ppqhip_minmax_t': (c_int, [c_f32p, c_i64, c_f32p, c_vp, c_vp]),
     'ppqhip_minmax_c': (c_int, [c_f32p, c_i64, c_i64, c_i64, c_f32p, c_f32p, c_vp]),
-    'ppqhip_minmax_c_multi_table_bytes': (c_i64, [c_int]),
-    'ppqhip_minmax_c_multi': (c_int, [c_vp, c_int, c_vp, c_int, c_vp]),
+    'ppqhip_minmax_c_multi': (c_int, [c_vp, c_int, c_vp]),
     'ppqhip_fq_linear_multi_table_bytes': (c_i64, [c_int]),
     'ppqhip_fq_linear_multi': (c_int, [c_vp, c_int, c_int, c_vp, c_int, c_vp]),
     'ppqhip_float_scale_search_table_bytes': (c_i64, [c_int]),

@@ -133,6 +133,57 @@ __device__ __forceinline__ float fq_linear_scalar(float x, float s, int o, int q
     return (float)(q - o) * s;
 }
 
+// ---- round-to-nearest-even quotient without the IEEE division on the common path ------------------------------------
+// The reference divides (`value / scale`, linear.cu:73-74 "never do (1 / s)") and rounds half to even.  rint(RN(x / s)) is
+// reproduced from t = RN(x * rc), rc ~ 1 / s, whenever that is PROVABLY the same integer:
+//   * rc carries a relative error <= 2^-23 (v_rcp_f32: 1 ulp; the exactly rounded 1.0f / s: 2^-24), the product one rounding
+//     (2^-24), the reference's quotient q one rounding (2^-24): |t - q| <= |t| * 2^-22 * (1 + 2^-22);
+//   * rint(t) != rint(q) needs a half-integer h = k + 0.5 with min(t, q) <= h <= max(t, q) (a tie counts: q == h rounds to
+//     even, t may sit on either side), i.e. within |t| * 2^-22 of t.  d = t - rint(t) is exact (|t| < 2^23, Sterbenz), so is
+//     0.5 - |d| (a multiple of ulp(t), at most 0.5): the distance from t to the nearest half-integer.  Lanes with
+//     0.5 - |d| >= |t| * 2^-20 (four times the bound) are safe; the others -- about |t| * 2^-19 of all values, every
+//     |t| >= 2^19, inf, NaN (the comparison is unordered) -- take the true division.
+//   * rc must be a normal number for the error bound to hold: scales outside [2^-100, 2^100] (and <= 0, NaN) hand back
+//     NaN, which sends every lane through the division.
+#ifndef PPQHIP_FQ_RCP
+#define PPQHIP_FQ_RCP 1
+#endif
+__device__ __forceinline__ float fq_safe_rcp(float s) {
+    const float a = __builtin_fabsf(s);
+    return (a >= 0x1p-100f && a <= 0x1p100f) ? __builtin_amdgcn_rcpf(s) : __builtin_nanf("");
+}
+__device__ __forceinline__ bool rne_quotient_is_safe(float t, float r) {       // r = rint(t)
+    return (0.5f - __builtin_fabsf(t - r)) >= __builtin_fabsf(t) * 0x1p-20f;
+}
+
+// four elements of one (scale, offset): QuantizeScalar + DequantizeScalar with ONE divergent region per float4
+template <int R>
+__device__ __forceinline__ float4 fq_linear4(const float4& a, float s, float rc, int o, int qmin, int qmax, int rounding) {
+    float4 out;
+    if constexpr (R == ROUND_HALF_EVEN && PPQHIP_FQ_RCP != 0) {
+        const float t0 = a.x * rc, t1 = a.y * rc, t2 = a.z * rc, t3 = a.w * rc;
+        float r0 = __builtin_rintf(t0), r1 = __builtin_rintf(t1), r2 = __builtin_rintf(t2), r3 = __builtin_rintf(t3);
+        const bool u0 = !rne_quotient_is_safe(t0, r0), u1 = !rne_quotient_is_safe(t1, r1);
+        const bool u2 = !rne_quotient_is_safe(t2, r2), u3 = !rne_quotient_is_safe(t3, r3);
+        if (u0 | u1 | u2 | u3) {                 // rare: next to a rounding tie (or a special value): the reference's own arithmetic
+            if (u0) r0 = __builtin_rintf(a.x / s);
+            if (u1) r1 = __builtin_rintf(a.y / s);
+            if (u2) r2 = __builtin_rintf(a.z / s);
+            if (u3) r3 = __builtin_rintf(a.w / s);
+        }
+        out.x = (float)(clampi(add_sat(f2i_sat(r0), o), qmin, qmax) - o) * s;
+        out.y = (float)(clampi(add_sat(f2i_sat(r1), o), qmin, qmax) - o) * s;
+        out.z = (float)(clampi(add_sat(f2i_sat(r2), o), qmin, qmax) - o) * s;
+        out.w = (float)(clampi(add_sat(f2i_sat(r3), o), qmin, qmax) - o) * s;
+    } else {
+        out.x = fq_linear_scalar<R>(a.x, s, o, qmin, qmax, rounding);
+        out.y = fq_linear_scalar<R>(a.y, s, o, qmin, qmax, rounding);
+        out.z = fq_linear_scalar<R>(a.z, s, o, qmin, qmax, rounding);
+        out.w = fq_linear_scalar<R>(a.w, s, o, qmin, qmax, rounding);
+    }
+    return out;
+}
+
 // wave64 reductions through DPP-backed shuffles
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll

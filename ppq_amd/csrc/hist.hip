@@ -27,6 +27,8 @@
 //     caller's persistent [rows][bins] accumulator (plain stream-ordered read-modify-write), folded
 //     once at render; the one-shot entry points store rows to scratch + one reduce launch, or use
 //     device atomics when only a handful of workgroups run (small tensors: one launch).
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace ppqhip {
@@ -224,8 +226,16 @@ void hist_persistent_kernel(const HistJobs jobs) {
     uint32_t t = (uint32_t)(((uint64_t)g * jobs.total_tiles) / G);
     const uint32_t t_end = (uint32_t)(((uint64_t)(g + 1) * jobs.total_tiles) / G);
     const int bins = jobs.bins, copies = jobs.copies;
-    for (int i = threadIdx.x; i < copies * bins; i += kHistBlock) lds[i] = 0;
-    __syncthreads();
+    // The LDS copies are zeroed AFTER the first tile's loads have been issued (their latency covers the stores and the
+    // barrier; on a 6 MB tensor the kernel is a single latency chain, nothing else hides them).  The barrier is the bare
+    // s_barrier behind an LDS-only wait: __syncthreads() would also drain vmcnt, i.e. wait for the loads just issued.
+    bool zeroed = false;
+    auto zero_lds = [&]() {
+        if (zeroed) return;
+        for (int i = threadIdx.x; i < copies * bins; i += kHistBlock) lds[i] = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        zeroed = true;
+    };
     if (t >= t_end) {                       // more workgroups than tiles: nothing to bin
         if (jobs.mode == FLUSH_ROWS_STORE) for (int b = threadIdx.x; b < bins; b += kHistBlock) jobs.job[0].rows[(size_t)g * bins + b] = 0;
         return;
@@ -274,6 +284,7 @@ void hist_persistent_kernel(const HistJobs jobs) {
             // ping-pong between two register tiles; the prefetch index is clamped (wave uniform), so the
             // loads stay unconditional straight-line code: the last tile of the range is fetched twice.
             fetch(bufa, k);
+            zero_lds();
             for (;;) {
                 fetch(bufb, min(k + 1, kf - 1));
                 consume(bufa, k);
@@ -283,6 +294,7 @@ void hist_persistent_kernel(const HistJobs jobs) {
                 if (++k >= kf) break;
             }
         }
+        zero_lds();
         for (; k < k1; k++) {             // ragged tail tile (or a tensor that is not 16-B aligned): masked 4-B loads
             const uint32_t e0 = k * kTileElems + threadIdx.x;
 #pragma unroll 4
@@ -299,6 +311,85 @@ void hist_persistent_kernel(const HistJobs jobs) {
         acc.hot_bin = -1;
         int* dst = jobs.mode == FLUSH_ATOMIC ? job.rows : job.rows + (size_t)g * bins;
         lds_hist_flush(lds, bins, copies, dst, jobs.mode);
+    }
+}
+
+// ---- the single-tensor kernel for LATENCY-BOUND sizes (one launch on a few MB: B = [1,512,56,56] is 6.4 MB) ------------------
+// On such a tensor a launch is one dependent chain -- dispatch, kernel-argument fetch, first-byte latency, binning, flush -- and the
+// persistent kernel above spends ~2 us of it on its own generality: its 3 KB job table is fetched in two DEPENDENT scalar-load
+// rounds (launch header, then the job the workgroup landed in), its tiles ping-pong two at a time, the LDS copies are zeroed before
+// the first load is issued.  This kernel takes ONE tensor with its few arguments by value (one scalar-load round), issues up to
+// kSmallK 16-B loads per lane before anything else, zeroes the LDS copy while they fly and bins them in arrival order with the same
+// Binner.  Counts are the same integers whatever the traversal.  Flush: device atomics either into the caller's histogram (few
+// workgroups: every workgroup touches every 64-B line of the histogram once and the memory-side atomic unit serialises the
+// operations on a line, ~15 ns each -- tools/floor_table.py, `floor_atomic`) or into the workgroup's OWN row of a persistent
+// accumulator (no contention at all, so the grid can cover every CU; atomics instead of a load-add-store keep the row's
+// read latency out of the chain).
+#ifndef PPQHIP_HIST_SMALL_K
+#define PPQHIP_HIST_SMALL_K 8
+#endif
+constexpr int kSmallK = PPQHIP_HIST_SMALL_K;
+template <bool ASYM, bool CLIP>
+__global__ __launch_bounds__(kHistBlock) void hist_small_kernel(const float* __restrict__ x, uint32_t n, float a, float hs, int bins,
+                                                                 int copies, int* __restrict__ dst, int own_row) {
+    extern __shared__ int lds[];
+    const uint32_t G = gridDim.x, g = blockIdx.x;
+    const uint32_t nvec = n >> 2;
+    const uint32_t full_rows = nvec / kHistBlock;                     // rows of kHistBlock float4 in which every lane has one
+    const uint32_t r0 = (uint32_t)(((uint64_t)g * full_rows) / G), r1 = (uint32_t)(((uint64_t)(g + 1) * full_rows) / G);
+    const float4* xv = reinterpret_cast<const float4*>(x) + threadIdx.x;
+    Binner<ASYM, CLIP, true> acc;
+    acc.init(lds + ((threadIdx.x >> 6) % copies) * bins, bins);
+    acc.set_rule(a, hs);
+    bool zeroed = false;
+    auto zero_lds = [&]() {
+        if (zeroed) return;
+        for (int i = threadIdx.x; i < copies * bins; i += kHistBlock) lds[i] = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS only: the loads stay in flight
+        zeroed = true;
+    };
+    for (uint32_t r = r0; r < r1; r += kSmallK) {
+        float4 buf[kSmallK];
+        const uint32_t cnt = min((uint32_t)kSmallK, r1 - r);          // workgroup uniform
+#pragma unroll
+        for (int k = 0; k < kSmallK; k++)
+            if ((uint32_t)k < cnt) buf[k] = xv[(size_t)(r + k) * kHistBlock];
+        zero_lds();
+#pragma unroll
+        for (int k = 0; k < kSmallK; k++) {
+            if ((uint32_t)k < cnt) {
+                int b[4];
+                acc.bins4(buf[k], b);
+                if ((k & 1) == 0) acc.elect(b[0], true);
+                if (CLIP) acc.commit4_exec(b);
+                else {
+                    acc.template commit<true>(b[0], true); acc.template commit<true>(b[1], true);
+                    acc.template commit<true>(b[2], true); acc.template commit<true>(b[3], true);
+                }
+            }
+        }
+    }
+    zero_lds();
+    if (g == G - 1) {                                                  // the ragged rest: < kHistBlock float4 + n % 4 elements, masked 4-B loads
+        const uint32_t e0 = full_rows * kHistBlock * 4;
+        const uint32_t trips = (n - e0 + kHistBlock - 1) / kHistBlock;
+        for (uint32_t t = 0; t < trips; t++) {
+            const uint32_t i = e0 + t * kHistBlock + threadIdx.x;
+            const bool in = i < n;
+            const float v = in ? x[i] : 0.f;
+            const int b = acc.bin1(v);
+            if ((t & 3) == 0) acc.elect(b, in);
+            acc.template commit<false>(b, in);
+        }
+    }
+    acc.flush_hot();
+    int* row = own_row ? dst + (size_t)g * bins : dst;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int b = threadIdx.x; b < bins; b += kHistBlock) {
+        int sum = 0;
+        for (int c = 0; c < copies; c++) sum += lds[c * bins + b];
+        if (sum) atomicAdd(&row[b], sum);
     }
 }
 
@@ -501,16 +592,68 @@ static void launch_persistent(const HistJobs& args, int grid, int asym, int clip
 static int persistent_grid(uint32_t tiles) {
     uint32_t g = tiles / PPQHIP_HIST_MIN_TILES;
     if (g > PPQHIP_HIST_ATOMIC_MAX_WG) g = tiles / (2 * PPQHIP_HIST_MIN_TILES);
+#ifdef PPQHIP_DEV_KNOBS                       // measurement builds only (tools/floor_table.py sweeps the grid of the one-shot launch)
+    if (const char* e = getenv("PPQHIP_DEV_HIST_WG")) { const int v = atoi(e); if (v > 0) g = (uint32_t)v; }
+#endif
     if (g < 1) g = 1;
     const uint32_t cap = (uint32_t)(num_cu() * kHistWgPerCu);      // <= kHistRows: a partitioned device runs a smaller grid
     if (g > cap) g = cap;
     return (int)g;
 }
 
+static bool dev_force_atomic() {
+#ifdef PPQHIP_DEV_KNOBS
+    if (const char* e = getenv("PPQHIP_DEV_HIST_ATOMIC")) return atoi(e) != 0;
+#endif
+    return false;
+}
+
 // one-shot histogram of one tensor, accumulated into hist[bins] (rows == nullptr) or into the caller's
 // persistent rows[kHistRows][bins]
+#ifndef PPQHIP_HIST_SMALL_ELEMS
+#define PPQHIP_HIST_SMALL_ELEMS (4ll << 20)     // single tensors up to 16 MB take hist_small_kernel
+#endif
+#ifndef PPQHIP_HIST_SMALL_WG_ATOMIC
+#define PPQHIP_HIST_SMALL_WG_ATOMIC 112         // one-shot (shared histogram): workgroups at most
+#endif
+static int dev_knob(const char* name, int fallback) {
+#ifdef PPQHIP_DEV_KNOBS
+    if (const char* e = getenv(name)) return atoi(e);
+#endif
+    (void)name;
+    return fallback;
+}
+
+static bool launch_hist_small(const float* x, int64_t n, BinRule rule, int32_t* hist, hipStream_t s, int32_t* rows) {
+    if (!dev_knob("PPQHIP_DEV_HIST_SMALL", 1) || n > PPQHIP_HIST_SMALL_ELEMS || !aligned16(x)) return false;
+    const uint32_t full_rows = (uint32_t)((n >> 2) / kHistBlock);
+    uint32_t g;
+    if (rows) g = (full_rows + 1) / 2;                                   // own rows: no contention, two loads per lane
+    else g = full_rows / 4;                                              // shared histogram: every workgroup touches every line
+    const uint32_t cap = rows ? (uint32_t)(num_cu() * kHistWgPerCu) : (uint32_t)PPQHIP_HIST_SMALL_WG_ATOMIC;
+    if (g > cap) g = cap;
+    g = (uint32_t)dev_knob("PPQHIP_DEV_HIST_WG", (int)g);
+    if (g > (uint32_t)kHistRows) g = kHistRows;
+    if (g < 1) g = 1;
+    const int copies = pick_copies(rule.bins, kHistBlock);
+    int* dst = rows ? rows : hist;
+    const int own = rows ? 1 : 0;
+#define PPQ_LAUNCH_HIST_SMALL(A, C)                                                                                   \
+    hipLaunchKernelGGL((hist_small_kernel<A, C>), dim3(g), dim3(kHistBlock), lds_bytes(rule.bins, copies), s, x,     \
+                       (uint32_t)n, rule.a, rule.hs, rule.bins, copies, dst, own)
+    switch ((rule.asym ? 2 : 0) | (rule.clip ? 1 : 0)) {
+        case 0: PPQ_LAUNCH_HIST_SMALL(false, false); break;
+        case 1: PPQ_LAUNCH_HIST_SMALL(false, true); break;
+        case 2: PPQ_LAUNCH_HIST_SMALL(true, false); break;
+        default: PPQ_LAUNCH_HIST_SMALL(true, true); break;
+    }
+#undef PPQ_LAUNCH_HIST_SMALL
+    return true;
+}
+
 static int launch_hist_one(const float* x, int64_t n, BinRule rule, int32_t* hist, void* workspace, hipStream_t s,
                            int32_t* rows) {
+    if (launch_hist_small(x, n, rule, hist, s, rows)) return PPQHIP_OK;
     HistJobs args;
     args.count = 1; args.bins = rule.bins; args.copies = pick_copies(rule.bins, kHistBlock);
     HistJob& d = args.job[0];
@@ -519,7 +662,7 @@ static int launch_hist_one(const float* x, int64_t n, BinRule rule, int32_t* his
     const int grid = persistent_grid(args.total_tiles);
     int* partial = nullptr;
     if (rows) { args.mode = FLUSH_ROWS_ADD; d.rows = rows; }
-    else if (grid <= PPQHIP_HIST_ATOMIC_MAX_WG) { args.mode = FLUSH_ATOMIC; d.rows = hist; }
+    else if (grid <= PPQHIP_HIST_ATOMIC_MAX_WG || dev_force_atomic()) { args.mode = FLUSH_ATOMIC; d.rows = hist; }
     else {
         partial = workspace ? (int*)workspace : (int*)scratch(s, sizeof(int) * (size_t)grid * rule.bins);
         if (partial == nullptr) return PPQHIP_ERR_HIP;

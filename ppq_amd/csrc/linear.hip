@@ -30,23 +30,17 @@ __global__ __launch_bounds__(kBlock) void fq_linear_t_tile_kernel(
     const float4* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
     float4* __restrict__ out, uint32_t nvec, const float* __restrict__ xtail, float* __restrict__ otail,
     int ntail, int qmin, int qmax, int rounding) {
-    const float s = scale[0];
-    const int o = round_offset(offset[0]);
     const uint32_t base = blockIdx.x * (kBlock * U) + threadIdx.x;
     float4 a[U];
 #pragma unroll
     for (int k = 0; k < U; k++)
         a[k] = load4<NT>(&x[min(base + k * kBlock, nvec - 1)]);   // branch-free (clamped) so all U loads issue back to back
+    const float s = scale[0];
+    const int o = round_offset(offset[0]);
+    const float rc = fq_safe_rcp(s);
 #pragma unroll
     for (int k = 0; k < U; k++) {
-        if (base + k * kBlock < nvec) {
-            float4 r;
-            r.x = fq_linear_scalar<R>(a[k].x, s, o, qmin, qmax, rounding);
-            r.y = fq_linear_scalar<R>(a[k].y, s, o, qmin, qmax, rounding);
-            r.z = fq_linear_scalar<R>(a[k].z, s, o, qmin, qmax, rounding);
-            r.w = fq_linear_scalar<R>(a[k].w, s, o, qmin, qmax, rounding);
-            out[base + k * kBlock] = r;
-        }
+        if (base + k * kBlock < nvec) out[base + k * kBlock] = fq_linear4<R>(a[k], s, rc, o, qmin, qmax, rounding);
     }
     if (blockIdx.x == 0 && (int)threadIdx.x < ntail)
         otail[threadIdx.x] = fq_linear_scalar<R>(xtail[threadIdx.x], s, o, qmin, qmax, rounding);
@@ -75,14 +69,7 @@ __global__ __launch_bounds__(kBlock) void fq_linear_c_tile_kernel(
 #pragma unroll
     for (int k = 0; k < U; k++) {
         const uint32_t vv = base + k * kBlock;
-        if (vv < nvec) {
-            float4 r;
-            r.x = fq_linear_scalar<R>(a[k].x, s[k], o[k], qmin, qmax, rounding);
-            r.y = fq_linear_scalar<R>(a[k].y, s[k], o[k], qmin, qmax, rounding);
-            r.z = fq_linear_scalar<R>(a[k].z, s[k], o[k], qmin, qmax, rounding);
-            r.w = fq_linear_scalar<R>(a[k].w, s[k], o[k], qmin, qmax, rounding);
-            out[vv] = r;
-        }
+        if (vv < nvec) out[vv] = fq_linear4<R>(a[k], s[k], fq_safe_rcp(s[k]), o[k], qmin, qmax, rounding);
     }
 }
 
@@ -461,7 +448,10 @@ static int validate_channels(int64_t n, int64_t C, int64_t epc, const char* what
 // Tensors of at least kStreamElems elements (192 MiB) cannot be resident in the 256 MiB Infinity
 // Cache together with their output: read them with streaming (nontemporal) loads.
 constexpr int64_t kStreamElems = 48ll << 20;
-constexpr int kTileU = 2;
+#ifndef PPQHIP_FQ_U
+#define PPQHIP_FQ_U 2
+#endif
+constexpr int kTileU = PPQHIP_FQ_U;
 
 template <int R>
 static void launch_lt(const float* x, const float* scale, const float* offset, float* out, int64_t n,
@@ -560,14 +550,7 @@ __global__ __launch_bounds__(kBlock) void fq_linear_multi_kernel(const FqMultiAr
 #pragma unroll
         for (int k = 0; k < U; k++) {
             const uint32_t vv = base + k * kBlock;
-            if (vv < nvec) {
-                float4 r;
-                r.x = fq_linear_scalar<R>(a[k].x, s[k], o[k], j.qmin, j.qmax, args.rounding);
-                r.y = fq_linear_scalar<R>(a[k].y, s[k], o[k], j.qmin, j.qmax, args.rounding);
-                r.z = fq_linear_scalar<R>(a[k].z, s[k], o[k], j.qmin, j.qmax, args.rounding);
-                r.w = fq_linear_scalar<R>(a[k].w, s[k], o[k], j.qmin, j.qmax, args.rounding);
-                ov[vv] = r;
-            }
+            if (vv < nvec) ov[vv] = fq_linear4<R>(a[k], s[k], fq_safe_rcp(s[k]), o[k], j.qmin, j.qmax, args.rounding);
         }
     } else {
 #pragma unroll

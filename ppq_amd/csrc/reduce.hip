@@ -397,14 +397,16 @@ static int validate(int64_t n, const char* what) {
 // ---- per-channel min / max of MANY tensors, one launch ----------------------------------------------
 // ParameterQuantizePass (optim/parameters.py:156-215) observes every weight of the graph once: 54 tensors of 0.01 .. 9 MB
 // for ResNet-50, each a ~7 us launch in the per-tensor path (profiles/r03_bench_kernel_stats.csv: 270 minmax_c launches).
-// One launch here: the job table is device resident (weights do not move), the kernel arguments carry the prefix of work
-// items, ONE WAVE per item as in minmax_c_wave_kernel: item -> (job, row, chunk of <= 8192 elements of that row).
+// One launch here: the job table travels BY VALUE in the kernel arguments (64 jobs x 52 B = 3.3 KB of the 4 KB limit, like
+// HistJobs / LsqMultiArgs): no host-to-device copy, so the launch is legal inside a HIP-graph capture and does not synchronise
+// the host (round 4 uploaded a pageable table per call -- ADVICE r4).  ONE WAVE per item as in minmax_c_wave_kernel:
+// item -> (job, row, chunk of <= 8192 elements of that row).
 // A job whose channels each consist of exactly one item (outer == 1, one chunk: every convolution / Gemm weight with
 // channel axis 0) may be marked `fresh`: its wave STORES min / max, so the caller need not seed the buffers with +-inf
 // (three tiny launches per weight otherwise); all other jobs fold into seeded buffers with the float atomics.
 // min / max are order independent: results are bit-identical to ppqhip_minmax_c whatever the geometry.
-constexpr int kMMCMultiMax = 128;
-struct MMCJob {
+constexpr int kMMCMultiMax = 64;
+struct MMCJob {                              // 48 B
     const float* x;
     float* mins;
     float* maxs;
@@ -412,11 +414,12 @@ struct MMCJob {
     uint32_t vec_ok, fresh;
 };
 struct MMCMultiArgs {
+    MMCJob jobs[kMMCMultiMax];
     uint32_t first_item[kMMCMultiMax];
     uint32_t count;
     uint32_t items;
-    const MMCJob* jobs;
 };
+static_assert(sizeof(MMCMultiArgs) <= 4096, "kernel arguments are limited to 4 KB");
 
 __global__ __launch_bounds__(kBlock) void minmax_c_multi_kernel(const MMCMultiArgs args) {
     const uint32_t item = blockIdx.x * (kBlock / kWave) + (threadIdx.x >> 6);
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(kBlock) void minmax_c_multi_kernel(const MMCMultiAr
         const uint32_t mid = (lo + hi) >> 1;
         if (args.first_item[mid] <= item) lo = mid; else hi = mid;
     }
-    const MMCJob j = args.jobs[__builtin_amdgcn_readfirstlane(lo)];   // wave-uniform address: scalar loads
+    const MMCJob& j = args.jobs[__builtin_amdgcn_readfirstlane(lo)];  // wave-uniform index into the kernel arguments: scalar loads
     const uint32_t local = item - args.first_item[lo];
     const uint32_t row = local / j.chunks, chunk = local - row * j.chunks;
     const uint32_t c = row % j.C;
@@ -637,15 +640,9 @@ int ppqhip_isotone_t(const float* x, int64_t n, float* dest, void* workspace, vo
     return finish_launch("isotone_t");
 }
 
-int64_t ppqhip_minmax_c_multi_table_bytes(int num_jobs) {
-    return num_jobs > 0 ? (int64_t)sizeof(MMCJob) * num_jobs : 0;
-}
-
-int ppqhip_minmax_c_multi(const ppqhip_minmax_c_job* jobs, int num_jobs, void* device_table, int upload, void* stream) {
+int ppqhip_minmax_c_multi(const ppqhip_minmax_c_job* jobs, int num_jobs, void* stream) {
     if (num_jobs <= 0) return PPQHIP_OK;
-    if (jobs == nullptr || device_table == nullptr) {
-        set_error("minmax_c_multi: jobs / device_table is null"); return PPQHIP_ERR_INVALID_VALUE;
-    }
+    if (jobs == nullptr) { set_error("minmax_c_multi: jobs is null"); return PPQHIP_ERR_INVALID_VALUE; }
     hipStream_t s = (hipStream_t)stream;
     double bytes = 0.0;
     for (int k = 0; k < num_jobs; k++) {
@@ -664,39 +661,33 @@ int ppqhip_minmax_c_multi(const ppqhip_minmax_c_job* jobs, int num_jobs, void* d
         bytes += 4.0 * (double)j.n;
     }
     LaunchScope scope(K_MINMAX_C, bytes, s);
-    for (int base = 0; base < num_jobs; base += kMMCMultiMax) {
-        const int count = (num_jobs - base) < kMMCMultiMax ? (num_jobs - base) : kMMCMultiMax;
+    for (int base = 0; base < num_jobs; ) {
         MMCMultiArgs args;
-        args.count = (uint32_t)count;
-        args.jobs = (const MMCJob*)device_table + base;
-        std::vector<MMCJob> table(upload ? count : 0);
         uint64_t items = 0;
-        for (int k = 0; k < count; k++) {
-            const ppqhip_minmax_c_job& src = jobs[base + k];
+        int count = 0;
+        for (; count < kMMCMultiMax && base + count < num_jobs; count++) {
+            const ppqhip_minmax_c_job& src = jobs[base + count];
             const uint32_t chunks = (uint32_t)((src.elem_per_channel + kMMCChunk - 1) / kMMCChunk);
             const uint64_t rows = (uint64_t)(src.n / src.elem_per_channel);
-            args.first_item[k] = (uint32_t)items;
-            items += rows * chunks;
-            if (items > 0x7fffffffULL) { set_error("minmax_c_multi: too many work items in one call"); return PPQHIP_ERR_INVALID_VALUE; }
-            if (upload) {
-                MMCJob& d = table[k];
-                d.x = src.x; d.mins = src.mins; d.maxs = src.maxs;
-                d.C = (uint32_t)src.num_channel; d.epc = (uint32_t)src.elem_per_channel;
-                d.outer = (uint32_t)(rows / (uint64_t)src.num_channel); d.chunks = chunks;
-                d.vec_ok = (aligned16(src.x) && src.elem_per_channel % 4 == 0) ? 1u : 0u;
-                d.fresh = src.fresh ? 1u : 0u;
+            if (items + rows * chunks > 0x7fffffffULL) {
+                if (count == 0) { set_error("minmax_c_multi: too many work items in one job"); return PPQHIP_ERR_INVALID_VALUE; }
+                break;                                                  // the rest goes into the next launch
             }
+            args.first_item[count] = (uint32_t)items;
+            items += rows * chunks;
+            MMCJob& d = args.jobs[count];
+            d.x = src.x; d.mins = src.mins; d.maxs = src.maxs;
+            d.C = (uint32_t)src.num_channel; d.epc = (uint32_t)src.elem_per_channel;
+            d.outer = (uint32_t)(rows / (uint64_t)src.num_channel); d.chunks = chunks;
+            d.vec_ok = (aligned16(src.x) && src.elem_per_channel % 4 == 0) ? 1u : 0u;
+            d.fresh = src.fresh ? 1u : 0u;
         }
-        for (int k = count; k < kMMCMultiMax; k++) args.first_item[k] = (uint32_t)items;
+        for (int k = count; k < kMMCMultiMax; k++) { args.first_item[k] = (uint32_t)items; args.jobs[k] = args.jobs[0]; }
+        args.count = (uint32_t)count;
         args.items = (uint32_t)items;
-        if (upload) {
-            // pageable source: the runtime stages the copy before returning, `table` may go out of scope
-            if (int st = check_hip(hipMemcpyAsync((MMCJob*)device_table + base, table.data(), sizeof(MMCJob) * count,
-                                                  hipMemcpyHostToDevice, s), "minmax_c_multi table upload"))
-                return st;
-        }
         const uint32_t blocks = (uint32_t)((items + kBlock / kWave - 1) / (kBlock / kWave));
         hipLaunchKernelGGL(minmax_c_multi_kernel, dim3(blocks), dim3(kBlock), 0, s, args);
+        base += count;
     }
     return finish_launch("minmax_c_multi");
 }

@@ -780,15 +780,15 @@ class _HipExtension:
             _raise(lib.ppqhip_minmax_c(v.data_ptr(), v.numel(), C, epc, mins.data_ptr(), maxs.data_ptr(), _stream()))
 
     @ staticmethod
-    def MinMax_C_Multi(values, channel_axes, mins, maxs, fresh: bool = False, table=None):
+    def MinMax_C_Multi(values, channel_axes, mins, maxs, fresh: bool = False):
         """``MinMax_C`` for MANY tensors in ONE launch (``ppqhip_minmax_c_multi``): every weight ParameterQuantizePass observes.
         ``mins[k]`` / ``maxs[k]``: contiguous float32[C_k]; accumulated into (seed with +-inf) unless ``fresh``: then they are
         OVERWRITTEN, allowed for tensors whose channel axis is the outermost one with at most 8192 elements per channel
         (one wave per channel; ``minmax_c_fresh_ok``).  ``fresh`` may be a list with one flag per item; as a single True it
         applies to the items that qualify, the others must have been seeded by the caller and are accumulated.
-        ``table``: an optional uint8 device tensor to reuse as the job table (returned)."""
+        The job table travels in the kernel arguments: nothing is uploaded, the launch can be captured into a HIP graph."""
         n = len(values)
-        if n == 0: return table
+        if n == 0: return
         if not (len(channel_axes) == len(mins) == len(maxs) == n):
             raise RuntimeError(_KERNEL_FAILURE + 'MinMax_C_Multi: argument lists differ in length')
         dev = values[0].device
@@ -808,12 +808,15 @@ class _HipExtension:
                 owns = False
             keep.append(v)
             jobs[k] = (v.data_ptr(), mins[k].data_ptr(), maxs[k].data_ptr(), v.numel(), C, epc, 1 if owns else 0, 0)
-        need = int(lib.ppqhip_minmax_c_multi_table_bytes(n))
-        if table is None or table.numel() < need or table.device != dev:
-            table = torch.empty(need, dtype=torch.uint8, device=dev)
         with _DeviceOf(values[0]):
-            _raise(lib.ppqhip_minmax_c_multi(jobs.ctypes.data, n, table.data_ptr(), 1, _stream()))
-        return table
+            _raise(lib.ppqhip_minmax_c_multi(jobs.ctypes.data, n, _stream()))
+
+    @ staticmethod
+    def minmax_c_outer_is_one(value, channel_axis: int) -> bool:
+        """True for parameter-shaped tensors: the channel axis is the outermost one that is not 1 (one row per channel)."""
+        v = _dense(value, channel_axis)
+        C, epc = _geometry(v.shape, channel_axis)
+        return v.numel() == C * epc
 
     @ staticmethod
     def minmax_c_fresh_ok(value, channel_axis: int) -> bool:
@@ -1160,12 +1163,16 @@ class CUDA:
         return mins, maxs
 
     @ staticmethod
-    def MinMax_C_Multi(tensors, channel_axes, mins, maxs, fresh: bool = False, table=None):
-        return HIP_EXTENSION.MinMax_C_Multi(tensors, channel_axes, mins, maxs, fresh, table)
+    def MinMax_C_Multi(tensors, channel_axes, mins, maxs, fresh: bool = False):
+        return HIP_EXTENSION.MinMax_C_Multi(tensors, channel_axes, mins, maxs, fresh)
 
     @ staticmethod
     def minmax_c_fresh_ok(tensor, channel_axis: int) -> bool:
         return HIP_EXTENSION.minmax_c_fresh_ok(tensor, channel_axis)
+
+    @ staticmethod
+    def minmax_c_outer_is_one(tensor, channel_axis: int) -> bool:
+        return HIP_EXTENSION.minmax_c_outer_is_one(tensor, channel_axis)
 
     @ staticmethod
     def ChannelSum(tensor, channel_axis: int, sums):

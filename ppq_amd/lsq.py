@@ -15,10 +15,10 @@ from torch.autograd import Function
 
 from .core import QuantizationProperty as P
 from .core import QuantizationStates, rounding_value, state_value
-from .blocks import COMPUTING_OP, block_forward
+from .blocks import COMPUTING_OP, block_forward, torch_mean_square_error
 from .calibration import QuantizationOptimizationPass
 from .ffi import CUDA
-from .qfunction import PPQuantFunction, _as_1d
+from .qfunction import PPQLinearQuantFunction, PPQuantFunction, _as_1d
 
 
 class CuLSQ_LT(Function):
@@ -238,8 +238,17 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
         # MI355X-side execution choices (no twin in the reference; the values trained are the per-tensor path's up to float
         # summation order): all weight delegators of a block in ONE forward + ONE backward launch (LSQWeightGroup), and the
         # optimizer step of a block captured ONCE as a HIP graph and replayed for its remaining steps (single process only)
+        # use_hip_graph: on that path the default optimizer is Adam(capturable=True) -- its step count and bias corrections are
+        # float32 DEVICE tensors instead of Python doubles, and it stays that optimizer for the eager steps of a block whose
+        # capture failed -- so the trained values differ from the eager / reference `torch.optim.Adam` run by more than float
+        # summation order: per step the bias-corrected step size differs in the last float32 bits (~1e-7 relative), and the
+        # scale gradients here are ~1e-8 (the order of Adam's eps), so after a few steps individual scales may sit one
+        # lr-sized step apart (test_hip_graph_replay_of_the_block_step_equals_eager_steps states the tolerance).  use_hip_graph=False is the
+        # reference's optimizer bit for bit.
         self.group_weights = group_weights
         self.use_hip_graph = use_hip_graph
+        self._graph_broken = False              # a capture failed in THIS pass: its later blocks stay eager (reason: graph_error)
+        self.graph_error = None
         self.capture_error_mode = 'global'
         self.incremental_inputs = True          # quantised block inputs from blocks.PrefixCache instead of a full forward per block
         self.profile_phases = False             # True: synchronise around the phases and fill phase_ms (a measuring aid)
@@ -326,9 +335,6 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
             if any({k: (tuple(v.shape), v.dtype) for k, v in d.items()} != first for d in dicts[1:]): return False
         return True
 
-    _graph_broken = False      # a capture failed in this process: later blocks / passes stay eager (reason: graph_error)
-    graph_error = None
-
     def _train_with_graph(self, train_step, qt_inputs, fp_outputs) -> int:
         """Step 0 eagerly on a side stream, ONE capture of the same step on that stream, replays for the rest; returns the
         number of steps done (0 or 1 when the capture failed: the caller finishes eagerly and later blocks do not retry)."""
@@ -370,8 +376,8 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
                     error = error or e
         if error is not None:                           # a call that cannot be captured: finish eagerly, stop trying
             import traceback
-            LearnedStepSizePass._graph_broken = True
-            LearnedStepSizePass.graph_error = self.stats['graph_error'] = \
+            self._graph_broken = True
+            self.graph_error = self.stats['graph_error'] = \
                 f'{type(error).__name__}: {str(error)[:600]} @ ' + ' <- '.join(
                     f'{f.name}:{f.lineno}' for f in reversed(traceback.extract_tb(error.__traceback__)[-6:]))
             self.stats['graph_failures'] += 1
@@ -435,7 +441,8 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
                     for op in block.rps:                                  # training.py:793-798 (the STE gradient passes)
                         if hasattr(op, 'config') and op.type in COMPUTING_OP:
                             w, wc = op.inputs[1].value, op.config.input_quantization_config[1]
-                            loss = loss + self._loss(w, PPQuantFunction(w, wc)) * self.gamma
+                            # always the reference's own MSE over PPQLinearQuantFunction, whatever `loss_fn` is
+                            loss = loss + torch_mean_square_error(w, PPQLinearQuantFunction(w, wc)) * self.gamma
             loss.backward()
             for g in groups: g.flush()
             with torch.no_grad():

@@ -146,7 +146,6 @@ class ObservationQueue:
     def __init__(self, max_pending_bytes: int = 4 << 30):
         self._minmax = []                  # (tensor, slots)
         self._minmax_c = []                # (tensor, channel_axis, mins, maxs, fresh)
-        self._c_tables = {}                # device -> job-table buffer of the per-channel launch, reused
         self._hist = {}                    # (asymmetric, bins, device) -> [(tensor, rows, p0, p1)]
         self._quantile = {}                # (q, device) -> [(tensor, dest)]
         self._bytes = 0
@@ -214,8 +213,8 @@ class ObservationQueue:
             for it in self._minmax_c: by_dev.setdefault(it[0].device, []).append(it)
             self._minmax_c = []
             for dev, items in by_dev.items():
-                self._c_tables[dev] = CUDA.MinMax_C_Multi([i[0] for i in items], [i[1] for i in items], [i[2] for i in items],
-                                                          [i[3] for i in items], [i[4] for i in items], self._c_tables.get(dev))
+                CUDA.MinMax_C_Multi([i[0] for i in items], [i[1] for i in items], [i[2] for i in items],
+                                    [i[3] for i in items], [i[4] for i in items])
                 self.launches += 1
         if self._hist:
             pending, self._hist = self._hist, {}
@@ -317,10 +316,10 @@ class TorchMinMaxObserver(BaseTensorObserver):
             else: CUDA.MinMax_T_Slots(value, self._slots)    # no per-batch reduction kernel
             self._slots_dirty = True
         elif cfg.policy.has_property(P.PER_CHANNEL):
-            # weights (and other small tensors) join the forward's ONE multi-tensor launch; a big activation keeps its own
-            # launch (the single-tensor kernel groups several short rows per wave, the multi kernel does not)
-            queued = (self.queue is not None and value.is_cuda
-                      and (value.numel() <= (1 << 22) or CUDA.minmax_c_fresh_ok(value, cfg.channel_axis)))
+            # parameter-shaped tensors (channel axis outermost: one row per channel) join the forward's ONE multi-tensor
+            # launch; an activation [N, C, ...] keeps its own launch -- the single-tensor kernel groups several short rows
+            # of a channel per wave, the multi kernel takes one wave per row
+            queued = (self.queue is not None and value.is_cuda and CUDA.minmax_c_outer_is_one(value, cfg.channel_axis))
             fresh = False
             if self._range is None:
                 C = value.shape[cfg.channel_axis]

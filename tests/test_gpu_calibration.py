@@ -387,6 +387,49 @@ def test_graph_and_async_modes_equal_eager(mode):
     assert (p.graph_replays == 14) == ('graph' in mode)                   # 7 replays per phase
 
 
+@pytest.mark.parametrize('batch', [1, 4])
+def test_per_channel_activation_observers_under_hip_graph_capture(batch):
+    """(batch 1: every activation is "one row per channel" and is queued into the multi-tensor launch; batch 4: direct launches.)
+    ADVICE r4: per-channel min-max observers ride the multi-tensor launch (`ppqhip_minmax_c_multi`), whose job table now travels
+    in the kernel arguments -- so the launch is legal inside a captured calibration forward.  Per-channel ACTIVATION configs
+    (channel axis 1) + per-channel weights, `use_hip_graph=True`: the pass must really replay (no fallback) and leave the scales
+    of the eager loop, bit for bit (min / max are order independent)."""
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    from ppq_amd.core import QuantizationPolicy, QuantizationProperty as QP
+    g = torch.Generator().manual_seed(21)
+    batches = [torch.rand(batch, 3, 24, 24, generator=g).to(DEV) * (1 + 0.1 * i) for i in range(8)]
+
+    def run(**kw):
+        graph = harness.small_cnn_graph(seed=3)
+        harness.quantize_graph(graph, 'minmax')
+        touched = 0
+        for op in graph.operations.values():
+            for c, v in op.config_with_variable:
+                if v.is_parameter or c.dominated_by is not c or c.state.value != 1: continue          # INITIAL activation roots only
+                c.policy = QuantizationPolicy(QP.LINEAR.value + QP.SYMMETRICAL.value + QP.PER_CHANNEL.value)
+                c.channel_axis = 1
+                touched += 1
+        assert touched >= 3
+        ex = harness.TorchExecutor(graph, DEV)
+        harness.ParameterQuantizePass().optimize(graph)
+        p = RuntimeCalibrationPass(method=None, **kw)
+        p.optimize(graph, dataloader=batches, executor=ex, calib_steps=8)
+        torch.cuda.synchronize()
+        out = []
+        for op in graph.operations.values():
+            for c, v in op.config_with_variable:
+                if not v.is_parameter and c.dominated_by is c and c.state.value == 4 and c.channel_axis == 1:
+                    out.append(c.scale.detach().cpu().clone())
+        return p, out
+    _, eager = run(use_hip_graph=False)
+    p, replayed = run(use_hip_graph=True)
+    assert p.graph_replays == 7                                           # one phase (min-max), 7 of the 8 batches replayed
+    assert len(eager) == len(replayed) >= 3
+    for a, b in zip(eager, replayed):
+        assert a.numel() > 1 and torch.equal(a, b)
+
+
 def test_auto_graph_mode_equals_eager():
     """use_hip_graph='auto' times one eager step per phase and captures only when launch-bound; either
     way the scales equal the eager loop's.  The small CNN at batch 4 is launch-bound, so with the

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(_lib.lib, name), f'{name} declared in include/ppq_hip.h but not exported'
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
-    assert _lib.lib.ppqhip_version() == _lib.ABI_VERSION == 3
+    assert _lib.lib.ppqhip_version() == _lib.ABI_VERSION == 4
 
 
 def test_no_cpu_fallback_and_error_convention():
