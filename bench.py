@@ -9,8 +9,9 @@ one `RuntimeCalibrationPass.optimize(...)` with `calib_steps = K` (phase 1 range
 phase 2 histogram collection incl. the per-forward weight fake-quant the reference performs, batched
 KL search, render), bracketed by barrier + torch.cuda.synchronize on both sides, MAX over ranks.
 Inputs (K batches of torch.rand(batch,3,224,224)) are resident in HBM before the timer starts.
-Weak scaling: every rank calibrates K batches of its own; statistics merge with one RCCL all-reduce
-per phase (ppq_amd/distributed.py); value = N*K*batch / time.
+Weak scaling: every rank calibrates K batches of its own; statistics merge with two RCCL collectives per
+phase -- a 13-word layout probe (MAX) and ONE data all-reduce over one flat buffer (ppq_amd/distributed.py);
+value = N*K*batch / time.
 
 The timed pass is repeated `--repeats` times (default 3, each on a freshly built graph, each timing
 exactly K steps); `value` is the MEDIAN pass and `values` / `spread_pct` report all of them.
@@ -211,7 +212,8 @@ def collect_prof():
 
 
 # device kernels that implement each logical library kernel (prefixes of the demangled names rocprofv3 prints)
-DEVICE_KERNELS = {'hist_sym_t': ('ppqhip::hist_persistent_kernel<false',), 'hist_asym_t': ('ppqhip::hist_persistent_kernel<true',),
+DEVICE_KERNELS = {'hist_sym_t': ('ppqhip::hist_persistent_kernel<false', 'ppqhip::hist_small_kernel<false'),
+                  'hist_asym_t': ('ppqhip::hist_persistent_kernel<true', 'ppqhip::hist_small_kernel<true'),
                   'minmax_t': ('ppqhip::minmax_persistent_kernel', 'ppqhip::minmax_t_kernel'),
                   'fq_linear_c': ('ppqhip::fq_linear_multi_kernel', 'ppqhip::fq_linear_c_tile_kernel'),
                   'fq_linear_t': ('ppqhip::fq_linear_t_tile_kernel',),
@@ -267,7 +269,7 @@ def staged_reference():
     return path if os.path.isdir(os.path.join(path, 'ppq')) else None
 
 
-def cpu_baseline(bins, target_samples=32, batch_samples=4, budget_s=30.0):
+def cpu_baseline(bins, target_samples=32, batch_samples=4, budget_s=15.0):
     """PPQ's USING_CUDA_KERNEL=False path on the host cores: the same two-phase KL calibration of the same
     ResNet-50 graph, torch-CPU ops on all host threads (torch.histc / min / max / round, range.py:86-98,
     175-188, qfunction/linear.py:27-32).  The reference's own classes when a staged copy is importable
@@ -296,13 +298,16 @@ def cpu_baseline(bins, target_samples=32, batch_samples=4, budget_s=30.0):
     secs1, _ = runner(graph(), warm, bins)
     n_batches = max(1, min(target_samples // batch_samples, int(budget_s / max(secs1, 1e-3))))
     batches = [torch.rand(batch_samples, 3, 224, 224, generator=g) for _ in range(n_batches)]
-    secs, _ = runner(graph(), batches, bins)
+    runs = [runner(graph(), batches, bins)[0] for _ in range(2)]        # best of two: the first pays page faults / thread start-up
+    secs = min(runs)
     n = batch_samples * n_batches
     small = [torch.rand(2, 3, 224, 224, generator=g) for _ in range(2)]
     psecs, _ = timed_calibrate_cpu(graph(), small, bins)
     return {'value': round(n / secs, 3), 'unit': 'samples/s', 'cores': torch.get_num_threads(), 'kind': kind,
             'sample': f'{n} samples ({n_batches} batches of {batch_samples}) of the same ResNet-50 KL-{bins} calibration, '
-                      f"PPQ's USING_CUDA_KERNEL=False torch-CPU path on {torch.get_num_threads()} threads; {secs:.1f} s",
+                      f"PPQ's USING_CUDA_KERNEL=False torch-CPU path on {torch.get_num_threads()} threads; best of 2 runs: "
+                      + ' / '.join(f'{t:.1f} s' for t in runs),
+            'values': [round(n / t, 3) for t in runs],
             'port_c_oracle': {'value': round(4 / psecs, 3), 'unit': 'samples/s', 'cores': 1,
                               'sample': f'4 samples, torch-CPU dense ops + single-threaded C restatement of the kernels; {psecs:.1f} s'}}
 
@@ -330,6 +335,76 @@ def roofline_entry(prof_rows, prefer=None):
             'frac_of_measured_copy_ceiling': round(ach / 6290.0, 4)}      # MI355X_MICROARCH.md: 6.29 TB/s float4 copy
 
 
+def north_star_b_child(bins):
+    """`--b-child` (run under rocprofv3 --kernel-trace by north_star_b): the single-tensor entry points on B = [1,512,56,56],
+    300 launches each over 6 rotating inputs / outputs, in a fixed order the parent knows."""
+    from ppq_amd import CUDA, _lib
+    lib = _lib.lib
+    dev = 'cuda:0'
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=dev).manual_seed(7)
+    xs = [torch.randn(1, 512, 56, 56, device=dev, generator=g) for _ in range(6)]
+    outs = [torch.empty_like(xs[0]) for _ in range(6)]
+    n, C, epc = xs[0].numel(), 512, 56 * 56
+    sc = torch.rand(C, device=dev, generator=g) * 0.05 + 0.01
+    oc = torch.randint(0, 255, [C], device=dev, generator=g).float()
+    s1 = torch.tensor([0.03], device=dev); o1 = torch.zeros(1, device=dev)
+    hist = torch.zeros(bins, dtype=torch.int32, device=dev)
+    rows = torch.zeros(CUDA.hist_rows(), bins, dtype=torch.int32, device=dev)
+    slots = torch.tensor([float('inf'), float('-inf')], device=dev).repeat(CUDA.minmax_slots(), 1).contiguous()
+    hs = float(xs[0].abs().max()) / bins
+    P = lambda t: t.data_ptr()      # noqa: E731
+    for k in range(2000): outs[k % 6].copy_(xs[k % 6])            # clocks / caches in a steady state
+    torch.cuda.synchronize()
+    for k in range(300): lib.ppqhip_fq_linear_c(P(xs[k % 6]), P(sc), P(oc), P(outs[k % 6]), n, C, epc, 0, 255, 0, st)
+    torch.cuda.synchronize()
+    for k in range(300): lib.ppqhip_fq_linear_t(P(xs[k % 6]), P(s1), P(o1), P(outs[k % 6]), n, -128, 127, 0, st)
+    torch.cuda.synchronize()
+    for k in range(300): lib.ppqhip_hist_sym_t_rows(P(xs[k % 6]), n, hs, 1, P(rows), bins, st)
+    torch.cuda.synchronize()
+    for k in range(300): lib.ppqhip_hist_sym_t(P(xs[k % 6]), n, hs, 1, P(hist), bins, None, st)
+    torch.cuda.synchronize()
+    for k in range(300): lib.ppqhip_minmax_t_slots(P(xs[k % 6]), n, P(slots), st)
+    torch.cuda.synchronize()
+
+
+def north_star_b(bins, timeout_s: float = 180.0):
+    """The tensor BASELINE.json's north star names, B = [1,512,56,56] fp32 (6.4 MB), through the single-tensor entry points:
+    MEDIAN device durations from `rocprofv3 --kernel-trace` of a child of this file (`--b-child`) -- these launches are a few
+    microseconds long and latency-bound, event pairs cannot time them (their own overhead is as long as the kernel).  The same
+    numbers next to their floors (empty kernel, pure read, copy, read + atomic combine): profiles/r05_floor_table.txt."""
+    rocprof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if rocprof is None: return None
+    work = tempfile.mkdtemp(prefix='ppq_b_', dir='/tmp')
+    try:
+        cmd = [rocprof, '--output-format', 'csv', '--kernel-trace', '-d', work, '-o', 'b', '--', sys.executable, os.path.abspath(__file__),
+               '--b-child', '--bins', str(bins)]
+        subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+        files = glob.glob(os.path.join(work, '**', '*kernel_trace.csv'), recursive=True)
+        if not files: return None
+        dur = {}
+        for r in csv.DictReader(open(files[0])):
+            name = r['Kernel_Name'].replace('void ', '').replace('ppqhip::', '').split('(')[0].split('<')[0]
+            key = (name, int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])))
+            dur.setdefault(key, []).append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
+        n = 512 * 56 * 56
+
+        def med(pred):
+            v = sorted(d for k, ds in dur.items() if pred(k) for d in ds[20:])
+            return v[len(v) // 2] / 1e3 if len(v) >= 100 else None
+        small = sorted({k[1] for k in dur if k[0] == 'hist_small_kernel'})
+        out = {'fq_linear_c': (8, med(lambda k: k[0] == 'fq_linear_c_tile_kernel')), 'fq_linear_t': (8, med(lambda k: k[0] == 'fq_linear_t_tile_kernel')),
+               'hist_sym_t_rows': (4, med(lambda k: k[0] == 'hist_small_kernel' and len(small) == 2 and k[1] == small[1])),
+               'hist_sym_t_oneshot': (4, med(lambda k: k[0] == 'hist_small_kernel' and len(small) == 2 and k[1] == small[0])),
+               'minmax_t': (4, med(lambda k: k[0] == 'minmax_persistent_kernel'))}
+        return {k: {'us': round(us, 2), 'GBps': round(bpe * n / us / 1e3, 1), 'frac_of_8TBps': round(bpe * n / us / 1e3 / HBM_PEAK_GBPS, 3)}
+                for k, (bpe, us) in out.items() if us}
+    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def seam_variants(dev, batches, steps, bins, method):
     """The plugin seams INSIDE the unmodified reference, timed on this box: the reference's own BaseGraph +
     TensorRT quantizer + TorchExecutor are the host (driven through oracle/reference_import.py, which only imports and calls
@@ -355,12 +430,16 @@ def seam_variants(dev, batches, steps, bins, method):
             times, checksum = [], None
             for rep in range(3):
                 rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(harness.resnet50_graph(seed=0)), dev, batches[0], bins=bins, method=method)
-                p = RefPass(method=method) if stack == 'kernels' else OurPass(method=method, check_steps=False)
+                # small batches: 'auto' -- the pass times one eager step and captures the REFERENCE executor's loop into a HIP graph
+                # when that step is launch-bound (batch 1); at batch >= 16 the step is GPU-bound and stays eager, as in the headline
+                p = RefPass(method=method) if stack == 'kernels' else OurPass(method=method, check_steps=False,
+                                                                             use_hip_graph='auto' if batches[0].shape[0] < 16 else False)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 if stack == 'kernels': p.optimize(graph=rg, dataloader=batches, executor=rex, calib_steps=n, collate_fn=None)
                 else: PFL.Pipeline([p]).optimize(graph=rg, dataloader=batches, executor=rex, calib_steps=n, collate_fn=None, verbose=False)
                 torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
                 checksum = float(sum(RI.activation_scales(rg).values()))
+                replays = getattr(p, 'graph_replays', 0)
                 del rg, rex, p
             best = min(times[1:])
             samples = n * batches[0].shape[0]
@@ -368,7 +447,8 @@ def seam_variants(dev, batches, steps, bins, method):
                                      'pass': "reference executor + BaseGraph driving ppq_amd's RuntimeCalibrationPass + observers inside ppq.lib.Pipeline: install_plugins_into_ppq()"}[stack]
                                     + f'; ResNet-50 {method} {bins} bins, {n} x {batches[0].shape[0]}',
                         'seam': stack, 'samples': samples, 'value': round(samples / best, 2), 'unit': 'samples/s',
-                        'ms_per_step': round(best / n * 1e3, 3), 'scale_checksum': checksum})
+                        'ms_per_step': round(best / n * 1e3, 3), 'scale_checksum': checksum, 'graph_replays': replays,
+                        'values': [round(samples / t, 2) for t in times[1:]]})
     except Exception as e:            # a broken stage must not cost the bench line
         print(f'[bench] seam variants skipped: {type(e).__name__}: {e}', file=sys.stderr)
     finally:
@@ -383,26 +463,31 @@ def workload_variants(args):
     """BASELINE configs 3, 4, 5 as short child runs of this file: each line's value + the roofline entry of its dominant
     kernel.  Children skip baselines, PMC passes and their own variants; MIOpen immediate mode keeps their warm-up short."""
     out = []
-    for name, extra in (('resnet50_cfg3', ['--workload', 'resnet50_cfg3', '--steps', '4', '--batch', '32']),
-                        ('vit_b16_fp8', ['--workload', 'vit_b16_fp8', '--steps', '4', '--batch', '16']),
+    for name, extra in (('resnet50_cfg3', ['--workload', 'resnet50_cfg3', '--steps', '8', '--batch', '32']),
+                        ('vit_b16_fp8', ['--workload', 'vit_b16_fp8', '--steps', '8', '--batch', '16']),
                         ('yolov6s_int4_lsq', ['--workload', 'yolov6s_int4_lsq', '--steps', '8', '--batch', '8']),
                         # the headline pass at the reference's DEFAULT KL bin count (core/common.py:18: 4096; BASELINE quotes 2048)
                         ('resnet50_kl_bins4096', ['--workload', 'resnet50', '--bins', '4096', '--steps', '8', '--batch', '32']),
                         # the percentile observer on the headline topology: the in-situ number of the quantile launch
                         # sequence (quantile.hip; one sequence per forward over 72 tensors, hints from the previous batch)
                         ('resnet50_percentile', ['--workload', 'resnet50', '--method', 'percentile', '--steps', '16', '--batch', '32'])):
-        cmd = [sys.executable, os.path.abspath(__file__), '--warmup', '1', '--repeats', '1', '--variants', '0', '--pmc', '0',
-               '--no-cpu-baseline', '--no-cpu-ops', '--settle-ms', '0', '--miopen-find', '0'] + extra
+        # every child warms ITSELF with MIOpen's find mode on (one complete untimed pass over one batch): the parent's own find
+        # results live in its process until it exits, and a child in immediate mode on a fresh box runs the vendor library's
+        # heuristic picks instead (BENCH_r04: config 3 at 26 ms / step in the driver's run against 11.5 in the builder's, whose
+        # box had a user database from an earlier command); >= 8 timed steps, three timed passes (value = their median), spread reported
+        cmd = [sys.executable, os.path.abspath(__file__), '--warmup', '1', '--repeats', '3', '--variants', '0', '--pmc', '0',
+               '--no-cpu-baseline', '--no-cpu-ops', '--settle-ms', '100', '--miopen-find', '1'] + extra
         try:
             t0 = time.perf_counter()
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
             line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
             if r.returncode != 0 or not line:
                 out.append({'workload': name, 'error': (r.stderr or r.stdout)[-300:]}); continue
             j = json.loads(line[-1])
             roof = j.get('roofline') or {}
             out.append({'workload': j['config']['workload'], 'name': name, 'metric': j['metric'], 'value': j['value'], 'unit': j['unit'],
-                        'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'child_wall_s': round(time.perf_counter() - t0, 1),
+                        'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'values': j.get('values'), 'spread_pct': j.get('spread_pct'),
+                        'child_wall_s': round(time.perf_counter() - t0, 1),
                         'roofline': {k: roof.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'launches', 'avg_launch_us',
                                                               'algorithmic_bytes_per_launch')}})
             if name == 'yolov6s_int4_lsq':      # per-block tensors of 0.05 .. 6 MB: every launch is latency-, not bandwidth-bound
@@ -410,6 +495,7 @@ def workload_variants(args):
                 out[-1]['launches_per_eager_step'] = j['config'].get('launches_per_eager_step')
                 out[-1]['per_tensor_eager_samples_per_s'] = j['config'].get('per_tensor_eager_samples_per_s')
                 out[-1]['phase_ms_whole_pass'] = j['config'].get('phase_ms_whole_pass')
+                out[-1]['step'] = j['config'].get('step')
                 out[-1]['roofline']['note'] = ('block-wise finetuning: all weight delegators of a block share ONE LSQ-backward launch per step '
                                                '(ppqhip_fq_linear_c_bwd_multi; activations keep one launch each) and the step is replayed from a '
                                                'HIP graph; per-block tensors of 0.05 .. 6 MB stay latency-bound; the same kernels on '
@@ -465,7 +551,7 @@ def main_lsq(args, rank, world, dev):
         del ex
     elapsed = sorted(times)[len(times) // 2]
     blocks = len(p.report)
-    roof, prof_rows, launches_per_step, per_tensor_eager_s, phase_ms = None, [], None, 1.0, None
+    roof, prof_rows, launches_per_step, per_tensor_eager_s, phase_ms, step_report = None, [], None, 1.0, None, None
     if rank == 0 and world == 1:
         graph2, ex2 = build()
         torch.cuda.synchronize(); _lib.lib.ppqhip_prof_enable(1)
@@ -484,6 +570,28 @@ def main_lsq(args, rank, world, dev):
         pq.optimize(graph4, batches, ex4)
         phase_ms = {k: round(v, 1) for k, v in pq.phase_ms.items()}
         del graph4, ex4
+
+        def replay_ms(steps, max_blocks, **kw):
+            """ms per REPLAYED optimizer step (synchronised around the replay loops of all blocks)."""
+            gq, eq = build()
+            q = LearnedStepSizePass(steps=steps, lr=1e-5, block_size=5, **kw)
+            q.profile_phases, q.max_blocks = True, max_blocks
+            q.optimize(gq, batches, eq)
+            n = max(1, q.stats['graph_replays'])
+            return round(q.phase_ms.get('graph_replays', 0.0) / n, 4), q.stats
+        # what the round-5 changes to the step buy: activation delegators with ONE finish launch per step + fused Adam, against
+        # round 4's step (a finish launch per activation, foreach Adam) -- same blocks, same steps
+        r5_ms, r5_stats = replay_ms(args.steps, None)
+        r4_ms, _ = replay_ms(args.steps, None, group_activations=False, fused_adam=False)
+        # the reference's DEFAULT step count (500, optim/training.py:700-713) on the first 3 blocks: the regime in which the
+        # replays, not the collection / capture overheads, are the pass
+        torch.cuda.synchronize(); t5 = time.perf_counter()
+        long_ms, long_stats = replay_ms(500, 3)
+        torch.cuda.synchronize(); t5 = time.perf_counter() - t5
+        step_report = {'replay_ms_per_step': r5_ms, 'replay_ms_per_step_round4_form': r4_ms,
+                       'fused_adam_blocks': r5_stats.get('fused_adam_blocks', 0), 'grouped_activations': r5_stats.get('grouped_activations', 0),
+                       'steps500_blocks3': {'replay_ms_per_step': long_ms, 'wall_s': round(t5, 2),
+                                            'samples_per_s': round(3 * 500 * args.batch / t5, 1), 'graph_replays': long_stats['graph_replays']}}
         # the same pass without this round's execution choices: per-tensor launches, eager steps (what round 3 measured)
         graph3, ex3 = build()
         torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -503,10 +611,13 @@ def main_lsq(args, rank, world, dev):
                                    f'(timed: the whole pass incl. its target / input collection)', 'samples': samples, 'batch': args.batch,
                        'blocks': blocks, 'optimizer_steps': total_steps, 'kept_blocks': sum(1 for _, a, b in p.report if b <= a),
                        'parallelism': f'dp{world} (one flat gradient all-reduce per step)', 'rccl_ranks': world,
-                       'execution': dict(p.stats, graph_error=LearnedStepSizePass.graph_error, note='grouped_weights: weight delegators served by ONE forward + ONE backward launch per step; '
+                       'execution': dict(p.stats, graph_error=p.graph_error, note='grouped_weights: weight delegators served by ONE forward + ONE backward launch per step; '
                                                         'graph_replays: optimizer steps replayed from a captured HIP graph'),
                        'launches_per_eager_step': launches_per_step if (rank == 0 and world == 1) else None,
-                       'phase_ms_whole_pass': phase_ms,
+                       'phase_ms_whole_pass': phase_ms, 'step': step_report,
+                       'replay_ms_per_step': (step_report or {}).get('replay_ms_per_step'),
+                       'replay_ms_per_step_round4_form': (step_report or {}).get('replay_ms_per_step_round4_form'),
+                       'steps500_blocks3_samples_per_s': ((step_report or {}).get('steps500_blocks3') or {}).get('samples_per_s'),
                        'per_tensor_eager_samples_per_s': round(samples / per_tensor_eager_s, 2) if (rank == 0 and world == 1) else None},
             'roofline': roof, 'cpu_baseline': None,
             'kernels': [{'name': r['name'], 'launches': r['launches'], 'total_ms': round(r['total_ms'], 3),
@@ -532,6 +643,7 @@ def main():
     ap.add_argument('--variants', type=int, default=1, help="also time SURVEY 8(d)'s own protocol (batch 1 x 256 steps) once and report it in config.variants")
     ap.add_argument('--pmc', type=int, default=1, help='measure roofline.traffic with two rocprofv3 --pmc child passes of this command')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--b-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--host-selftest', action='store_true', help='CPU-only check of spawn + rendezvous + merge (gloo); no GPU work')
     ap.add_argument('--backend', type=str, default='nccl')
     ap.add_argument('--single-device', type=int, default=0, help='debug: put every rank on cuda:0 (use with --backend gloo)')
@@ -557,6 +669,7 @@ def main():
     if WORKLOAD != 'resnet50':              # the reference-CPU legs and the batch-1 variant describe config 2 only
         args.no_cpu_baseline = args.no_cpu_ops = True
         args.variants = 0
+    if args.b_child: return north_star_b_child(args.bins)
     maybe_spawn(args)
     if args.host_selftest: return host_selftest(args)
     rank, world, local = setup_dist(args.gpus, args.backend, bool(args.single_device))
@@ -716,6 +829,37 @@ def main():
         cpu_ops = {'kind': 'reference-path', 'cores': torch.get_num_threads(), 'unit': 'ms (median) / GB/s of algorithmic bytes',
                    'rows': T.op_table(args.bins)}
 
+    scalars = {}
+    if rank == 0 and world == 1 and args.variants:
+        # the driver keeps the SCALAR keys of `config` and drops nested ones: the figures that matter are repeated here flat
+        def val(pred):
+            for v in variants:
+                if pred(v) and 'value' in v: return v['value']
+            return None
+        scalars = {
+            'batch1_x256_samples_per_s': val(lambda v: str(v.get('workload', '')).startswith('batch 1 x 256')),
+            'reuse_activations_samples_per_s': val(lambda v: 'reuse_activations' in str(v.get('workload', ''))),
+            f'seam_kernels_b{args.batch}_samples_per_s': val(lambda v: v.get('seam') == 'kernels' and v.get('samples', 0) > 64),
+            f'seam_pass_b{args.batch}_samples_per_s': val(lambda v: v.get('seam') == 'pass' and v.get('samples', 0) > 64),
+            'seam_kernels_b1_samples_per_s': val(lambda v: v.get('seam') == 'kernels' and v.get('samples', 0) == 64),
+            'seam_pass_b1_samples_per_s': val(lambda v: v.get('seam') == 'pass' and v.get('samples', 0) == 64),
+            'cfg3_samples_per_s': val(lambda v: v.get('name') == 'resnet50_cfg3'),
+            'cfg4_samples_per_s': val(lambda v: v.get('name') == 'vit_b16_fp8'),
+            'cfg5_samples_per_s': val(lambda v: v.get('name') == 'yolov6s_int4_lsq'),
+            'cfg5_replay_ms_per_step': next((((v.get('step') or {}).get('replay_ms_per_step')) for v in variants if v.get('name') == 'yolov6s_int4_lsq'), None),
+            'cfg5_replay_ms_per_step_round4_form': next((((v.get('step') or {}).get('replay_ms_per_step_round4_form')) for v in variants if v.get('name') == 'yolov6s_int4_lsq'), None),
+            'cfg5_steps500_blocks3_samples_per_s': next(((((v.get('step') or {}).get('steps500_blocks3') or {}).get('samples_per_s')) for v in variants if v.get('name') == 'yolov6s_int4_lsq'), None),
+            'kl4096_samples_per_s': val(lambda v: v.get('name') == 'resnet50_kl_bins4096'),
+            'percentile_samples_per_s': val(lambda v: v.get('name') == 'resnet50_percentile'),
+        }
+        for v in variants:
+            if v.get('name') in ('resnet50_cfg3', 'vit_b16_fp8', 'yolov6s_int4_lsq') and v.get('roofline'):
+                key = {'resnet50_cfg3': 'cfg3', 'vit_b16_fp8': 'cfg4', 'yolov6s_int4_lsq': 'cfg5'}[v['name']]
+                scalars[f'{key}_roofline_frac'] = v['roofline'].get('frac')
+                scalars[f'{key}_spread_pct'] = v.get('spread_pct')
+        nsb = north_star_b(args.bins)             # rocprofv3 --kernel-trace medians of a child (None without rocprofv3)
+        for k_, r_ in (nsb or {}).items():
+            scalars[f'B_{k_}_rocprof_median_us'] = r_['us']; scalars[f'B_{k_}_frac_of_8TBps'] = r_['frac_of_8TBps']
     if rank == 0:
         samples = world * args.steps * args.batch
         out = {
@@ -731,8 +875,9 @@ def main():
                                     f'per-channel INT8 weights, {args.steps} batches x {args.batch} x 3x224x224 per GPU') if WORKLOAD == 'resnet50'
                        else f'{WORKLOADS[WORKLOAD][0]}; RuntimeCalibrationPass {args.method}, {args.bins} bins, {args.steps} batches x {args.batch} x 3x224x224 per GPU',
                        'samples': samples, 'batch': args.batch, 'observed_tensors': n_obs,
-                       'parallelism': f'dp{world} (batches sharded, 1 all-reduce per phase)',
+                       'parallelism': f'dp{world} (batches sharded; per phase 1 layout-probe MAX + 1 data all-reduce over one flat buffer)',
                        'rccl_ranks': world, 'backend': args.backend if world > 1 else None, 'merge': merge_stats,
+                       **scalars,
                        'variants': variants,
                        'async_observe': bool(args.async_observe), 'cache_params': bool(args.cache_params),
                        'channels_last': bool(args.channels_last), 'fuse_params': bool(args.fuse_params), 'batch_observations': bool(args.batch_observations),

@@ -41,7 +41,8 @@ typedef enum {
 } ppqhip_status;
 
 #define PPQHIP_ABI_VERSION 4   /* 2: quantile hints (round 3); 3: *_multi LSQ / min-max entry points, quantile sequence (round 4);
-                                * 4: ppqhip_minmax_c_multi carries its job table in the kernel arguments (no device table / upload) */
+                                * 4: ppqhip_minmax_c_multi carries its job table in the kernel arguments (no device table / upload); split per-tensor LSQ
+ *    backward (ppqhip_fq_linear_t_bwd_main / ppqhip_lsq_finish_multi) (round 5) */
 
 /* library / device introspection ------------------------------------------------------------- */
 const char* ppqhip_last_error(void);
@@ -100,6 +101,22 @@ int ppqhip_fq_linear_c_bwd(const float* x, const float* scale, const float* offs
                            const float* grad_y, float* grad_x, float* grad_s, int64_t n,
                            int64_t num_channel, int64_t elem_per_channel,
                            int clip_min, int clip_max, int rounding, void* stream);
+
+/* The same backward in two halves, for callers that back-propagate through SEVERAL per-tensor configs in one sweep (the
+ * activation delegators of a block-wise LSQ step): `_main` computes grad_x and leaves ppqhip_fq_linear_t_bwd_partials(n)
+ * per-workgroup partial sums of the scale gradient in the caller-owned `partial`; ONE ppqhip_lsq_finish_multi launch at the end
+ * of the sweep turns the partials of all jobs into their grad_s (OVERWRITTEN) -- each exactly as ppqhip_fq_linear_t_bwd's own
+ * finish would (same lanes, same order, double accumulation: bit-identical).  Job table in the kernel arguments. */
+int64_t ppqhip_fq_linear_t_bwd_partials(int64_t n);
+int ppqhip_fq_linear_t_bwd_main(const float* x, const float* scale, const float* offset, const float* grad_y, float* grad_x,
+                                float* partial, int64_t n, int clip_min, int clip_max, int rounding, void* stream);
+typedef struct ppqhip_lsq_finish_job {
+    const float* partial;     /* written by ppqhip_fq_linear_t_bwd_main for a tensor of n elements */
+    float* grad_s;            /* 1 element */
+    int64_t n;
+    int32_t clip_min, clip_max;
+} ppqhip_lsq_finish_job;
+int ppqhip_lsq_finish_multi(const ppqhip_lsq_finish_job* jobs, int num_jobs, void* stream);
 
 /* LSQ backward of MANY per-channel tensors in one launch -- what a block-wise LSQ step needs for all the weights of its
  * block (LearnedStepSizePass.finetune, optim/training.py:728-826, calls CuLSQ_LC.backward -> QuantizeTensor_LC_B once per

@@ -41,6 +41,9 @@ PROTOTYPES = {
     'ppqhip_fq_linear_c_bwd': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_int,
                                        c_int, c_int, c_vp]),
     'ppqhip_fq_linear_c_bwd_multi': (c_int, [c_vp, c_int, c_int, c_vp]),
+    'ppqhip_fq_linear_t_bwd_partials': (c_i64, [c_i64]),
+    'ppqhip_fq_linear_t_bwd_main': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_int, c_vp]),
+    'ppqhip_lsq_finish_multi': (c_int, [c_vp, c_int, c_vp]),
     'ppqhip_fq_float_t': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_int, c_flt, c_flt, c_int, c_vp]),
     'ppqhip_fq_float_c': (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_i64, c_i64, c_int, c_int, c_flt, c_flt,
                                   c_int, c_vp]),

@@ -206,6 +206,19 @@ class PrefixCache:
         """The block's parameters / scales changed: forget its outputs and everything computed from them -- and, with them
         gone, every tensor nothing will be computed from any more (see :meth:`prune`)."""
         dead, stack = set(), [v for op in block.rps for v in op.outputs]
+        # a config OUTSIDE the block may read a scale the block just trained (TensorQuantizationConfig.dominated_by / master links,
+        # core.py): the outputs of such an operation are stale too, wherever it sits in the graph (ADVICE r4; quantize_graph never
+        # links across blocks today -- the guard costs one pass over the configs)
+        owned = {id(cfg) for op in block.rps if hasattr(op, 'config') for cfg, _ in op.config_with_variable}
+        inside = {id(op) for op in block.rps}
+        for op in self.graph.operations.values():
+            if id(op) in inside or not hasattr(op, 'config'): continue
+            for cfg, _ in op.config_with_variable:
+                root, hops = cfg, 0
+                while getattr(root, 'dominated_by', root) is not root and hops < 64: root, hops = root.dominated_by, hops + 1
+                if root is not cfg and id(root) in owned:
+                    stack.extend(op.outputs)
+                    break
         while stack:
             v = stack.pop()
             if v.name in dead: continue

@@ -104,10 +104,26 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         safe = (TorchMinMaxObserver, TorchHistObserver, TorchMSEObserver, ConstantObserver)
         return all(type(ob) in safe for hook in hooks.values() for ob in hook._observer_table.values())
 
+    @ staticmethod
+    def _forward_fn(executor):
+        """What one calibration forward calls.  The reference's ``TorchExecutor.forward`` (executor/torch.py:325-410) is its
+        PUBLIC ``forward_with_gradient`` (:412-456, the same loop over ``_executing_order``) wrapped in ``torch.no_grad()`` and
+        ``@empty_ppq_cache`` -- ``torch.cuda.empty_cache(); gc.collect()`` before EVERY batch (core/defs.py:43-55): ~8 ms of host
+        time per call (most of a batch-1 step) and, because it frees device memory, illegal inside a HIP-graph capture.  On that
+        executor the pass therefore calls ``forward_with_gradient`` under its own ``torch.no_grad()``: the same operations on the
+        same tensors, without emptying the allocator between batches.  Any other executor (this package's harness, a user's
+        own) is called through ``forward`` as before."""
+        cls = type(executor)
+        if cls.__module__.startswith('ppq.') and hasattr(executor, 'forward_with_gradient') and hasattr(executor, '_executing_order'):
+            return executor.forward_with_gradient
+        return executor.forward
+
     def _forward(self, executor, data, hooks, output_names):
+        import torch
         recording = self._queue is not None and self._recording
         if recording: self._queue.recorder = []
-        executor.forward(inputs=data, hooks=hooks, output_names=output_names)
+        with torch.no_grad():
+            self._forward_fn(executor)(inputs=data, hooks=hooks, output_names=output_names)
         if self._queue is not None: self._queue.flush()      # one multi-tensor launch per statistic kind
         if recording:
             rec, self._queue.recorder = self._queue.recorder, None

@@ -75,6 +75,15 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, FastDiv f) {
     return (__umulhi(n, f.m) + n) >> f.l;
 }
 
+// Balanced split of T work items over G workgroups: workgroup g owns [begin, end); the first T % G workgroups own one item more.
+// (floor(g * T / G) needs a 64-bit product and a 64-bit division: ~200 scalar instructions at the head of every persistent
+// kernel, on the critical path of a latency-bound launch.  This is one 32-bit division.)
+__device__ __forceinline__ void even_split(uint32_t T, uint32_t G, uint32_t g, uint32_t& begin, uint32_t& end) {
+    const uint32_t q = T / G, rem = T - q * G;
+    begin = g * q + min(g, rem);
+    end = begin + q + (g < rem ? 1u : 0u);
+}
+
 // v_cvt_i32_f32: round-toward-zero, saturating, NaN -> 0 (the value passed in is already integral)
 __device__ __forceinline__ int f2i_sat(float v) {
     int r;

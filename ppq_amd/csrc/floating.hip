@@ -110,25 +110,23 @@ __global__ __launch_bounds__(kBlock) void fq_float_t_tile_kernel(
     const float4* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
     float4* __restrict__ out, uint32_t nvec, const float* __restrict__ xtail, float* __restrict__ otail,
     int ntail, FloatFmt fmt, int rounding) {
-    const float s = scale[0], o = offset[0];
     const uint32_t base = blockIdx.x * (kBlock * U) + threadIdx.x;
     float4 a[U];
 #pragma unroll
     for (int k = 0; k < U; k++)
         a[k] = load4<NT>(&x[min(base + k * kBlock, nvec - 1)]);   // branch-free (clamped) so all U loads issue back to back
+    const float s = scale[0], o = offset[0];
     const uint32_t rb = float_fast_ok<R>(fmt) ? pow2_reciprocal_bits(s) : 0u;
     if (rb) {                                                     // kernel-uniform
         const float rcp = __uint_as_float(rb);
 #pragma unroll
-        for (int k = 0; k < U; k++) {
-            if (base + k * kBlock < nvec) {
-                float4 r;
-                r.x = (quant_float_rne_pow2(a[k].x, rcp, fmt) - o) * s;
-                r.y = (quant_float_rne_pow2(a[k].y, rcp, fmt) - o) * s;
-                r.z = (quant_float_rne_pow2(a[k].z, rcp, fmt) - o) * s;
-                r.w = (quant_float_rne_pow2(a[k].w, rcp, fmt) - o) * s;
-                out[base + k * kBlock] = r;
-            }
+        for (int k = 0; k < U; k++) {                             // unconditional arithmetic, predicated store (see linear.hip)
+            float4 r;
+            r.x = (quant_float_rne_pow2(a[k].x, rcp, fmt) - o) * s;
+            r.y = (quant_float_rne_pow2(a[k].y, rcp, fmt) - o) * s;
+            r.z = (quant_float_rne_pow2(a[k].z, rcp, fmt) - o) * s;
+            r.w = (quant_float_rne_pow2(a[k].w, rcp, fmt) - o) * s;
+            if (base + k * kBlock < nvec) out[base + k * kBlock] = r;
         }
         if (blockIdx.x == 0 && (int)threadIdx.x < ntail)
             otail[threadIdx.x] = (quant_float_rne_pow2(xtail[threadIdx.x], rcp, fmt) - o) * s;
@@ -190,14 +188,14 @@ __global__ __launch_bounds__(kBlock) void fq_float_c_tile_kernel(
     for (int k = 0; k < U; k++) {
         const uint32_t vv = base + k * kBlock;
         const uint32_t rb = float_fast_ok<R>(fmt) ? pow2_reciprocal_bits(s[k]) : 0u;
-        if (vv < nvec && rb) {                                     // diverges only where a wave straddles channels of both kinds
-            const float rcp = __uint_as_float(rb);
+        if (rb) {                                                  // diverges only where a wave straddles channels of both kinds
+            const float rcp = __uint_as_float(rb);                 // unconditional arithmetic, predicated store (see linear.hip)
             float4 r;
             r.x = (quant_float_rne_pow2(a[k].x, rcp, fmt) - o[k]) * s[k];
             r.y = (quant_float_rne_pow2(a[k].y, rcp, fmt) - o[k]) * s[k];
             r.z = (quant_float_rne_pow2(a[k].z, rcp, fmt) - o[k]) * s[k];
             r.w = (quant_float_rne_pow2(a[k].w, rcp, fmt) - o[k]) * s[k];
-            out[vv] = r;
+            if (vv < nvec) out[vv] = r;
         } else if (vv < nvec) {
             float4 r;
             r.x = (quant_float_scalar<R>(a[k].x, s[k], fmt, rounding) - o[k]) * s[k];
@@ -498,6 +496,8 @@ static int validate(int64_t n, const char* what) {
 
 constexpr int64_t kStreamElems = 48ll << 20;   // >= 192 MiB: streaming loads (see linear.hip)
 constexpr int kTileU = 2;
+constexpr int kSmallU = 1;                     // latency-bound tensors: twice the waves, half the work behind each load (linear.hip)
+constexpr int64_t kSmallElems = 4ll << 20;
 
 template <int R>
 static void launch_ft(const float* x, const float* scale, const float* offset, float* out, int64_t n,
@@ -507,13 +507,13 @@ static void launch_ft(const float* x, const float* scale, const float* offset, f
         const int ntail = (int)(n & 3);
         const float* xt = x + (size_t)nvec * 4;
         float* ot = out + (size_t)nvec * 4;
-        const dim3 grid((nvec + kBlock * kTileU - 1) / (kBlock * kTileU));
-        if (n >= kStreamElems)
-            hipLaunchKernelGGL((fq_float_t_tile_kernel<R, kTileU, true>), grid, dim3(kBlock), 0, st, (const float4*)x,
-                               scale, offset, (float4*)out, nvec, xt, ot, ntail, fmt, rounding);
-        else
-            hipLaunchKernelGGL((fq_float_t_tile_kernel<R, kTileU, false>), grid, dim3(kBlock), 0, st, (const float4*)x,
-                               scale, offset, (float4*)out, nvec, xt, ot, ntail, fmt, rounding);
+#define PPQ_LAUNCH_FT(U, NT)                                                                                          \
+        hipLaunchKernelGGL((fq_float_t_tile_kernel<R, U, NT>), dim3((nvec + kBlock * U - 1) / (kBlock * U)), dim3(kBlock), 0, st, \
+                           (const float4*)x, scale, offset, (float4*)out, nvec, xt, ot, ntail, fmt, rounding)
+        if (n >= kStreamElems) PPQ_LAUNCH_FT(kTileU, true);
+        else if (n <= kSmallElems) PPQ_LAUNCH_FT(kSmallU, false);
+        else PPQ_LAUNCH_FT(kTileU, false);
+#undef PPQ_LAUNCH_FT
     } else {
         hipLaunchKernelGGL((fq_float_scalar_kernel<R>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, x, scale,
                            offset, out, (uint32_t)n, make_fastdiv(1), make_fastdiv(1), 0, fmt, rounding);
@@ -526,13 +526,13 @@ static void launch_fc(const float* x, const float* scale, const float* offset, f
     if (aligned16(x) && aligned16(out) && epc % 4 == 0) {
         const uint32_t nvec = (uint32_t)(n >> 2);
         const FastDiv vpc = make_fastdiv((uint32_t)(epc / 4)), nc = make_fastdiv((uint32_t)C);
-        const dim3 grid((nvec + kBlock * kTileU - 1) / (kBlock * kTileU));
-        if (n >= kStreamElems)
-            hipLaunchKernelGGL((fq_float_c_tile_kernel<R, kTileU, true>), grid, dim3(kBlock), 0, st, (const float4*)x,
-                               scale, offset, (float4*)out, nvec, vpc, nc, fmt, rounding);
-        else
-            hipLaunchKernelGGL((fq_float_c_tile_kernel<R, kTileU, false>), grid, dim3(kBlock), 0, st, (const float4*)x,
-                               scale, offset, (float4*)out, nvec, vpc, nc, fmt, rounding);
+#define PPQ_LAUNCH_FC(U, NT)                                                                                          \
+        hipLaunchKernelGGL((fq_float_c_tile_kernel<R, U, NT>), dim3((nvec + kBlock * U - 1) / (kBlock * U)), dim3(kBlock), 0, st, \
+                           (const float4*)x, scale, offset, (float4*)out, nvec, vpc, nc, fmt, rounding)
+        if (n >= kStreamElems) PPQ_LAUNCH_FC(kTileU, true);
+        else if (n <= kSmallElems) PPQ_LAUNCH_FC(kSmallU, false);
+        else PPQ_LAUNCH_FC(kTileU, false);
+#undef PPQ_LAUNCH_FC
     } else {
         hipLaunchKernelGGL((fq_float_scalar_kernel<R>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, x, scale,
                            offset, out, (uint32_t)n, make_fastdiv((uint32_t)epc), make_fastdiv((uint32_t)C), 1, fmt,

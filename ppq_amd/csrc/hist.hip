@@ -154,26 +154,34 @@ struct Binner : WaveBinCounter<ASYM, CLIP, HOT> {
 
 };
 
-// column sums of partial[count][bins] into hist.  grid = (ceil(bins / 256), slices): each thread
-// sums its bin over one slice of the partial histograms (coalesced 1-KiB rows, 8 loads in flight)
-// and issues at most one atomic -- `slices` atomics per bin in total, no long serial chain.
-constexpr int kReduceSlices = 16;
-__global__ __launch_bounds__(kBlock) void hist_reduce_kernel(const int* __restrict__ partial, int count, int bins,
-                                                             int* __restrict__ hist) {
-    const int b = blockIdx.x * kBlock + threadIdx.x;
-    if (b >= bins) return;
-    const int per = (count + gridDim.y - 1) / gridDim.y;
-    const int lo = blockIdx.y * per;
-    const int hi = min(lo + per, count);
+// column sums of partial[count][bins] into hist: hist[b] += sum over rows.  One workgroup of 1024 lanes owns kReduceBins
+// consecutive bins (a 128-B segment of every row): lane (slice, bin) adds its bin over every kReduceSlices-th row with 8 loads in
+// flight, the slices meet in LDS and ONE lane per bin adds the total with a plain read-modify-write -- a bin has exactly one
+// owner, so there are no atomics and the integer sum has no order anyway.  (Round 2's form -- 128 workgroups, 16 same-address
+// device atomics per bin -- took 4.7 us for the 4 MB of rows of a 512-workgroup launch: 0.85 TB/s.)
+constexpr int kReduceBins = 32, kReduceSlices = 32, kReduceBlock = kReduceBins * kReduceSlices;
+__global__ __launch_bounds__(kReduceBlock) void hist_reduce_kernel(const int* __restrict__ partial, int count, int bins,
+                                                                   int* __restrict__ hist) {
+    __shared__ int lds[kReduceSlices][kReduceBins];
+    const int lane_bin = threadIdx.x % kReduceBins, slice = threadIdx.x / kReduceBins;
+    const int b = blockIdx.x * kReduceBins + lane_bin;
     int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int i = lo;
-    for (; i + 8 <= hi; i += 8) {
+    if (b < bins) {
+        int i = slice;
+        for (; i + 7 * kReduceSlices < count; i += 8 * kReduceSlices) {
 #pragma unroll
-        for (int k = 0; k < 8; k++) acc[k] += partial[(size_t)(i + k) * bins + b];
+            for (int k = 0; k < 8; k++) acc[k] += partial[(size_t)(i + k * kReduceSlices) * bins + b];
+        }
+        for (; i < count; i += kReduceSlices) acc[0] += partial[(size_t)i * bins + b];
     }
-    for (; i < hi; i++) acc[0] += partial[(size_t)i * bins + b];
-    const int s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-    if (s) atomicAdd(&hist[b], s);
+    lds[slice][lane_bin] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    __syncthreads();
+    if (slice == 0 && b < bins) {
+        int t = 0;
+#pragma unroll
+        for (int k = 0; k < kReduceSlices; k++) t += lds[k][lane_bin];
+        if (t) hist[b] += t;
+    }
 }
 
 // ---- the persistent kernel ---------------------------------------------------------------------
@@ -223,8 +231,8 @@ __global__ __launch_bounds__(kHistBlock, (kHistBlock * kHistWgPerCu + 255) / 256
 void hist_persistent_kernel(const HistJobs jobs) {
     extern __shared__ int lds[];
     const uint32_t G = gridDim.x, g = blockIdx.x;
-    uint32_t t = (uint32_t)(((uint64_t)g * jobs.total_tiles) / G);
-    const uint32_t t_end = (uint32_t)(((uint64_t)(g + 1) * jobs.total_tiles) / G);
+    uint32_t t, t_end;
+    even_split(jobs.total_tiles, G, g, t, t_end);
     const int bins = jobs.bins, copies = jobs.copies;
     // The LDS copies are zeroed AFTER the first tile's loads have been issued (their latency covers the stores and the
     // barrier; on a 6 MB tensor the kernel is a single latency chain, nothing else hides them).  The barrier is the bare
@@ -319,24 +327,21 @@ void hist_persistent_kernel(const HistJobs jobs) {
 // persistent kernel above spends ~2 us of it on its own generality: its 3 KB job table is fetched in two DEPENDENT scalar-load
 // rounds (launch header, then the job the workgroup landed in), its tiles ping-pong two at a time, the LDS copies are zeroed before
 // the first load is issued.  This kernel takes ONE tensor with its few arguments by value (one scalar-load round), issues up to
-// kSmallK 16-B loads per lane before anything else, zeroes the LDS copy while they fly and bins them in arrival order with the same
+// 8 16-B loads per lane before anything else, zeroes the LDS copy while they fly and bins them in arrival order with the same
 // Binner.  Counts are the same integers whatever the traversal.  Flush: device atomics either into the caller's histogram (few
 // workgroups: every workgroup touches every 64-B line of the histogram once and the memory-side atomic unit serialises the
 // operations on a line, ~15 ns each -- tools/floor_table.py, `floor_atomic`) or into the workgroup's OWN row of a persistent
 // accumulator (no contention at all, so the grid can cover every CU; atomics instead of a load-add-store keep the row's
 // read latency out of the chain).
-#ifndef PPQHIP_HIST_SMALL_K
-#define PPQHIP_HIST_SMALL_K 8
-#endif
-constexpr int kSmallK = PPQHIP_HIST_SMALL_K;
-template <bool ASYM, bool CLIP>
+template <bool ASYM, bool CLIP, int kSmallK>       // kSmallK: loads in flight per lane = rows of a share fetched at once (2 | 4 | 8)
 __global__ __launch_bounds__(kHistBlock) void hist_small_kernel(const float* __restrict__ x, uint32_t n, float a, float hs, int bins,
                                                                  int copies, int* __restrict__ dst, int own_row) {
     extern __shared__ int lds[];
     const uint32_t G = gridDim.x, g = blockIdx.x;
     const uint32_t nvec = n >> 2;
     const uint32_t full_rows = nvec / kHistBlock;                     // rows of kHistBlock float4 in which every lane has one
-    const uint32_t r0 = (uint32_t)(((uint64_t)g * full_rows) / G), r1 = (uint32_t)(((uint64_t)(g + 1) * full_rows) / G);
+    uint32_t r0, r1;
+    even_split(full_rows, G, g, r0, r1);
     const float4* xv = reinterpret_cast<const float4*>(x) + threadIdx.x;
     Binner<ASYM, CLIP, true> acc;
     acc.init(lds + ((threadIdx.x >> 6) % copies) * bins, bins);
@@ -351,9 +356,10 @@ __global__ __launch_bounds__(kHistBlock) void hist_small_kernel(const float* __r
     for (uint32_t r = r0; r < r1; r += kSmallK) {
         float4 buf[kSmallK];
         const uint32_t cnt = min((uint32_t)kSmallK, r1 - r);          // workgroup uniform
+        // straight-line loads with a clamped row index (the last row of the share is fetched again instead of branching): a
+        // load under `if (k < cnt)` lands in its own basic block and the compiler waits for ALL earlier loads in front of it
 #pragma unroll
-        for (int k = 0; k < kSmallK; k++)
-            if ((uint32_t)k < cnt) buf[k] = xv[(size_t)(r + k) * kHistBlock];
+        for (int k = 0; k < kSmallK; k++) buf[k] = xv[(size_t)min(r + (uint32_t)k, r1 - 1) * kHistBlock];
         zero_lds();
 #pragma unroll
         for (int k = 0; k < kSmallK; k++) {
@@ -423,21 +429,27 @@ __global__ __launch_bounds__(kBlock) void hist_t_global_kernel(const float* __re
 #ifndef PPQHIP_HIST_C_WGPC
 #define PPQHIP_HIST_C_WGPC 1             // workgroups per CU a launch should have before channels stop being split
 #endif
-template <bool ASYM, bool CLIP>
+template <bool ASYM, bool CLIP, bool NT>
 __global__ __launch_bounds__(kHistBlock, (kHistBlock * kHistWgPerCu + 255) / 256)
 void hist_c_channel_kernel(const float* __restrict__ x, FastDiv vec_per_row, uint32_t C, uint32_t outer, uint32_t splits,
                            BinRule rule, int copies, int* __restrict__ hist, const float* __restrict__ scales,
-                           const float* __restrict__ mins, const float* __restrict__ maxs) {
+                           const float* __restrict__ mins, const float* __restrict__ maxs, int flush_mode) {
     extern __shared__ int lds[];
     const int bins = rule.bins;
-    for (int i = threadIdx.x; i < copies * bins; i += kHistBlock) lds[i] = 0;
-    __syncthreads();
+    bool zeroed = false;                  // zeroed behind the first tile's loads (see hist_persistent_kernel)
+    auto zero_lds = [&]() {
+        if (zeroed) return;
+        for (int i = threadIdx.x; i < copies * bins; i += kHistBlock) lds[i] = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        zeroed = true;
+    };
     const uint32_t c = blockIdx.x % C, sp = blockIdx.x / C;
     const uint32_t vpr = vec_per_row.d;
     // the channel's rows as ONE virtual float4 range [0, outer * vpr); split `sp` owns [v0, v0 + V) of it
     const uint32_t all = outer * vpr;
-    const uint32_t v0 = (uint32_t)(((uint64_t)sp * all) / splits);
-    const uint32_t V = (uint32_t)(((uint64_t)(sp + 1) * all) / splits) - v0;
+    uint32_t v0, v_end;
+    even_split(all, splits, sp, v0, v_end);
+    const uint32_t V = v_end - v0;
     Binner<ASYM, CLIP, true> acc;
     acc.init(lds + ((threadIdx.x >> 6) % copies) * bins, bins);
     if (ASYM) acc.set_rule(mins[c], (maxs[c] - mins[c]) / (float)bins);      // per-channel range (hist_scale as in sort.cu:123)
@@ -453,7 +465,7 @@ void hist_c_channel_kernel(const float* __restrict__ x, FastDiv vec_per_row, uin
         float4 bufa[kHistU], bufb[kHistU];
         auto fetch = [&](float4 (&buf)[kHistU], uint32_t tile) {
 #pragma unroll
-            for (int u = 0; u < kHistU; u++) buf[u] = *at(tile * kTileVec + u * kHistBlock + threadIdx.x);
+            for (int u = 0; u < kHistU; u++) buf[u] = load4<NT>(at(tile * kTileVec + u * kHistBlock + threadIdx.x));
         };
         auto consume = [&](const float4 (&buf)[kHistU]) {
 #pragma unroll
@@ -470,6 +482,7 @@ void hist_c_channel_kernel(const float* __restrict__ x, FastDiv vec_per_row, uin
         };
         uint32_t k = 0;
         fetch(bufa, k);
+        zero_lds();
         for (;;) {
             fetch(bufb, min(k + 1, tiles - 1));
             consume(bufa);
@@ -479,6 +492,7 @@ void hist_c_channel_kernel(const float* __restrict__ x, FastDiv vec_per_row, uin
             if (++k >= tiles) break;
         }
     }
+    zero_lds();
     for (uint32_t v = tiles * kTileVec + threadIdx.x, t = 0; t < kHistU; t++, v += kHistBlock) {   // the ragged rest (< one tile)
         const bool in = v < V;                                             // wave-uniform trip count, masked lanes
         const float4 a = in ? *at(v) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -489,7 +503,7 @@ void hist_c_channel_kernel(const float* __restrict__ x, FastDiv vec_per_row, uin
         acc.template commit<false>(b[2], in); acc.template commit<false>(b[3], in);
     }
     acc.flush_hot();
-    lds_hist_flush(lds, bins, copies, hist + (size_t)c * bins, splits == 1 ? FLUSH_ROWS_ADD : FLUSH_ATOMIC);
+    lds_hist_flush(lds, bins, copies, hist + (size_t)c * bins, flush_mode);
 }
 
 // the same ownership for rows that are not float4-addressable (elem_per_channel % 4 != 0: the 7 x 7 planes of a CNN's last
@@ -506,8 +520,9 @@ __global__ __launch_bounds__(kHistBlock) void hist_c_channel_scalar_kernel(
     const uint32_t c = blockIdx.x % C, sp = blockIdx.x / C;
     const uint32_t epc = elem_per_row.d;
     const uint32_t all = outer * epc;
-    const uint32_t v0 = (uint32_t)(((uint64_t)sp * all) / splits);
-    const uint32_t V = (uint32_t)(((uint64_t)(sp + 1) * all) / splits) - v0;
+    uint32_t v0, v_end;
+    even_split(all, splits, sp, v0, v_end);
+    const uint32_t V = v_end - v0;
     Binner<ASYM, CLIP, true> acc;
     acc.init(lds + ((threadIdx.x >> 6) % copies) * bins, bins);
     if (ASYM) acc.set_rule(mins[c], (maxs[c] - mins[c]) / (float)bins);
@@ -565,7 +580,7 @@ static int pick_copies(int bins, int block) {
 static size_t lds_bytes(int bins, int copies) { return sizeof(int) * (size_t)copies * bins; }
 
 static void launch_reduce(const int* partial, int grid, int bins, int32_t* hist, hipStream_t s) {
-    hipLaunchKernelGGL(hist_reduce_kernel, dim3((bins + kBlock - 1) / kBlock, kReduceSlices), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL(hist_reduce_kernel, dim3((bins + kReduceBins - 1) / kReduceBins), dim3(kReduceBlock), 0, s,
                        partial, grid, bins, hist);
 }
 
@@ -638,9 +653,16 @@ static bool launch_hist_small(const float* x, int64_t n, BinRule rule, int32_t* 
     const int copies = pick_copies(rule.bins, kHistBlock);
     int* dst = rows ? rows : hist;
     const int own = rows ? 1 : 0;
-#define PPQ_LAUNCH_HIST_SMALL(A, C)                                                                                   \
-    hipLaunchKernelGGL((hist_small_kernel<A, C>), dim3(g), dim3(kHistBlock), lds_bytes(rule.bins, copies), s, x,     \
+    const uint32_t share = (full_rows + g - 1) / g;                         // rows of the largest share: all of them in flight when <= 8
+#define PPQ_LAUNCH_HIST_SMALL_K(A, C, K)                                                                              \
+    hipLaunchKernelGGL((hist_small_kernel<A, C, K>), dim3(g), dim3(kHistBlock), lds_bytes(rule.bins, copies), s, x,  \
                        (uint32_t)n, rule.a, rule.hs, rule.bins, copies, dst, own)
+#define PPQ_LAUNCH_HIST_SMALL(A, C)                                                                                   \
+    do {                                                                                                              \
+        if (share <= 2) PPQ_LAUNCH_HIST_SMALL_K(A, C, 2);                                                             \
+        else if (share <= 4) PPQ_LAUNCH_HIST_SMALL_K(A, C, 4);                                                        \
+        else PPQ_LAUNCH_HIST_SMALL_K(A, C, 8);                                                                        \
+    } while (0)
     switch ((rule.asym ? 2 : 0) | (rule.clip ? 1 : 0)) {
         case 0: PPQ_LAUNCH_HIST_SMALL(false, false); break;
         case 1: PPQ_LAUNCH_HIST_SMALL(false, true); break;
@@ -648,6 +670,7 @@ static bool launch_hist_small(const float* x, int64_t n, BinRule rule, int32_t* 
         default: PPQ_LAUNCH_HIST_SMALL(true, true); break;
     }
 #undef PPQ_LAUNCH_HIST_SMALL
+#undef PPQ_LAUNCH_HIST_SMALL_K
     return true;
 }
 
@@ -815,9 +838,19 @@ static int hist_c_impl(const float* x, int64_t n, int64_t num_channel, int64_t e
         const uint64_t tiles_per_channel = ((uint64_t)outer * (uint64_t)(elem_per_channel / 4)) / kTileVec;      // a split should have >= 1 full tile
         if (splits > tiles_per_channel) splits = tiles_per_channel > 0 ? (uint32_t)tiles_per_channel : 1u;
         const int copies = pick_copies(rule.bins, kHistBlock);
+        // a channel's only workgroup adds with plain read-modify-writes when the launch is HBM bound; on a latency-bound
+        // tensor the (uncontended) atomic form keeps the read of the counter row out of the dependent chain
+        const int flush_mode = (splits == 1 && n > PPQHIP_HIST_SMALL_ELEMS) ? FLUSH_ROWS_ADD : FLUSH_ATOMIC;
+        const bool nt = n >= PPQHIP_HIST_NT_ELEMS;      // streaming loads beyond cache residency, as in the per-tensor kernel
 #define PPQ_LAUNCH_HIST_CC(A, CL)                                                                                     \
-        hipLaunchKernelGGL((hist_c_channel_kernel<A, CL>), dim3(C * splits), dim3(kHistBlock), lds_bytes(rule.bins, copies), s, x, \
-                           make_fastdiv((uint32_t)(elem_per_channel / 4)), C, outer, splits, rule, copies, hist, scales, mins, maxs)
+        do {                                                                                                          \
+            if (nt) hipLaunchKernelGGL((hist_c_channel_kernel<A, CL, true>), dim3(C * splits), dim3(kHistBlock), lds_bytes(rule.bins, copies), s, x, \
+                           make_fastdiv((uint32_t)(elem_per_channel / 4)), C, outer, splits, rule, copies, hist, scales, mins, maxs, \
+                           flush_mode);                                                                               \
+            else hipLaunchKernelGGL((hist_c_channel_kernel<A, CL, false>), dim3(C * splits), dim3(kHistBlock), lds_bytes(rule.bins, copies), s, x, \
+                           make_fastdiv((uint32_t)(elem_per_channel / 4)), C, outer, splits, rule, copies, hist, scales, mins, maxs, \
+                           flush_mode);                                                                               \
+        } while (0)
         switch ((asym ? 2 : 0) | (rule.clip ? 1 : 0)) {
             case 0: PPQ_LAUNCH_HIST_CC(false, false); break;
             case 1: PPQ_LAUNCH_HIST_CC(false, true); break;

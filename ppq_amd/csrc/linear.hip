@@ -38,9 +38,12 @@ __global__ __launch_bounds__(kBlock) void fq_linear_t_tile_kernel(
     const float s = scale[0];
     const int o = round_offset(offset[0]);
     const float rc = fq_safe_rcp(s);
+    // the arithmetic is unconditional (lanes past the end recompute the clamped element), only the STORE is predicated: with
+    // the whole body under `if (v < nvec)` the compiler sinks the loads into the branch, behind the wait for the scale
 #pragma unroll
     for (int k = 0; k < U; k++) {
-        if (base + k * kBlock < nvec) out[base + k * kBlock] = fq_linear4<R>(a[k], s, rc, o, qmin, qmax, rounding);
+        const float4 r = fq_linear4<R>(a[k], s, rc, o, qmin, qmax, rounding);
+        if (base + k * kBlock < nvec) out[base + k * kBlock] = r;
     }
     if (blockIdx.x == 0 && (int)threadIdx.x < ntail)
         otail[threadIdx.x] = fq_linear_scalar<R>(xtail[threadIdx.x], s, o, qmin, qmax, rounding);
@@ -66,10 +69,13 @@ __global__ __launch_bounds__(kBlock) void fq_linear_c_tile_kernel(
             o[k] = round_offset(offset[c]);
         }
     }
+    // unconditional arithmetic, predicated store: under `if (vv < nvec)` the compiler sinks the tile's x / scale loads into the
+    // branch, BEHIND the wait for the offsets (two dependent memory round trips on a latency-bound tensor)
 #pragma unroll
     for (int k = 0; k < U; k++) {
         const uint32_t vv = base + k * kBlock;
-        if (vv < nvec) out[vv] = fq_linear4<R>(a[k], s[k], fq_safe_rcp(s[k]), o[k], qmin, qmax, rounding);
+        const float4 r = fq_linear4<R>(a[k], s[k], fq_safe_rcp(s[k]), o[k], qmin, qmax, rounding);
+        if (vv < nvec) out[vv] = r;
     }
 }
 
@@ -154,36 +160,10 @@ __global__ __launch_bounds__(kBlock) void to_int_kernel(const float* __restrict_
     }
 }
 
-// 1-byte outputs: 16 consecutive elements per lane -- four 16-B loads, ONE 16-B store (a 4-B store per lane writes 256 B per
-// wave instruction: 0.62 of the roofline on [32, 512, 56, 56]; this form 16 x that per instruction).  elem_per_channel % 16 == 0.
-template <typename OUT, bool CHANNEL>
-__global__ __launch_bounds__(kBlock) void to_int8_x16_kernel(const float* __restrict__ x, const float* __restrict__ scale,
-                                                             const float* __restrict__ offset, OUT* __restrict__ out, uint32_t n16,
-                                                             FastDiv elem_per_channel, FastDiv num_channel, float qmin, float qmax,
-                                                             int rounding) {
-    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;           // group of 16 elements
-    if (g >= n16) return;
-    const uint32_t i0 = g * 16u;
-    uint32_t c = 0;
-    if (CHANNEL) { const uint32_t row = fdiv(i0, elem_per_channel); c = row - fdiv(row, num_channel) * num_channel.d; }
-    const float s = scale[c], o = offset[c];
-    const float4* xv = reinterpret_cast<const float4*>(x + i0);
-    float4 a[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) a[u] = xv[u];
-    uint32_t w[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const int q0 = to_int_scalar(a[u].x, s, o, qmin, qmax, rounding), q1 = to_int_scalar(a[u].y, s, o, qmin, qmax, rounding);
-        const int q2 = to_int_scalar(a[u].z, s, o, qmin, qmax, rounding), q3 = to_int_scalar(a[u].w, s, o, qmin, qmax, rounding);
-        w[u] = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
-    }
-    *reinterpret_cast<uint4*>(out + i0) = make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-// The same conversion with COALESCED loads: lane l of a workgroup reads float4 number base + l + u * kBlock (a wave reads
-// 1 KiB contiguous per instruction, U of them in flight; the x16 kernel above makes every lane walk its own 64-B segment, four
-// partial touches of each cache line) and writes the 4 bytes of each float4 as one dword: 256 B contiguous per wave and store.
+// 1-byte outputs with COALESCED loads: lane l of a workgroup reads float4 number base + l + u * kBlock (a wave reads 1 KiB
+// contiguous per instruction, U of them in flight) and writes the 4 bytes of each float4 as one dword: 256 B contiguous per
+// wave and store.  (Round 3's form -- 16 consecutive elements per lane, one 16-B store -- made every lane walk its own 64-B
+// segment, four partial touches of each cache line: 0.69 of the roofline against 0.77; removed in round 5.)
 // Streaming (nontemporal) loads when the tensor exceeds cache residency.
 template <typename OUT, bool CHANNEL, bool NT>
 __global__ __launch_bounds__(kBlock) void to_int8_vec_kernel(const float4* __restrict__ x, const float* __restrict__ scale,
@@ -263,30 +243,36 @@ __global__ __launch_bounds__(kBlock) void fq_linear_t_bwd_kernel(
     const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ partial, uint32_t n, int vec_ok,
     int qmin, int qmax, int rounding) {
     __shared__ float lds[kBlock / kWave];
+    float acc = 0.f;
+    uint32_t done = 0;
+    constexpr int U = PPQHIP_LSQ_U;
+    const uint32_t nvec = n >> 2;
+    const float4* xv = reinterpret_cast<const float4*>(x);
+    const float4* dv = reinterpret_cast<const float4*>(dy);
+    float4* gv = reinterpret_cast<float4*>(gx);
+    const uint32_t tile = kBlock * U;
+    const uint32_t tiles = (nvec + tile - 1) / tile;
+    const uint32_t per = (tiles + gridDim.x - 1) / gridDim.x;
+    const uint32_t lo = blockIdx.x * per * tile;
+    const uint32_t hi = min(lo + per * tile, nvec);
+    // the first tile's 2 U loads are issued BEFORE scale / offset are read (two dependent scalar loads and a division would
+    // otherwise sit in front of them: on the 0.05 .. 6 MB activations of a block-wise LSQ step the launch is one latency chain)
+    float4 a[U], d[U];
+    uint32_t v = lo + threadIdx.x;
+    const bool any = vec_ok && v < hi;
+    if (any) {
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t at = min(v + u * kBlock, hi - 1);              // clamped: loads stay unconditional
+            a[u] = load4<NT>(&xv[at]); d[u] = load4<NT>(&dv[at]);
+        }
+    }
     const float s = scale[0];
     const float rcp_s = 1.0f / s;
     const float o = __builtin_roundf(offset[0]);
     const int oi = f2i_sat(o);
-    float acc = 0.f;
-    uint32_t done = 0;
     if (vec_ok) {
-        constexpr int U = PPQHIP_LSQ_U;
-        const uint32_t nvec = n >> 2;
-        const float4* xv = reinterpret_cast<const float4*>(x);
-        const float4* dv = reinterpret_cast<const float4*>(dy);
-        float4* gv = reinterpret_cast<float4*>(gx);
-        const uint32_t tile = kBlock * U;
-        const uint32_t tiles = (nvec + tile - 1) / tile;
-        const uint32_t per = (tiles + gridDim.x - 1) / gridDim.x;
-        const uint32_t lo = blockIdx.x * per * tile;
-        const uint32_t hi = min(lo + per * tile, nvec);
-        for (uint32_t v = lo + threadIdx.x; v < hi; v += tile) {
-            float4 a[U], d[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) {
-                const uint32_t at = min(v + u * kBlock, hi - 1);          // clamped: loads stay unconditional
-                a[u] = load4<NT>(&xv[at]); d[u] = load4<NT>(&dv[at]);
-            }
+        while (v < hi) {
 #pragma unroll
             for (int u = 0; u < U; u++) {
                 if (v + u * kBlock >= hi) break;
@@ -296,6 +282,14 @@ __global__ __launch_bounds__(kBlock) void fq_linear_t_bwd_kernel(
                 acc += lsq_bwd_elem<false, R>(a[u].z, d[u].z, s, rcp_s, o, oi, qmin, qmax, rounding, &g.z);
                 acc += lsq_bwd_elem<false, R>(a[u].w, d[u].w, s, rcp_s, o, oi, qmin, qmax, rounding, &g.w);
                 gv[v + u * kBlock] = g;
+            }
+            v += tile;
+            if (v < hi) {                                                  // (grids are sized one tile per workgroup: rarely taken)
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const uint32_t at = min(v + u * kBlock, hi - 1);
+                    a[u] = load4<NT>(&xv[at]); d[u] = load4<NT>(&dv[at]);
+                }
             }
         }
         done = nvec << 2;
@@ -333,6 +327,37 @@ __global__ __launch_bounds__(kLsqFinishBlock) void lsq_finish_kernel(const float
         double t = 0.0;
         for (int w = 0; w < kLsqFinishBlock / kWave; w++) t += lds[w];
         gs[0] = (float)t * grad_factor;
+    }
+}
+
+// the same sum for MANY scale gradients in one launch: workgroup j finishes job j exactly as lsq_finish_kernel would (same
+// lanes, same order, same double accumulation -> bit-identical).  A block-wise LSQ step back-propagates through 5-10 activation
+// delegators; each main kernel leaves its partials in a caller-owned buffer and ONE launch at the end of the sweep turns them
+// into the scale gradients (scales are autograd leaves: nothing further back waits for them).
+constexpr int kLsqFinishMax = 96;
+struct LsqFinishJob { const float* partial; float* gs; uint32_t count; float grad_factor; };      // 24 B
+struct LsqFinishArgs { LsqFinishJob job[kLsqFinishMax]; };
+__global__ __launch_bounds__(kLsqFinishBlock) void lsq_finish_multi_kernel(const LsqFinishArgs args) {
+    __shared__ double lds[kLsqFinishBlock / kWave];
+    const LsqFinishJob& j = args.job[blockIdx.x];
+    const float* __restrict__ partial = j.partial;
+    const uint32_t count = j.count;
+    double acc = 0.0;
+    for (uint32_t i = threadIdx.x; i < count; i += 8 * kLsqFinishBlock) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const uint32_t at = i + u * kLsqFinishBlock; v[u] = at < count ? partial[at] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += (double)v[u];
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) acc += __shfl_xor(acc, m, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int w = 0; w < kLsqFinishBlock / kWave; w++) t += lds[w];
+        j.gs[0] = (float)t * j.grad_factor;
     }
 }
 
@@ -448,10 +473,22 @@ static int validate_channels(int64_t n, int64_t C, int64_t epc, const char* what
 // Tensors of at least kStreamElems elements (192 MiB) cannot be resident in the 256 MiB Infinity
 // Cache together with their output: read them with streaming (nontemporal) loads.
 constexpr int64_t kStreamElems = 48ll << 20;
+// Tile shape: U 16-B accesses per lane and workgroup.  HBM-bound tensors stream best with U = 2 (half as many workgroups to
+// dispatch); a tensor of a few MB is ONE latency chain (dispatch -> loads -> arithmetic -> stores) in which the arithmetic of
+// the last-arriving wave is exposed, so U = 1 (twice the waves, half the work behind each load) is 0.2 us faster on
+// B = [1,512,56,56]: 4.28 -> 4.08 us per tensor, 4.44 -> 4.24 per channel (rocprofv3 medians, interleaved A/B,
+// profiles/r05_floor_table.txt); the copy floor of the same 12.8 MB is 3.88 us.
 #ifndef PPQHIP_FQ_U
 #define PPQHIP_FQ_U 2
 #endif
+#ifndef PPQHIP_FQ_SMALL_U
+#define PPQHIP_FQ_SMALL_U 1
+#endif
+#ifndef PPQHIP_FQ_SMALL_ELEMS
+#define PPQHIP_FQ_SMALL_ELEMS (4ll << 20)      // up to 16 MB in + 16 MB out
+#endif
 constexpr int kTileU = PPQHIP_FQ_U;
+constexpr int kSmallU = PPQHIP_FQ_SMALL_U;
 
 template <int R>
 static void launch_lt(const float* x, const float* scale, const float* offset, float* out, int64_t n,
@@ -461,13 +498,13 @@ static void launch_lt(const float* x, const float* scale, const float* offset, f
         const int ntail = (int)(n & 3);
         const float* xt = x + (size_t)nvec * 4;
         float* ot = out + (size_t)nvec * 4;
-        const dim3 grid((nvec + kBlock * kTileU - 1) / (kBlock * kTileU));
-        if (n >= kStreamElems)
-            hipLaunchKernelGGL((fq_linear_t_tile_kernel<R, kTileU, true>), grid, dim3(kBlock), 0, st, (const float4*)x,
-                               scale, offset, (float4*)out, nvec, xt, ot, ntail, qmin, qmax, rounding);
-        else
-            hipLaunchKernelGGL((fq_linear_t_tile_kernel<R, kTileU, false>), grid, dim3(kBlock), 0, st, (const float4*)x,
-                               scale, offset, (float4*)out, nvec, xt, ot, ntail, qmin, qmax, rounding);
+#define PPQ_LAUNCH_LT(U, NT)                                                                                          \
+        hipLaunchKernelGGL((fq_linear_t_tile_kernel<R, U, NT>), dim3((nvec + kBlock * U - 1) / (kBlock * U)), dim3(kBlock), 0, st, \
+                           (const float4*)x, scale, offset, (float4*)out, nvec, xt, ot, ntail, qmin, qmax, rounding)
+        if (n >= kStreamElems) PPQ_LAUNCH_LT(kTileU, true);
+        else if (n <= PPQHIP_FQ_SMALL_ELEMS) PPQ_LAUNCH_LT(kSmallU, false);
+        else PPQ_LAUNCH_LT(kTileU, false);
+#undef PPQ_LAUNCH_LT
     } else {
         hipLaunchKernelGGL((fq_linear_t_scalar_kernel<R>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, x,
                            scale, offset, out, (uint32_t)n, qmin, qmax, rounding);
@@ -480,13 +517,13 @@ static void launch_lc(const float* x, const float* scale, const float* offset, f
     if (aligned16(x) && aligned16(out) && (epc % 4 == 0)) {
         const uint32_t nvec = (uint32_t)(n >> 2);
         const FastDiv vpc = make_fastdiv((uint32_t)(epc / 4)), nc = make_fastdiv((uint32_t)C);
-        const dim3 grid((nvec + kBlock * kTileU - 1) / (kBlock * kTileU));
-        if (n >= kStreamElems)
-            hipLaunchKernelGGL((fq_linear_c_tile_kernel<R, kTileU, true>), grid, dim3(kBlock), 0, st, (const float4*)x,
-                               scale, offset, (float4*)out, nvec, vpc, nc, qmin, qmax, rounding);
-        else
-            hipLaunchKernelGGL((fq_linear_c_tile_kernel<R, kTileU, false>), grid, dim3(kBlock), 0, st, (const float4*)x,
-                               scale, offset, (float4*)out, nvec, vpc, nc, qmin, qmax, rounding);
+#define PPQ_LAUNCH_LC(U, NT)                                                                                          \
+        hipLaunchKernelGGL((fq_linear_c_tile_kernel<R, U, NT>), dim3((nvec + kBlock * U - 1) / (kBlock * U)), dim3(kBlock), 0, st, \
+                           (const float4*)x, scale, offset, (float4*)out, nvec, vpc, nc, qmin, qmax, rounding)
+        if (n >= kStreamElems) PPQ_LAUNCH_LC(kTileU, true);
+        else if (n <= PPQHIP_FQ_SMALL_ELEMS) PPQ_LAUNCH_LC(kSmallU, false);
+        else PPQ_LAUNCH_LC(kTileU, false);
+#undef PPQ_LAUNCH_LC
     } else {
         const FastDiv e = make_fastdiv((uint32_t)epc), nc = make_fastdiv((uint32_t)C);
         hipLaunchKernelGGL((fq_linear_c_scalar_kernel<R>), dim3(stream_grid(n, kBlock)), dim3(kBlock), 0, st, x,
@@ -550,7 +587,8 @@ __global__ __launch_bounds__(kBlock) void fq_linear_multi_kernel(const FqMultiAr
 #pragma unroll
         for (int k = 0; k < U; k++) {
             const uint32_t vv = base + k * kBlock;
-            if (vv < nvec) ov[vv] = fq_linear4<R>(a[k], s[k], fq_safe_rcp(s[k]), o[k], j.qmin, j.qmax, args.rounding);
+            const float4 r = fq_linear4<R>(a[k], s[k], fq_safe_rcp(s[k]), o[k], j.qmin, j.qmax, args.rounding);
+            if (vv < nvec) ov[vv] = r;
         }
     } else {
 #pragma unroll
@@ -761,9 +799,6 @@ static int to_int_impl(const float* x, const float* scale, const float* offset, 
     const FastDiv e = make_fastdiv((uint32_t)(channel ? epc : 1)), nc = make_fastdiv((uint32_t)(channel ? C : 1));
     const dim3 grid((uint32_t)((n + kBlock * 4 - 1) / (kBlock * 4)));
     const float qmin = (float)clip_min, qmax = (float)clip_max;
-    // 1-byte outputs, 16-B aligned both ways, channels in whole groups of 16: the bulk goes through the 16-per-lane kernel,
-    // the (< 16 element) rest through the general one
-#ifndef PPQHIP_TOINT_X16
     // 1-byte outputs, 16-B aligned input, 4-B aligned output, channels in whole float4s: the coalesced kernel takes n / 4 groups,
     // the (< 4 element) rest goes through the general one
     if (out_dtype != 2 && aligned16(x) && (reinterpret_cast<uintptr_t>(out) % 4 == 0) && (!channel || epc % 4 == 0) && n >= 4) {
@@ -787,22 +822,6 @@ static int to_int_impl(const float* x, const float* scale, const float* offset, 
                                          out_dtype, false, stream, what);
         set_error("%s: internal: ragged tail with channels", what); return PPQHIP_ERR_INVALID_VALUE;      // n % (C * epc) == 0 and epc % 4 == 0
     }
-#endif
-    if (out_dtype != 2 && aligned16(x) && aligned16(out) && (!channel || epc % 16 == 0) && n >= 16) {
-        const uint32_t n16 = (uint32_t)(n / 16);
-        const dim3 g16((n16 + kBlock - 1) / kBlock);
-#define PPQ_LAUNCH_TOINT16(T, CH) hipLaunchKernelGGL((to_int8_x16_kernel<T, CH>), g16, dim3(kBlock), 0, s, x, scale, offset, (T*)out, \
-                                                     n16, e, nc, qmin, qmax, rounding)
-        if (out_dtype == 0) { if (channel) PPQ_LAUNCH_TOINT16(int8_t, true); else PPQ_LAUNCH_TOINT16(int8_t, false); }
-        else { if (channel) PPQ_LAUNCH_TOINT16(uint8_t, true); else PPQ_LAUNCH_TOINT16(uint8_t, false); }
-#undef PPQ_LAUNCH_TOINT16
-        const int64_t done = (int64_t)n16 * 16;
-        if (done == n) return finish_launch(what);
-        // the rest: per-tensor (or the tail's own channel: elements [done, n) continue the last row)
-        if (!channel) return to_int_impl(x + done, scale, offset, (uint8_t*)out + done, n - done, 1, n - done, clip_min, clip_max, rounding,
-                                         out_dtype, false, stream, what);
-        set_error("%s: internal: ragged tail with channels", what); return PPQHIP_ERR_INVALID_VALUE;      // n % (C * epc) == 0 and epc % 16 == 0
-    }
 #define PPQ_LAUNCH_TOINT(T, CH) hipLaunchKernelGGL((to_int_kernel<T, CH>), grid, dim3(kBlock), 0, s, x, scale, offset, (T*)out, \
                                                    (uint32_t)n, vec_ok, e, nc, qmin, qmax, rounding)
     if (out_dtype == 0) { if (channel) PPQ_LAUNCH_TOINT(int8_t, true); else PPQ_LAUNCH_TOINT(int8_t, false); }
@@ -823,6 +842,54 @@ int ppqhip_to_int_c(const float* x, const float* scale, const float* offset, voi
                        "to_int_c");
 }
 
+static int lsq_t_grid(int64_t n) { return stream_grid(n, kBlock * 4 * PPQHIP_LSQ_U, PPQHIP_LSQ_MAX_WG); }
+
+static void launch_lsq_t_main(const float* x, const float* scale, const float* offset, const float* grad_y, float* grad_x,
+                              float* partial, int64_t n, int grid, int clip_min, int clip_max, int rounding, hipStream_t s) {
+    const int vec_ok = (aligned16(x) && aligned16(grad_y) && aligned16(grad_x)) ? 1 : 0;
+    const bool nt = n >= kStreamElems / 2;       // x and dy together exceed cache residency: streaming loads
+#define PPQ_LAUNCH_LSQ_T(R, NT)                                                                                     \
+    hipLaunchKernelGGL((fq_linear_t_bwd_kernel<R, NT>), dim3(grid), dim3(kBlock), 0, s, x, scale, offset, grad_y,   \
+                       grad_x, partial, (uint32_t)n, vec_ok, clip_min, clip_max, rounding)
+    if (rounding == ROUND_HALF_EVEN) { if (nt) PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, true); else PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, false); }
+    else { if (nt) PPQ_LAUNCH_LSQ_T(-1, true); else PPQ_LAUNCH_LSQ_T(-1, false); }
+#undef PPQ_LAUNCH_LSQ_T
+}
+
+int64_t ppqhip_fq_linear_t_bwd_partials(int64_t n) { return n > 0 && n <= 0x7fffffffLL ? (int64_t)lsq_t_grid(n) : 0; }
+
+int ppqhip_fq_linear_t_bwd_main(const float* x, const float* scale, const float* offset, const float* grad_y, float* grad_x,
+                                float* partial, int64_t n, int clip_min, int clip_max, int rounding, void* stream) {
+    if (int st = validate_n(n, "fq_linear_t_bwd_main")) return st;
+    if (partial == nullptr) { set_error("fq_linear_t_bwd_main: partial is null"); return PPQHIP_ERR_INVALID_VALUE; }
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope scope(K_FQ_LINEAR_T_BWD, 12.0 * (double)n, s);
+    launch_lsq_t_main(x, scale, offset, grad_y, grad_x, partial, n, lsq_t_grid(n), clip_min, clip_max, rounding, s);
+    return finish_launch("fq_linear_t_bwd_main");
+}
+
+int ppqhip_lsq_finish_multi(const ppqhip_lsq_finish_job* jobs, int num_jobs, void* stream) {
+    if (num_jobs <= 0) return PPQHIP_OK;
+    if (jobs == nullptr) { set_error("lsq_finish_multi: jobs is null"); return PPQHIP_ERR_INVALID_VALUE; }
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < num_jobs; base += kLsqFinishMax) {
+        const int count = (num_jobs - base) < kLsqFinishMax ? (num_jobs - base) : kLsqFinishMax;
+        LsqFinishArgs args;
+        for (int k = 0; k < count; k++) {
+            const ppqhip_lsq_finish_job& src = jobs[base + k];
+            if (int st = validate_n(src.n, "lsq_finish_multi")) return st;
+            if (!src.partial || !src.grad_s) { set_error("lsq_finish_multi: job %d has a null pointer", base + k); return PPQHIP_ERR_INVALID_VALUE; }
+            args.job[k].partial = src.partial; args.job[k].gs = src.grad_s;
+            args.job[k].count = (uint32_t)lsq_t_grid(src.n);
+            // rsqrtf(((double)n * (clip_max - clip_min))): linear.cu:299
+            args.job[k].grad_factor = (float)(1.0 / sqrt((double)src.n * (double)(src.clip_max - src.clip_min)));
+        }
+        for (int k = count; k < kLsqFinishMax; k++) args.job[k] = args.job[0];
+        hipLaunchKernelGGL(lsq_finish_multi_kernel, dim3(count), dim3(kLsqFinishBlock), 0, s, args);
+    }
+    return finish_launch("lsq_finish_multi");
+}
+
 int ppqhip_fq_linear_t_bwd(const float* x, const float* scale, const float* offset, const float* grad_y,
                            float* grad_x, float* grad_s, int64_t n, int clip_min, int clip_max,
                            int rounding, void* stream) {
@@ -836,17 +903,10 @@ int ppqhip_fq_linear_t_bwd(const float* x, const float* scale, const float* offs
     // the forward tile kernels).  Measured again in round 3 with ping-pong register tiles and the partial sum folded into
     // the launch (last workgroup, sharded tickets): 512 x 2 / CU 120 us, 512 x 4 122, 256 x 8 125, U = 4 124 -- against
     // 107 us for this kernel + its finish launch (profiles/r03_lsq_variants.txt)
-    const int grid = stream_grid(n, kBlock * 4 * PPQHIP_LSQ_U, PPQHIP_LSQ_MAX_WG);
+    const int grid = lsq_t_grid(n);
     float* partial = (float*)scratch(s, sizeof(float) * (size_t)grid);
     if (partial == nullptr) return PPQHIP_ERR_HIP;
-    const int vec_ok = (aligned16(x) && aligned16(grad_y) && aligned16(grad_x)) ? 1 : 0;
-    const bool nt = n >= kStreamElems / 2;       // x and dy together exceed cache residency: streaming loads
-#define PPQ_LAUNCH_LSQ_T(R, NT)                                                                                     \
-    hipLaunchKernelGGL((fq_linear_t_bwd_kernel<R, NT>), dim3(grid), dim3(kBlock), 0, s, x, scale, offset, grad_y,   \
-                       grad_x, partial, (uint32_t)n, vec_ok, clip_min, clip_max, rounding)
-    if (rounding == ROUND_HALF_EVEN) { if (nt) PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, true); else PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, false); }
-    else { if (nt) PPQ_LAUNCH_LSQ_T(-1, true); else PPQ_LAUNCH_LSQ_T(-1, false); }
-#undef PPQ_LAUNCH_LSQ_T
+    launch_lsq_t_main(x, scale, offset, grad_y, grad_x, partial, n, grid, clip_min, clip_max, rounding, s);
     hipLaunchKernelGGL(lsq_finish_kernel, dim3(1), dim3(kLsqFinishBlock), 0, s, (const float*)partial, (uint32_t)grid,
                        grad_factor, grad_s);
     return finish_launch("fq_linear_t_bwd");

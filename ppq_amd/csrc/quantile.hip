@@ -382,8 +382,8 @@ __global__ __launch_bounds__(kBlock) void quantile_sample_kernel(const QSeq s) {
     __shared__ uint32_t h[kQ1], hr[kQ1];
     if (s.header[kGCold] == 0u) return;                    // every job has its hint: nothing to estimate
     const uint32_t G = gridDim.x, g = blockIdx.x;
-    uint32_t u = (uint32_t)(((uint64_t)g * s.total_units) / G);
-    const uint32_t u_end = (uint32_t)(((uint64_t)(g + 1) * s.total_units) / G);
+    uint32_t u, u_end;
+    even_split(s.total_units, G, g, u, u_end);
     if (u >= u_end) return;
     load_prefix(fu, s.first_unit, s.count);
     for (int i = threadIdx.x; i < kQ1; i += kBlock) { h[i] = 0; hr[i] = 0; }
@@ -581,8 +581,8 @@ void quantile_filter_kernel(const QSeq s) {
     __shared__ uint32_t ties[2];                  // keys seen == T_hi / == T_lo (this workgroup, this job)
     __shared__ uint32_t scratch[kQFBlock / kWave], stop[2], thr[3];
     const uint32_t G = gridDim.x, g = blockIdx.x;
-    uint32_t t = (uint32_t)(((uint64_t)g * s.total_tiles) / G);
-    const uint32_t t_end = (uint32_t)(((uint64_t)(g + 1) * s.total_tiles) / G);
+    uint32_t t, t_end;
+    even_split(s.total_tiles, G, g, t, t_end);
     if (t >= t_end) return;
     if (threadIdx.x < 2) { staged_n[threadIdx.x] = 0; ties[threadIdx.x] = 0; }
     if (s.count > 1) load_prefix(ft, s.first_tile, s.count);       // (a single job: no table to look anything up in)

@@ -97,8 +97,8 @@ template <bool NT>
 __global__ __launch_bounds__(kMMBlock) void minmax_persistent_kernel(const MinMaxJobs jobs) {
     __shared__ float lds[32];
     const uint32_t G = gridDim.x, g = blockIdx.x;
-    uint32_t t = (uint32_t)(((uint64_t)g * jobs.total_tiles) / G);
-    const uint32_t t_end = (uint32_t)(((uint64_t)(g + 1) * jobs.total_tiles) / G);
+    uint32_t t, t_end;
+    even_split(jobs.total_tiles, G, g, t, t_end);
     if (t >= t_end) return;
     uint32_t lo = 0, hi = jobs.count;
     while (hi - lo > 1) {

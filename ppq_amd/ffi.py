@@ -140,6 +140,7 @@ _FLOAT_SEARCH_JOB = np.dtype([('x', '<u8'), ('rows', '<i8'), ('row_len', '<i8'),
                               ('clip_min', '<f4'), ('clip_max', '<f4')])
 _LSQ_JOB = np.dtype([('x', '<u8'), ('scale', '<u8'), ('offset', '<u8'), ('grad_y', '<u8'), ('grad_x', '<u8'), ('grad_s', '<u8'),
                      ('n', '<i8'), ('num_channel', '<i8'), ('elem_per_channel', '<i8'), ('clip_min', '<i4'), ('clip_max', '<i4')])
+_LSQ_FINISH_JOB = np.dtype([('partial', '<u8'), ('grad_s', '<u8'), ('n', '<i8'), ('clip_min', '<i4'), ('clip_max', '<i4')])
 _MINMAX_C_JOB = np.dtype([('x', '<u8'), ('mins', '<u8'), ('maxs', '<u8'), ('n', '<i8'), ('num_channel', '<i8'),
                           ('elem_per_channel', '<i8'), ('fresh', '<i4'), ('reserved', '<i4')])
 _QUANTILE_JOB = np.dtype([('x', '<u8'), ('dest', '<u8'), ('hint', '<u8'), ('n', '<i8')])
@@ -367,6 +368,45 @@ class _HipExtension:
                                               grad_x.data_ptr(), grad_s.data_ptr(), v.numel(), int(clip_min),
                                               int(clip_max), int(rounding), _stream()))
         return [grad_x, grad_s]
+
+    @ staticmethod
+    def lsq_t_partials(numel: int) -> int:
+        """Floats ``QuantizeTensor_LT_B_Main`` writes into ``partial`` for a tensor of ``numel`` elements."""
+        return int(lib.ppqhip_fq_linear_t_bwd_partials(int(numel)))
+
+    @ staticmethod
+    def QuantizeTensor_LT_B_Main(value, scale, offset, grad_y, clip_min: int, clip_max: int, rounding: int, partial) -> torch.Tensor:
+        """First half of ``QuantizeTensor_LT_B`` (``ppqhip_fq_linear_t_bwd_main``): returns grad_x and leaves the per-workgroup
+        partial sums of the scale gradient in the caller-owned float32 ``partial`` (>= ``lsq_t_partials(numel)`` elements);
+        ``LSQ_Finish_Multi`` turns the partials of many tensors into their grad_s in ONE launch."""
+        _f32(value, 'Value'); _f32(scale, 'Scale'); _f32(offset, 'Offset'); _f32(grad_y, 'Gard'); _f32(partial, 'Partial')
+        v = value.contiguous(); g = grad_y.contiguous()
+        if partial.numel() < int(lib.ppqhip_fq_linear_t_bwd_partials(v.numel())) or not partial.is_contiguous():
+            raise RuntimeError(_KERNEL_FAILURE + 'QuantizeTensor_LT_B_Main: partial is too small (see lsq_t_partials)')
+        grad_x = torch.empty_like(g)
+        with _DeviceOf(v):
+            _raise(lib.ppqhip_fq_linear_t_bwd_main(v.data_ptr(), scale.data_ptr(), offset.data_ptr(), g.data_ptr(), grad_x.data_ptr(),
+                                                   partial.data_ptr(), v.numel(), int(clip_min), int(clip_max), int(rounding), _stream()))
+        return grad_x
+
+    @ staticmethod
+    def LSQ_Finish_Multi(partials, numels, clip_mins, clip_maxs, grad_ss) -> None:
+        """Second half for MANY tensors (``ppqhip_lsq_finish_multi``): ``grad_ss[k][0]`` = the scale gradient of tensor k, bit
+        for bit what ``QuantizeTensor_LT_B`` returns."""
+        n = len(partials)
+        if n == 0: return
+        if not (len(numels) == len(clip_mins) == len(clip_maxs) == len(grad_ss) == n):
+            raise RuntimeError(_KERNEL_FAILURE + 'LSQ_Finish_Multi: argument lists differ in length')
+        jobs = np.empty(n, dtype=_LSQ_FINISH_JOB)
+        for k in range(n):
+            _f32(partials[k], 'Partial'); _f32(grad_ss[k], 'Grad_s')
+            if partials[k].device != partials[0].device or grad_ss[k].device != partials[0].device:
+                raise RuntimeError(_KERNEL_FAILURE + 'LSQ_Finish_Multi: one device per call')
+            if partials[k].numel() < int(lib.ppqhip_fq_linear_t_bwd_partials(int(numels[k]))) or grad_ss[k].numel() < 1:
+                raise RuntimeError(_KERNEL_FAILURE + f'LSQ_Finish_Multi: item {k}: partial / grad_s too small')
+            jobs[k] = (partials[k].data_ptr(), grad_ss[k].data_ptr(), int(numels[k]), int(clip_mins[k]), int(clip_maxs[k]))
+        with _DeviceOf(partials[0]):
+            _raise(lib.ppqhip_lsq_finish_multi(jobs.ctypes.data, n, _stream()))
 
     @ staticmethod
     def QuantizeTensor_LC_B(value, scale, offset, grad_y, clip_min: int, clip_max: int, rounding: int,
@@ -1047,6 +1087,18 @@ class CUDA:
     @ staticmethod
     def LinearQuantize_C_B(tensor, scales, offsets, dy, minimum: int, maximum: int, channel_axis: int, rounding: int):
         return HIP_EXTENSION.QuantizeTensor_LC_B(tensor, scales, offsets, dy, minimum, maximum, rounding, channel_axis)
+
+    @ staticmethod
+    def lsq_t_partials(numel: int) -> int:
+        return HIP_EXTENSION.lsq_t_partials(numel)
+
+    @ staticmethod
+    def LinearQuantize_T_B_Main(tensor, scales, offsets, dy, minimum: int, maximum: int, rounding: int, partial):
+        return HIP_EXTENSION.QuantizeTensor_LT_B_Main(tensor, scales, offsets, dy, minimum, maximum, rounding, partial)
+
+    @ staticmethod
+    def LSQ_Finish_Multi(partials, numels, minimums, maximums, grad_ss) -> None:
+        return HIP_EXTENSION.LSQ_Finish_Multi(partials, numels, minimums, maximums, grad_ss)
 
     @ staticmethod
     def LinearQuantize_C_B_Multi(tensors, scales, offsets, dys, minimums, maximums, channel_axes, rounding: int,

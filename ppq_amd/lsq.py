@@ -147,6 +147,82 @@ class LSQWeightGroup:
         for d, _, _ in self.members: d.group, d.slot = None, None
 
 
+class _DeferredScaleLSQ(Function):
+    """``CuLSQ_LT`` for an activation that belongs to an :class:`LSQActivationGroup`: forward is the same fake-quant launch,
+    backward computes grad_x (the producer's backward needs it now) with ``ppqhip_fq_linear_t_bwd_main`` and leaves the
+    partial sums of the SCALE gradient in the member's own buffer -- the scale is an autograd leaf, nothing further back waits
+    for its gradient; :meth:`LSQActivationGroup.flush` finishes all of them in ONE launch after the sweep."""
+    @ staticmethod
+    def forward(ctx, tensor, scales, offsets, quant_min: int, quant_max: int, rounding, group, slot: int) -> torch.Tensor:
+        r = rounding_value(rounding)
+        quantized = CUDA.LinearQuantize_T(tensor=tensor, scales=scales, offsets=offsets, minimum=quant_min, maximum=quant_max, rounding=r)
+        ctx.save_for_backward(tensor, scales, offsets)
+        ctx._quant_params = [quant_min, quant_max, r]
+        ctx.group, ctx.slot = group, slot
+        return quantized
+
+    @ staticmethod
+    def backward(ctx, dy: torch.Tensor):
+        tensor, scales, offsets = ctx.saved_tensors
+        quant_min, quant_max, rounding = ctx._quant_params
+        dx = ctx.group.backward_main(ctx.slot, tensor, scales, offsets, dy.contiguous(), quant_min, quant_max, rounding)
+        return dx, None, None, None, None, None, None, None
+
+
+class LSQActivationGroup:
+    """The per-tensor ACTIVATION delegators of one block: each backward is one launch (grad_x + partial sums) instead of the
+    per-tensor path's two (``ppqhip_fq_linear_t_bwd`` = main + finish), and ONE ``ppqhip_lsq_finish_multi`` launch per step
+    produces every scale gradient -- bit-identical to ``CuLSQ_LT`` (same kernels, same summation order).  Buffers (partials,
+    gradients) are allocated once per member and reused, so a captured HIP graph of the step finds them at fixed addresses."""
+    def __init__(self, members):
+        self.members = members                              # [(delegator, config)]
+        self.partials = [None] * len(members)
+        self.gs = [torch.empty_like(_as_1d(c.scale)) for _, c in members]
+        self.live = {}                                      # slot -> (numel, qmin, qmax) of this step's backward
+        self.launches = 0
+        for k, (d, _) in enumerate(members): d.act_group, d.act_slot = self, k
+
+    @ staticmethod
+    def eligible(delegator, config) -> bool:
+        pol = config.policy
+        return (not delegator.is_parameter and pol.has_property(P.LINEAR) and pol.has_property(P.PER_TENSOR)
+                and not pol.has_property(P.DYNAMIC) and isinstance(config.scale, torch.Tensor) and config.scale.is_cuda
+                and config.scale.is_leaf and config.scale.numel() == 1 and isinstance(config.offset, torch.Tensor))
+
+    @ classmethod
+    def build(cls, delegators: dict):
+        members = [(d, cfg) for cfg, d in delegators.items() if cls.eligible(d, cfg)]
+        return cls(members) if len(members) >= 2 else None
+
+    def backward_main(self, slot: int, tensor, scales, offsets, dy, quant_min: int, quant_max: int, rounding: int) -> torch.Tensor:
+        need = CUDA.lsq_t_partials(tensor.numel())
+        if slot in self.live or self.partials[slot] is None or self.partials[slot].numel() < need:
+            if slot in self.live: self.flush()                  # the same config quantises two tensors of the block: finish the first
+            if self.partials[slot] is None or self.partials[slot].numel() < need:
+                self.partials[slot] = torch.empty(need, dtype=torch.float32, device=tensor.device)
+        dx = CUDA.LinearQuantize_T_B_Main(tensor, scales, offsets, dy, quant_min, quant_max, rounding, self.partials[slot])
+        self.live[slot] = (tensor.numel(), quant_min, quant_max)
+        return dx
+
+    def flush(self) -> None:
+        """End of the backward sweep: the scale gradient of every member whose backward ran (ONE launch), ADDED to ``.grad``."""
+        if not self.live: return
+        slots = sorted(self.live)
+        CUDA.LSQ_Finish_Multi([self.partials[k] for k in slots], [self.live[k][0] for k in slots], [self.live[k][1] for k in slots],
+                              [self.live[k][2] for k in slots], [self.gs[k] for k in slots])
+        self.launches += 1
+        for k in slots:
+            leaf = self.members[k][1].scale
+            if not leaf.requires_grad: continue
+            g = self.gs[k].reshape(leaf.shape)              # a view of the member's own buffer (fixed address: graph replays)
+            if leaf.grad is None: leaf.grad = g
+            elif leaf.grad.data_ptr() != g.data_ptr(): leaf.grad.add_(g)
+        self.live = {}
+
+    def release(self) -> None:
+        for d, _ in self.members: d.act_group, d.act_slot = None, None
+
+
 class LSQDelegator:
     """training.py:318-421 (the TorchQuantizeDelegator protocol: ``__call__(tensor, config)``)."""
     def __init__(self, config, var, is_parameter_trainable: bool = True, is_scale_trainable: bool = True,
@@ -157,6 +233,7 @@ class LSQDelegator:
         self.policy = config.policy
         self.passive = state_value(config.state) == QuantizationStates.PASSIVE.value
         self.group, self.slot = None, None          # set by LSQWeightGroup: this weight rides the block's multi-tensor launches
+        self.act_group, self.act_slot = None, None  # set by LSQActivationGroup: the scale gradient is finished after the sweep
         self.param_backup = None
         if self.is_parameter and is_parameter_trainable:
             # detached: a grad-tracked clone of a requires_grad leaf would create (and keep alive) the leaf's AccumulateGrad node
@@ -199,6 +276,9 @@ class LSQDelegator:
                 return CuLSQ_LC.apply(tensor, config.scale, config.offset, config.channel_axis, config.quant_min,
                                       config.quant_max, config.rounding)
             elif config.policy.has_property(P.PER_TENSOR):
+                if self.act_group is not None and torch.is_grad_enabled():
+                    return _DeferredScaleLSQ.apply(tensor, _as_1d(config.scale), _as_1d(config.offset), config.quant_min,
+                                                   config.quant_max, config.rounding, self.act_group, self.act_slot)
                 return CuLSQ_LT.apply(tensor, _as_1d(config.scale), _as_1d(config.offset), config.quant_min,
                                       config.quant_max, config.rounding)
         elif config.policy.has_property(P.FLOATING):
@@ -224,7 +304,8 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
     def __init__(self, name: str = 'PPQ LSQ Optimization', interested_layers: List[str] = None, steps: int = 500,
                  gamma: float = 0.0, is_scale_trainable: bool = True, lr: float = 5e-5, block_size: int = 5,
                  expire_device: str = 'cpu', collecting_device: str = 'cuda', loss_fn=None, optimizer=None, *,
-                 process_group=None, group_weights: bool = True, use_hip_graph: bool = True):
+                 process_group=None, group_weights: bool = True, use_hip_graph: bool = True, group_activations: bool = True,
+                 fused_adam: bool = True):
         """The positional parameters are the reference's, in its order (training.py:700-713).  ``expire_device`` /
         ``collecting_device`` are accepted and unused: nothing is parked on the host, the block caches stay on the executor's
         device (288 GB of HBM).  ``loss_fn(y_pred, y_real)``: default = the reference's ``torch_mean_square_error``."""
@@ -246,15 +327,19 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
         # lr-sized step apart (test_hip_graph_replay_of_the_block_step_equals_eager_steps states the tolerance).  use_hip_graph=False is the
         # reference's optimizer bit for bit.
         self.group_weights = group_weights
+        self.group_activations = group_activations     # per-tensor activation delegators: one backward launch each + ONE finish launch per step
         self.use_hip_graph = use_hip_graph
+        self.fused_adam = fused_adam                   # on the HIP-graph path only (the eager path keeps the reference's optimizer)
         self._graph_broken = False              # a capture failed in THIS pass: its later blocks stay eager (reason: graph_error)
         self.graph_error = None
         self.capture_error_mode = 'global'
         self.incremental_inputs = True          # quantised block inputs from blocks.PrefixCache instead of a full forward per block
+        self.max_blocks = None                  # a measuring aid: finetune only the first k blocks (bench.py's 500-step variant)
         self.profile_phases = False             # True: synchronise around the phases and fill phase_ms (a measuring aid)
         self.phase_ms = {}
         self.report = []
-        self.stats = {'blocks': 0, 'graph_blocks': 0, 'graph_replays': 0, 'eager_steps': 0, 'grouped_weights': 0, 'graph_failures': 0}
+        self.stats = {'blocks': 0, 'graph_blocks': 0, 'graph_replays': 0, 'eager_steps': 0, 'grouped_weights': 0, 'grouped_activations': 0,
+                      'graph_failures': 0}
 
     def _phase(self, name: str):
         import contextlib
@@ -425,11 +510,20 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
         names = [v.name for v in block.ep.outputs]
         if len(qt_inputs) == 0: raise ValueError('Dataset is empty.')
         groups = LSQWeightGroup.build(delegators) if (self.group_weights and uniq[0].is_cuda) else []
+        act_group = LSQActivationGroup.build(delegators) if (self.group_activations and uniq[0].is_cuda) else None
         self.stats['blocks'] += 1
         self.stats['grouped_weights'] += sum(len(g.members) for g in groups)
+        self.stats['grouped_activations'] += len(act_group.members) if act_group is not None else 0
         graphable = self._graphable(qt_inputs, fp_outputs, uniq)
         if self.optimizer is not None: opt = self.optimizer(uniq, lr=self.lr)
-        else: opt = torch.optim.Adam(uniq, lr=self.lr, capturable=True) if graphable else torch.optim.Adam(uniq, lr=self.lr)
+        elif graphable:
+            opt = None
+            if self.fused_adam:                        # ONE multi-tensor kernel per step instead of the foreach form's 6-8 small ones
+                try: opt = torch.optim.Adam(uniq, lr=self.lr, capturable=True, fused=True)
+                except (RuntimeError, ValueError, TypeError) as e: self.stats['fused_adam_error'] = f'{type(e).__name__}: {str(e)[:200]}'
+            if opt is None: opt = torch.optim.Adam(uniq, lr=self.lr, capturable=True)
+            else: self.stats['fused_adam_blocks'] = self.stats.get('fused_adam_blocks', 0) + 1
+        else: opt = torch.optim.Adam(uniq, lr=self.lr)
 
         def train_step(qt_input, fp_output) -> None:
             opt.zero_grad()
@@ -445,6 +539,7 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
                             loss = loss + torch_mean_square_error(w, PPQLinearQuantFunction(w, wc)) * self.gamma
             loss.backward()
             for g in groups: g.flush()
+            if act_group is not None: act_group.flush()
             with torch.no_grad():
                 self._average([t.grad for t in uniq if t.grad is not None])
             opt.step()
@@ -458,6 +553,7 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
         with self._phase('post_loss'):
             post_loss = self._block_loss(block, qt_inputs, fp_outputs, executor)
         for g in groups: g.release()
+        if act_group is not None: act_group.release()
         for cfg, d in delegators.items():
             if post_loss > pre_loss: d.withdraw()
             d.finalize()
@@ -480,6 +576,7 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
         else:
             blocks = split_graph_into_blocks(graph, graph.topological_sort(), self.block_size,
                                              interested_layers=self.interested_layers)
+        if self.max_blocks is not None: blocks = blocks[: self.max_blocks]
         self.report = []
         # FP32 targets: the graph dequantised, i.e. (IR/quantize.py:124-141) computing with the parameters stored at
         # quantisation time -- what earlier blocks train does not move the targets of later ones, so the targets of EVERY

@@ -46,3 +46,18 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope='session')
 def golden_dir():
     return os.path.join(ROOT, 'tests', 'golden')
+
+
+def record_parity_residue(kind: str, test: str, **detail) -> None:
+    """every admitted relaxation of a parity statement (a KL near-tie, a vendor-convolution non-repeatability
+    that made a comparison inconclusive) is appended, per run, to gpurun_out/parity_residue.jsonl -- the builder copies the
+    round's file to profiles/.  Never raises."""
+    import json
+    import time
+    try:
+        out = os.path.join(os.environ.get('GRAFT_REPO_ROOT', ROOT), 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'parity_residue.jsonl'), 'a') as f:
+            f.write(json.dumps({'time': time.strftime('%Y-%m-%d %H:%M:%S'), 'kind': kind, 'test': test, **detail}) + '\n')
+    except Exception:
+        pass

@@ -1074,6 +1074,30 @@ def test_bench_two_ranks_on_one_gpu():
         assert key in one
 
 
+@pytest.mark.parametrize('workload', ['resnet50_cfg3', 'yolov6s_int4_lsq'])
+def test_bench_two_ranks_on_one_gpu_configs_3_and_5(workload):
+    """BASELINE configs 3 (ResNet-50, MSE search, asymmetric, histograms merged with an all-reduce) and 5 (YOLOv6-s-like INT4 LSQ,
+    data-parallel gradients) through the real `bench.py --gpus 2` path: two gloo ranks sharing this one MI355X (RCCL refuses
+    duplicate devices; the N-GPU run over RCCL is the driver's).  The contract of the 2-rank JSON line: n_gpus / rccl_ranks = 2,
+    whole-job samples, the merge records of config 3 (a layout probe + ONE data collective per phase, the asymmetric range and
+    the int32 histograms of all 72 observers in one flat buffer each), every block of config 5 trained on both ranks."""
+    small = ['--warmup', '1', '--repeats', '1', '--no-cpu-baseline', '--no-cpu-ops', '--pmc', '0', '--settle-ms', '0', '--variants', '0', '--miopen-find', '0']
+    if workload == 'resnet50_cfg3':
+        out = _run_bench('--gpus', '2', '--backend', 'gloo', '--single-device', '1', '--workload', workload, '--steps', '2', '--batch', '4', *small)
+        assert out['n_gpus'] == 2 and out['config']['rccl_ranks'] == 2 and out['config']['samples'] == 2 * 2 * 4
+        merge = out['config']['merge']
+        assert len(merge) == 2 and all(m['collectives'] == 1 and m['world_size'] == 2 for m in merge)
+        assert merge[0]['min_f32_bytes'] == 72 * 2 * 4 and merge[1]['sum_int32_bytes'] == 72 * 2048 * 4
+        assert 'mse' in out['metric'] and out['roofline']['kernel'] in ('hist_asym_t', 'minmax_t', 'fq_linear_c')
+    else:
+        out = _run_bench('--gpus', '2', '--backend', 'gloo', '--single-device', '1', '--workload', workload, '--steps', '2', '--batch', '2', *small)
+        assert out['n_gpus'] == 2 and out['config']['rccl_ranks'] == 2
+        assert out['config']['blocks'] == 27 and out['config']['optimizer_steps'] == 27 * 2
+        assert out['config']['samples'] == 2 * 27 * 2 * 2                                   # ranks x blocks x steps x batch
+        assert out['config']['execution']['graph_replays'] == 0                              # a gradient all-reduce per step: no HIP graph
+    assert out['value'] > 0 and out['scaling'] == 'weak'
+
+
 @pytest.mark.parametrize('sym', [True, False])
 def test_channelwise_mse_observer_equals_per_tensor_mse_on_each_channel(CUDA, sym):
     """SURVEY 8f-4 extension: 'mse_channel' (per-channel two-phase histogram MSE; the reference's 'mse' raises on

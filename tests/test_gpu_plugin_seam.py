@@ -60,6 +60,10 @@ def _assert_equal(name, got, want, hist_observers=None):
             if ra in kl and rb in kl and abs(ra - rb) == 128 and abs(kl[ra] - kl[rb]) <= 2e-4 * abs(kl[rb]):
                 ties[k] = (ra, rb, kl[ra], kl[rb]); del bad[k]
     if ties: print(f'[kl near-tie admitted] {name}: {ties}')
+    if hist_observers is not None:                   # every KL comparison leaves a record: how many configs, how many admitted ties
+        from conftest import record_parity_residue
+        record_parity_residue('kl_near_tie', name, configs=len(want), admitted=len(ties), mismatched=len(bad),
+                              ties={k: [int(v[0]), int(v[1]), float(v[2]), float(v[3])] for k, v in ties.items()})
     assert not bad and len(ties) <= 2, (name, len(bad), list(bad.items())[:3], ties)
 
 
@@ -180,6 +184,43 @@ def test_pass_plugged_into_the_reference_executor_runs_the_network_itself():
         _assert_equal(f'{method}: HIP pass on ppq.TorchExecutor', _scales(rg2), want)
         out = rex2.forward(batches[0])[0]
         assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize('topology,size,steps', [('small_cnn', 32, 12), ('resnet50', 224, 16)])
+def test_hip_graph_replay_through_the_reference_executor(topology, size, steps):
+    """Seam B at SURVEY 8(d)'s literal protocol size (batch 1) with ``use_hip_graph=True``: what is captured is the REFERENCE's
+    TorchExecutor loop (executor/torch.py:457-577) -- its operation table, its per-weight fake-quant calls into these kernels,
+    this package's hooks / observers / one statistics launch per forward -- and the remaining batches are graph replays.  The pass
+    enters through ``forward_with_gradient`` under ``no_grad`` (``forward`` = the same loop behind ``torch.cuda.empty_cache();
+    gc.collect()``, which cannot be captured: calibration._forward_fn).  Must really replay, and leave the eager seam's scales:
+    exactly on the small topology; on ResNet-50 up to what the vendor convolutions' own run-to-run rounding can move a KL
+    arg-min (most scales equal, every scale within one candidate step = 128 / chosen range <= 12.5 %)."""
+    import ppq_amd
+    from ppq_amd import harness
+    from ppq_amd.calibration import RuntimeCalibrationPass as OurPass
+    RI.load()
+    ppq_amd.install_plugins_into_ppq(observers=False)
+    import ppq.lib as PFL
+    build = harness.small_cnn_graph if topology == 'small_cnn' else harness.resnet50_graph
+    g = torch.Generator().manual_seed(29)
+    batches = [torch.rand(1, 3, size, size, generator=g).to(DEV) for _ in range(steps)]
+
+    def run(mode):
+        rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(build(seed=1)), DEV, batches[0], bins=2048, method='kl')
+        p = OurPass(method='kl', use_hip_graph=mode)
+        PFL.Pipeline([p]).optimize(graph=rg, dataloader=batches, executor=rex, calib_steps=steps, collate_fn=None, verbose=False)
+        torch.cuda.synchronize()
+        assert torch.isfinite(rex.forward(batches[0])[0]).all()           # the executor is still usable afterwards
+        return p, _scales(rg)
+    _, eager = run(False)
+    p, replayed = run(True)
+    assert p.graph_replays == 2 * (steps - 1), p.graph_replays             # two phases, all but the first batch of each replayed
+    assert set(eager) == set(replayed) and len(eager) >= (60 if topology == 'resnet50' else 4)
+    if topology == 'small_cnn':
+        for k in eager: assert torch.equal(eager[k][0], replayed[k][0]) and torch.equal(eager[k][1], replayed[k][1]), k
+    else:
+        rel = torch.stack([(replayed[k][0] - eager[k][0]).abs().max() / eager[k][0].abs().max() for k in eager])
+        assert float(rel.max()) <= 0.126 and int((rel <= 1e-6).sum()) >= int(0.9 * len(eager)), (float(rel.max()), int((rel <= 1e-6).sum()), len(eager))
 
 
 def test_finetuning_passes_plugged_into_the_reference_executor():

@@ -24,7 +24,8 @@ __global__ __launch_bounds__(BLOCK) void floor_read_kernel(const float4* __restr
     // contiguous share per workgroup, walked in tiles of BLOCK * U float4 (the library's traversal)
     const uint32_t tile = BLOCK * U;
     const uint32_t tiles = (nvec + tile - 1) / tile;
-    const uint32_t t0 = (uint32_t)(((uint64_t)blockIdx.x * tiles) / gridDim.x), t1 = (uint32_t)(((uint64_t)(blockIdx.x + 1) * tiles) / gridDim.x);
+    const uint32_t q = tiles / gridDim.x, rem = tiles - q * gridDim.x;        // balanced split, one 32-bit division
+    const uint32_t t0 = blockIdx.x * q + min(blockIdx.x, rem), t1 = t0 + q + (blockIdx.x < rem ? 1u : 0u);
     float m = 0.f;
     for (uint32_t t = t0; t < t1; t++) {
         float4 a[U];
@@ -81,7 +82,8 @@ __global__ __launch_bounds__(BLOCK) void floor_read_atomic_kernel(const float4* 
                                                                   int rows_mode, int keep) {
     const uint32_t tile = BLOCK * U;
     const uint32_t tiles = (nvec + tile - 1) / tile;
-    const uint32_t t0 = (uint32_t)(((uint64_t)blockIdx.x * tiles) / gridDim.x), t1 = (uint32_t)(((uint64_t)(blockIdx.x + 1) * tiles) / gridDim.x);
+    const uint32_t q = tiles / gridDim.x, rem = tiles - q * gridDim.x;        // balanced split, one 32-bit division
+    const uint32_t t0 = blockIdx.x * q + min(blockIdx.x, rem), t1 = t0 + q + (blockIdx.x < rem ? 1u : 0u);
     float m = 0.f;
     for (uint32_t t = t0; t < t1; t++) {
         float4 a[U];
