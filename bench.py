@@ -214,7 +214,7 @@ def collect_prof():
 # device kernels that implement each logical library kernel (prefixes of the demangled names rocprofv3 prints)
 DEVICE_KERNELS = {'hist_sym_t': ('ppqhip::hist_persistent_kernel<false', 'ppqhip::hist_small_kernel<false'),
                   'hist_asym_t': ('ppqhip::hist_persistent_kernel<true', 'ppqhip::hist_small_kernel<true'),
-                  'minmax_t': ('ppqhip::minmax_persistent_kernel', 'ppqhip::minmax_t_kernel'),
+                  'minmax_t': ('ppqhip::minmax_persistent_kernel', 'ppqhip::minmax_small_kernel', 'ppqhip::minmax_t_kernel'),
                   'fq_linear_c': ('ppqhip::fq_linear_multi_kernel', 'ppqhip::fq_linear_c_tile_kernel'),
                   'fq_linear_t': ('ppqhip::fq_linear_t_tile_kernel',),
                   # a quantile_t "launch" is one 7-kernel sequence: bytes of ALL its kernels (init zeroes 84 KB per job, the
@@ -396,7 +396,7 @@ def north_star_b(bins, timeout_s: float = 180.0):
         out = {'fq_linear_c': (8, med(lambda k: k[0] == 'fq_linear_c_tile_kernel')), 'fq_linear_t': (8, med(lambda k: k[0] == 'fq_linear_t_tile_kernel')),
                'hist_sym_t_rows': (4, med(lambda k: k[0] == 'hist_small_kernel' and len(small) == 2 and k[1] == small[1])),
                'hist_sym_t_oneshot': (4, med(lambda k: k[0] == 'hist_small_kernel' and len(small) == 2 and k[1] == small[0])),
-               'minmax_t': (4, med(lambda k: k[0] == 'minmax_persistent_kernel'))}
+               'minmax_t': (4, med(lambda k: k[0] in ('minmax_small_kernel', 'minmax_persistent_kernel')))}
         return {k: {'us': round(us, 2), 'GBps': round(bpe * n / us / 1e3, 1), 'frac_of_8TBps': round(bpe * n / us / 1e3 / HBM_PEAK_GBPS, 3)}
                 for k, (bpe, us) in out.items() if us}
     except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):

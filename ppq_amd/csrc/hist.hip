@@ -155,7 +155,7 @@ struct Binner : WaveBinCounter<ASYM, CLIP, HOT> {
 };
 
 // column sums of partial[count][bins] into hist: hist[b] += sum over rows.  One workgroup of 1024 lanes owns kReduceBins
-// consecutive bins (a 128-B segment of every row): lane (slice, bin) adds its bin over every kReduceSlices-th row with 8 loads in
+// consecutive bins (a 128-B segment of every row): lane (slice, bin) adds its bin over every kReduceSlices-th row with 16 loads in
 // flight, the slices meet in LDS and ONE lane per bin adds the total with a plain read-modify-write -- a bin has exactly one
 // owner, so there are no atomics and the integer sum has no order anyway.  (Round 2's form -- 128 workgroups, 16 same-address
 // device atomics per bin -- took 4.7 us for the 4 MB of rows of a 512-workgroup launch: 0.85 TB/s.)
@@ -165,16 +165,19 @@ __global__ __launch_bounds__(kReduceBlock) void hist_reduce_kernel(const int* __
     __shared__ int lds[kReduceSlices][kReduceBins];
     const int lane_bin = threadIdx.x % kReduceBins, slice = threadIdx.x / kReduceBins;
     const int b = blockIdx.x * kReduceBins + lane_bin;
-    int acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int total = 0;
     if (b < bins) {
         int i = slice;
-        for (; i + 7 * kReduceSlices < count; i += 8 * kReduceSlices) {
+        for (; i + 15 * kReduceSlices < count; i += 16 * kReduceSlices) {       // 512 rows = one trip: all 16 loads of a lane in flight
+            int v[16];
 #pragma unroll
-            for (int k = 0; k < 8; k++) acc[k] += partial[(size_t)(i + k * kReduceSlices) * bins + b];
+            for (int k = 0; k < 16; k++) v[k] = partial[(size_t)(i + k * kReduceSlices) * bins + b];
+#pragma unroll
+            for (int k = 0; k < 16; k++) total += v[k];
         }
-        for (; i < count; i += kReduceSlices) acc[0] += partial[(size_t)i * bins + b];
+        for (; i < count; i += kReduceSlices) total += partial[(size_t)i * bins + b];
     }
-    lds[slice][lane_bin] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    lds[slice][lane_bin] = total;
     __syncthreads();
     if (slice == 0 && b < bins) {
         int t = 0;
@@ -492,15 +495,31 @@ void hist_c_channel_kernel(const float* __restrict__ x, FastDiv vec_per_row, uin
             if (++k >= tiles) break;
         }
     }
-    zero_lds();
-    for (uint32_t v = tiles * kTileVec + threadIdx.x, t = 0; t < kHistU; t++, v += kHistBlock) {   // the ragged rest (< one tile)
-        const bool in = v < V;                                             // wave-uniform trip count, masked lanes
-        const float4 a = in ? *at(v) : make_float4(0.f, 0.f, 0.f, 0.f);
-        int b[4];
-        acc.bins4(a, b);
-        acc.elect(b[0], in);
-        acc.template commit<false>(b[0], in); acc.template commit<false>(b[1], in);
-        acc.template commit<false>(b[2], in); acc.template commit<false>(b[3], in);
+    {   // the ragged rest (< one tile; ALL of a [1, C, 56, 56] channel: 784 float4 against a tile of 1024): every load issued
+        // up front at a clamped index, then whole waves through the EXEC-mask commits and only the straddling wave masked
+        const uint32_t v0r = tiles * kTileVec + threadIdx.x;
+        float4 rest[kHistU];
+        if (V > tiles * kTileVec) {
+#pragma unroll
+            for (int t = 0; t < kHistU; t++) rest[t] = load4<NT>(at(min(v0r + t * kHistBlock, V - 1)));
+        }
+        zero_lds();
+        if (V > tiles * kTileVec) {
+#pragma unroll
+            for (int t = 0; t < kHistU; t++) {
+                const uint32_t v = v0r + t * kHistBlock;
+                const bool in = v < V;
+                if (__builtin_amdgcn_ballot_w64(in) == 0ull) continue;            // wave uniform: nothing of this wave left
+                int b[4];
+                acc.bins4(rest[t], b);
+                acc.elect(b[0], in);
+                if (CLIP && __builtin_amdgcn_ballot_w64(!in) == 0ull) acc.commit4_exec(b);   // the whole wave holds values
+                else {
+                    acc.template commit<false>(b[0], in); acc.template commit<false>(b[1], in);
+                    acc.template commit<false>(b[2], in); acc.template commit<false>(b[3], in);
+                }
+            }
+        }
     }
     acc.flush_hot();
     lds_hist_flush(lds, bins, copies, hist + (size_t)c * bins, flush_mode);

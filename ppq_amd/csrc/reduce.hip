@@ -164,6 +164,45 @@ __global__ __launch_bounds__(kMMBlock) void minmax_persistent_kernel(const MinMa
     }
 }
 
+// The single-tensor launch for LATENCY-bound sizes (see hist_small_kernel, hist.hip: direct arguments instead of the 2.3 KB job
+// table and its two dependent scalar-load rounds, every load of the share in flight before anything else).  The workgroup's slot
+// is read FIRST, so the read-modify-write at the end is no dependent load -> store chain.  K: rows of kMMBlock float4 per share.
+template <int K>
+__global__ __launch_bounds__(kMMBlock) void minmax_small_kernel(const float* __restrict__ x, uint32_t n, float* __restrict__ slots) {
+    __shared__ float lds[32];
+    const uint32_t G = gridDim.x, g = blockIdx.x;
+    float s_mn = INFINITY, s_mx = -INFINITY;
+    if (threadIdx.x == 0) { s_mn = slots[2 * g]; s_mx = slots[2 * g + 1]; }
+    const uint32_t nvec = n >> 2, full_rows = nvec / kMMBlock;
+    uint32_t r0, r1;
+    even_split(full_rows, G, g, r0, r1);
+    const float4* xv = reinterpret_cast<const float4*>(x) + threadIdx.x;
+    float mn = INFINITY, mx = -INFINITY;
+    for (uint32_t r = r0; r < r1; r += K) {
+        float4 buf[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) buf[k] = xv[(size_t)min(r + (uint32_t)k, r1 - 1) * kMMBlock];      // clamped: duplicates are harmless
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            mn = fminf(fminf(mn, buf[k].x), fminf(buf[k].y, fminf(buf[k].z, buf[k].w)));
+            mx = fmaxf(fmaxf(mx, buf[k].x), fmaxf(buf[k].y, fmaxf(buf[k].z, buf[k].w)));
+        }
+    }
+    if (g == G - 1) {                                                  // the ragged rest: < kMMBlock float4 + n % 4 elements
+        for (uint32_t i = full_rows * kMMBlock * 4 + threadIdx.x; i < n; i += kMMBlock) { const float a = x[i]; mn = fminf(mn, a); mx = fmaxf(mx, a); }
+    }
+    mn = wave_min(mn);
+    mx = wave_max(mx);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { lds[wid] = mn; lds[16 + wid] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kMMBlock / kWave; w++) { mn = fminf(mn, lds[w]); mx = fmaxf(mx, lds[16 + w]); }
+        slots[2 * g] = fminf(mn, s_mn);
+        slots[2 * g + 1] = fmaxf(mx, s_mx);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void minmax_finish_kernel(const float* __restrict__ partial, uint32_t count,
                                                                float* __restrict__ minmax) {
     __shared__ float lds[16];
@@ -518,6 +557,18 @@ int ppqhip_minmax_t_slots(const float* x, int64_t n, float* slots, void* stream)
     if (int st = validate(n, "minmax_t_slots")) return st;
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_MINMAX_T, 4.0 * (double)n, s);
+    if (n <= (4ll << 20) && aligned16(x)) {                       // up to 16 MB: the lean kernel, two rows (8 KB) per workgroup
+        const uint32_t full_rows = (uint32_t)((n >> 2) / kMMBlock);
+        uint32_t grid = (full_rows + 1) / 2;
+        const uint32_t cap = (uint32_t)(num_cu() * PPQHIP_MM_WGPC);     // one slot per workgroup
+        if (grid > cap) grid = cap;
+        if (grid < 1) grid = 1;
+        const uint32_t share = (full_rows + grid - 1) / grid;
+        if (share <= 2) hipLaunchKernelGGL((minmax_small_kernel<2>), dim3(grid), dim3(kMMBlock), 0, s, x, (uint32_t)n, slots);
+        else if (share <= 4) hipLaunchKernelGGL((minmax_small_kernel<4>), dim3(grid), dim3(kMMBlock), 0, s, x, (uint32_t)n, slots);
+        else hipLaunchKernelGGL((minmax_small_kernel<8>), dim3(grid), dim3(kMMBlock), 0, s, x, (uint32_t)n, slots);
+        return finish_launch("minmax_t_slots");
+    }
     MinMaxJobs args;
     args.count = 1;
     args.job[0].x = x; args.job[0].slots = slots; args.job[0].n = (uint32_t)n; args.job[0].first_tile = 0;
