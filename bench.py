@@ -607,6 +607,7 @@ def main_lsq(args, rank, world, dev):
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / total_steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (INT4 / INT8 simulated)', 'data': 'synthetic',
             'repeats': len(times), 'values': [round(samples / t, 2) for t in times],
+            'spread_pct': round(100.0 * (max(times) - min(times)) / elapsed, 2),
             'config': {'workload': f'{WORKLOADS[WORKLOAD][0]}; {blocks} blocks x {args.steps} Adam steps x batch {args.batch} x 3x{size}x{size} per GPU '
                                    f'(timed: the whole pass incl. its target / input collection)', 'samples': samples, 'batch': args.batch,
                        'blocks': blocks, 'optimizer_steps': total_steps, 'kept_blocks': sum(1 for _, a, b in p.report if b <= a),

@@ -150,8 +150,8 @@ __device__ __forceinline__ float fq_linear_scalar(float x, float s, int o, int q
 //   * rint(t) != rint(q) needs a half-integer h = k + 0.5 with min(t, q) <= h <= max(t, q) (a tie counts: q == h rounds to
 //     even, t may sit on either side), i.e. within |t| * 2^-22 of t.  d = t - rint(t) is exact (|t| < 2^23, Sterbenz), so is
 //     0.5 - |d| (a multiple of ulp(t), at most 0.5): the distance from t to the nearest half-integer.  Lanes with
-//     0.5 - |d| >= |t| * 2^-20 (four times the bound) are safe; the others -- about |t| * 2^-19 of all values, every
-//     |t| >= 2^19, inf, NaN (the comparison is unordered) -- take the true division.
+//     |d| + |t| * 2^-20 <= 0.5 (four times the bound) are safe; the others -- about |t| * 2^-19 of all values, every
+//     |t| >= 2^19 -- take the true division (see rne_tie_margin for NaN / inf).
 //   * rc must be a normal number for the error bound to hold: scales outside [2^-100, 2^100] (and <= 0, NaN) hand back
 //     NaN, which sends every lane through the division.
 #ifndef PPQHIP_FQ_RCP
@@ -161,8 +161,13 @@ __device__ __forceinline__ float fq_safe_rcp(float s) {
     const float a = __builtin_fabsf(s);
     return (a >= 0x1p-100f && a <= 0x1p100f) ? __builtin_amdgcn_rcpf(s) : __builtin_nanf("");
 }
-__device__ __forceinline__ bool rne_quotient_is_safe(float t, float r) {       // r = rint(t)
-    return (0.5f - __builtin_fabsf(t - r)) >= __builtin_fabsf(t) * 0x1p-20f;
+// distance-to-tie test as ONE number per lane: m = |t - rint(t)| + |t| 2^-20 (one fma; its single rounding is absorbed by the
+// 4x margin: for |t| < 0.25 no tie is in reach at all, above that the rounding is < 3e-8 against a margin of |t| 7e-7).  The lane
+// is safe when m <= 0.5; NaN compares unordered -> unsafe.  (v_max_f32 drops a NaN operand: a float4 with ONE NaN / inf element
+// may therefore pass the combined test below -- for such an element both paths give the same result anyway: rint keeps NaN / inf,
+// the saturating conversion maps them to 0 / INT_MAX, whether the quotient came from the reciprocal or from the division.)
+__device__ __forceinline__ float rne_tie_margin(float t, float d) {             // d = t - rint(t)
+    return __builtin_fmaf(__builtin_fabsf(t), 0x1p-20f, __builtin_fabsf(d));
 }
 
 // four elements of one (scale, offset): QuantizeScalar + DequantizeScalar with ONE divergent region per float4
@@ -170,15 +175,18 @@ template <int R>
 __device__ __forceinline__ float4 fq_linear4(const float4& a, float s, float rc, int o, int qmin, int qmax, int rounding) {
     float4 out;
     if constexpr (R == ROUND_HALF_EVEN && PPQHIP_FQ_RCP != 0) {
-        const float t0 = a.x * rc, t1 = a.y * rc, t2 = a.z * rc, t3 = a.w * rc;
-        float r0 = __builtin_rintf(t0), r1 = __builtin_rintf(t1), r2 = __builtin_rintf(t2), r3 = __builtin_rintf(t3);
-        const bool u0 = !rne_quotient_is_safe(t0, r0), u1 = !rne_quotient_is_safe(t1, r1);
-        const bool u2 = !rne_quotient_is_safe(t2, r2), u3 = !rne_quotient_is_safe(t3, r3);
-        if (u0 | u1 | u2 | u3) {                 // rare: next to a rounding tie (or a special value): the reference's own arithmetic
-            if (u0) r0 = __builtin_rintf(a.x / s);
-            if (u1) r1 = __builtin_rintf(a.y / s);
-            if (u2) r2 = __builtin_rintf(a.z / s);
-            if (u3) r3 = __builtin_rintf(a.w / s);
+        typedef float pk2 __attribute__((ext_vector_type(2)));                   // v_pk_mul_f32 / v_pk_add_f32: two lanes' worth per instruction
+        const pk2 t01 = pk2{a.x, a.y} * rc, t23 = pk2{a.z, a.w} * rc;
+        float r0 = __builtin_rintf(t01.x), r1 = __builtin_rintf(t01.y), r2 = __builtin_rintf(t23.x), r3 = __builtin_rintf(t23.y);
+        const pk2 d01 = t01 - pk2{r0, r1}, d23 = t23 - pk2{r2, r3};
+        const float m0 = rne_tie_margin(t01.x, d01.x), m1 = rne_tie_margin(t01.y, d01.y);
+        const float m2 = rne_tie_margin(t23.x, d23.x), m3 = rne_tie_margin(t23.y, d23.y);
+        if (!(__builtin_fmaxf(__builtin_fmaxf(m0, m1), __builtin_fmaxf(m2, m3)) <= 0.5f)) {
+            // rare: some element sits next to a rounding tie (or the scale is degenerate: rc = NaN): the reference's own arithmetic
+            if (!(m0 <= 0.5f)) r0 = __builtin_rintf(a.x / s);
+            if (!(m1 <= 0.5f)) r1 = __builtin_rintf(a.y / s);
+            if (!(m2 <= 0.5f)) r2 = __builtin_rintf(a.z / s);
+            if (!(m3 <= 0.5f)) r3 = __builtin_rintf(a.w / s);
         }
         out.x = (float)(clampi(add_sat(f2i_sat(r0), o), qmin, qmax) - o) * s;
         out.y = (float)(clampi(add_sat(f2i_sat(r1), o), qmin, qmax) - o) * s;
