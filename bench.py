@@ -24,6 +24,13 @@ USING_CUDA_KERNEL=False PyTorch-CPU path (oracle/torch_cpu_path.py, or the refer
 copy is importable) on a bounded sample of the same workload, `cpu_ops` the per-op table of BASELINE.md
 section 3 (N == 1 only).
 
+Because the driver keeps the SCALAR keys of `config` and drops nested ones, every figure of `config.variants` that matters is
+repeated as a flat scalar of `config` (N == 1, default run): `batch1_x256_samples_per_s`, `seam_{kernels,pass}_b{32,1}_samples_per_s`,
+`cfg3 / cfg4 / cfg5_samples_per_s` (+ their `_roofline_frac`, `_spread_pct`), `cfg5_replay_ms_per_step`, `kl4096_`, `percentile_`,
+`reuse_activations_samples_per_s`, and `B_<kernel>_rocprof_median_us` / `_frac_of_8TBps`: the MEDIAN device durations of the
+single-tensor launches on the north star's tensor B = [1,512,56,56], taken from a `rocprofv3 --kernel-trace` child of this file
+(`--b-child`; latency-bound launches of a few microseconds cannot be timed with event pairs).
+
 `config.variants` (N == 1, default run) also carries, each timed on this box in this run:
   * SURVEY 8(d)'s own protocol (batch 1 x 256 steps) with its wall time decomposed by phase / render and the eager step's
     host-issue vs device time;
@@ -32,7 +39,8 @@ section 3 (N == 1 only).
     observers on these kernels (`install_into_ppq`), and reference executor driving THIS package's pass + observers
     (`install_plugins_into_ppq`) -- the reference is the host there, what is measured is this library underneath it;
   * BASELINE configs 3, 4 and 5 as short child runs of this file (`--workload resnet50_cfg3 | vit_b16_fp8 |
-    yolov6s_int4_lsq`), each with the roofline entry of ITS dominant kernel (hist_asym_t, fq_float_*, lsq_bwd_*).
+    yolov6s_int4_lsq`), each with the roofline entry of ITS dominant kernel (hist_asym_t, fq_float_*, lsq_bwd_*); a child warms
+    itself with MIOpen's find mode on, times 8 steps three times and reports the spread.
 """
 import argparse
 import csv

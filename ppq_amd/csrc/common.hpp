@@ -170,10 +170,10 @@ __device__ __forceinline__ float rne_tie_margin(float t, float d) {             
     return __builtin_fmaf(__builtin_fabsf(t), 0x1p-20f, __builtin_fabsf(d));
 }
 
-// four elements of one (scale, offset): QuantizeScalar + DequantizeScalar with ONE divergent region per float4
+// _round2int(x / s) for the four elements of a float4 (one scale): the reciprocal path above for ROUND_HALF_EVEN, the reference's
+// division otherwise.  ONE divergent region per float4.
 template <int R>
-__device__ __forceinline__ float4 fq_linear4(const float4& a, float s, float rc, int o, int qmin, int qmax, int rounding) {
-    float4 out;
+__device__ __forceinline__ void round_quotient4(const float4& a, float s, float rc, int rounding, int (&r)[4]) {
     if constexpr (R == ROUND_HALF_EVEN && PPQHIP_FQ_RCP != 0) {
         typedef float pk2 __attribute__((ext_vector_type(2)));                   // v_pk_mul_f32 / v_pk_add_f32: two lanes' worth per instruction
         const pk2 t01 = pk2{a.x, a.y} * rc, t23 = pk2{a.z, a.w} * rc;
@@ -188,16 +188,25 @@ __device__ __forceinline__ float4 fq_linear4(const float4& a, float s, float rc,
             if (!(m2 <= 0.5f)) r2 = __builtin_rintf(a.z / s);
             if (!(m3 <= 0.5f)) r3 = __builtin_rintf(a.w / s);
         }
-        out.x = (float)(clampi(add_sat(f2i_sat(r0), o), qmin, qmax) - o) * s;
-        out.y = (float)(clampi(add_sat(f2i_sat(r1), o), qmin, qmax) - o) * s;
-        out.z = (float)(clampi(add_sat(f2i_sat(r2), o), qmin, qmax) - o) * s;
-        out.w = (float)(clampi(add_sat(f2i_sat(r3), o), qmin, qmax) - o) * s;
+        r[0] = f2i_sat(r0); r[1] = f2i_sat(r1); r[2] = f2i_sat(r2); r[3] = f2i_sat(r3);
     } else {
-        out.x = fq_linear_scalar<R>(a.x, s, o, qmin, qmax, rounding);
-        out.y = fq_linear_scalar<R>(a.y, s, o, qmin, qmax, rounding);
-        out.z = fq_linear_scalar<R>(a.z, s, o, qmin, qmax, rounding);
-        out.w = fq_linear_scalar<R>(a.w, s, o, qmin, qmax, rounding);
+        r[0] = (R >= 0) ? round2int_t<(R >= 0 ? R : 0)>(a.x / s) : round2int(a.x / s, rounding);
+        r[1] = (R >= 0) ? round2int_t<(R >= 0 ? R : 0)>(a.y / s) : round2int(a.y / s, rounding);
+        r[2] = (R >= 0) ? round2int_t<(R >= 0 ? R : 0)>(a.z / s) : round2int(a.z / s, rounding);
+        r[3] = (R >= 0) ? round2int_t<(R >= 0 ? R : 0)>(a.w / s) : round2int(a.w / s, rounding);
     }
+}
+
+// four elements of one (scale, offset): QuantizeScalar + DequantizeScalar
+template <int R>
+__device__ __forceinline__ float4 fq_linear4(const float4& a, float s, float rc, int o, int qmin, int qmax, int rounding) {
+    int r[4];
+    round_quotient4<R>(a, s, rc, rounding, r);
+    float4 out;
+    out.x = (float)(clampi(add_sat(r[0], o), qmin, qmax) - o) * s;
+    out.y = (float)(clampi(add_sat(r[1], o), qmin, qmax) - o) * s;
+    out.z = (float)(clampi(add_sat(r[2], o), qmin, qmax) - o) * s;
+    out.w = (float)(clampi(add_sat(r[3], o), qmin, qmax) - o) * s;
     return out;
 }
 

@@ -203,6 +203,9 @@ __global__ __launch_bounds__(kBlock) void to_int8_vec_kernel(const float4* __res
 template <bool CHANNEL, int R>
 __device__ __forceinline__ float lsq_bwd_elem(float v, float dy, float s, float rcp_s, float o, int oi, int qmin,
                                               int qmax, int rounding, float* gx) {
+    // (the reciprocal path of the forward kernels -- common.hpp: round_quotient4 -- was measured here in round 5 and LOST: its
+    //  divergent fallback region per float4 keeps the compiler from interleaving the U load / store groups of these kernels;
+    //  the weight launch of a block-wise LSQ step went 9.6 -> 17 us, Bx32 106 -> 109 us)
     const int r = (R >= 0) ? round2int_t<(R >= 0 ? R : 0)>(v / s) : round2int(v / s, rounding);
     const int qt = f2i_sat((float)r + o);
     const float q = (float)(qt - oi) * s;
@@ -237,7 +240,7 @@ __device__ __forceinline__ float block_sum(float v, float* lds) {
 #ifndef PPQHIP_LSQ_MAX_WG
 #define PPQHIP_LSQ_MAX_WG 65536         // workgroups per launch (one partial sum each)
 #endif
-template <int R, bool NT>
+template <int R, bool NT, int U>
 __global__ __launch_bounds__(kBlock) void fq_linear_t_bwd_kernel(
     const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ offset,
     const float* __restrict__ dy, float* __restrict__ gx, float* __restrict__ partial, uint32_t n, int vec_ok,
@@ -245,7 +248,6 @@ __global__ __launch_bounds__(kBlock) void fq_linear_t_bwd_kernel(
     __shared__ float lds[kBlock / kWave];
     float acc = 0.f;
     uint32_t done = 0;
-    constexpr int U = PPQHIP_LSQ_U;
     const uint32_t nvec = n >> 2;
     const float4* xv = reinterpret_cast<const float4*>(x);
     const float4* dv = reinterpret_cast<const float4*>(dy);
@@ -842,17 +844,26 @@ int ppqhip_to_int_c(const float* x, const float* scale, const float* offset, voi
                        "to_int_c");
 }
 
-static int lsq_t_grid(int64_t n) { return stream_grid(n, kBlock * 4 * PPQHIP_LSQ_U, PPQHIP_LSQ_MAX_WG); }
+// (x, dy) load pairs per lane and workgroup: 4 for HBM-bound tensors (sweep in profiles/r03_lsq_variants.txt), 1 for the
+// latency-bound ones (up to 16 MB per operand: four times the waves, a quarter of the arithmetic behind each load -- the
+// activations of a block-wise LSQ step are 0.05 .. 6 MB)
+#ifndef PPQHIP_LSQ_SMALL_U
+#define PPQHIP_LSQ_SMALL_U 1
+#endif
+static int lsq_t_u(int64_t n) { return n <= (4ll << 20) ? PPQHIP_LSQ_SMALL_U : PPQHIP_LSQ_U; }
+static int lsq_t_grid(int64_t n) { return stream_grid(n, kBlock * 4 * lsq_t_u(n), PPQHIP_LSQ_MAX_WG); }
 
 static void launch_lsq_t_main(const float* x, const float* scale, const float* offset, const float* grad_y, float* grad_x,
                               float* partial, int64_t n, int grid, int clip_min, int clip_max, int rounding, hipStream_t s) {
     const int vec_ok = (aligned16(x) && aligned16(grad_y) && aligned16(grad_x)) ? 1 : 0;
     const bool nt = n >= kStreamElems / 2;       // x and dy together exceed cache residency: streaming loads
-#define PPQ_LAUNCH_LSQ_T(R, NT)                                                                                     \
-    hipLaunchKernelGGL((fq_linear_t_bwd_kernel<R, NT>), dim3(grid), dim3(kBlock), 0, s, x, scale, offset, grad_y,   \
+#define PPQ_LAUNCH_LSQ_T(R, NT, U)                                                                                  \
+    hipLaunchKernelGGL((fq_linear_t_bwd_kernel<R, NT, U>), dim3(grid), dim3(kBlock), 0, s, x, scale, offset, grad_y, \
                        grad_x, partial, (uint32_t)n, vec_ok, clip_min, clip_max, rounding)
-    if (rounding == ROUND_HALF_EVEN) { if (nt) PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, true); else PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, false); }
-    else { if (nt) PPQ_LAUNCH_LSQ_T(-1, true); else PPQ_LAUNCH_LSQ_T(-1, false); }
+    if (lsq_t_u(n) == PPQHIP_LSQ_SMALL_U) {          // never nontemporal: these tensors are cache resident
+        if (rounding == ROUND_HALF_EVEN) PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, false, PPQHIP_LSQ_SMALL_U); else PPQ_LAUNCH_LSQ_T(-1, false, PPQHIP_LSQ_SMALL_U);
+    } else if (rounding == ROUND_HALF_EVEN) { if (nt) PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, true, PPQHIP_LSQ_U); else PPQ_LAUNCH_LSQ_T(ROUND_HALF_EVEN, false, PPQHIP_LSQ_U); }
+    else { if (nt) PPQ_LAUNCH_LSQ_T(-1, true, PPQHIP_LSQ_U); else PPQ_LAUNCH_LSQ_T(-1, false, PPQHIP_LSQ_U); }
 #undef PPQ_LAUNCH_LSQ_T
 }
 

@@ -197,7 +197,10 @@ class LSQActivationGroup:
     def backward_main(self, slot: int, tensor, scales, offsets, dy, quant_min: int, quant_max: int, rounding: int) -> torch.Tensor:
         need = CUDA.lsq_t_partials(tensor.numel())
         if slot in self.live or self.partials[slot] is None or self.partials[slot].numel() < need:
-            if slot in self.live: self.flush()                  # the same config quantises two tensors of the block: finish the first
+            if slot in self.live:                               # the same config quantises two tensors of the block: finish the first
+                self.flush()
+                leaf = self.members[slot][1].scale              # .. and keep its gradient apart from the buffer the second one overwrites
+                if leaf.grad is not None and leaf.grad.data_ptr() == self.gs[slot].data_ptr(): leaf.grad = leaf.grad.clone()
             if self.partials[slot] is None or self.partials[slot].numel() < need:
                 self.partials[slot] = torch.empty(need, dtype=torch.float32, device=tensor.device)
         dx = CUDA.LinearQuantize_T_B_Main(tensor, scales, offsets, dy, quant_min, quant_max, rounding, self.partials[slot])

@@ -1397,3 +1397,32 @@ def test_isotone_pass_marks_the_same_configs_as_the_reference(monkeypatch):
             assert out[0] == out[1] and table(a) == table(b), (name, kw, out)
             marked += sum(1 for row in table(b) if row[3] == 'Isotone')
     assert marked >= 20
+
+
+def test_calibration_pass_enters_the_reference_executor_below_its_cache_emptying_wrapper():
+    """RuntimeCalibrationPass._forward_fn: on the reference's own TorchExecutor (a class of a `ppq.` module with the public
+    `forward_with_gradient` next to `forward` and an `_executing_order`) the pass calls `forward_with_gradient` -- `forward` is the
+    same loop behind `torch.cuda.empty_cache(); gc.collect()` (core/defs.py:43-55), which no HIP graph can capture -- and runs it
+    under its own no_grad; every other executor (this package's harness, a user's) is entered through `forward`."""
+    import torch
+    from ppq_amd.calibration import RuntimeCalibrationPass
+    calls = []
+
+    class RefLike:
+        _executing_order = []
+        def forward(self, inputs, output_names=None, hooks=None): calls.append(('forward', torch.is_grad_enabled()))
+        def forward_with_gradient(self, inputs, output_names=None, hooks=None): calls.append(('forward_with_gradient', torch.is_grad_enabled()))
+    RefLike.__module__ = 'ppq.executor.torch'
+
+    class Other(RefLike): pass
+    Other.__module__ = 'ppq_amd.harness'
+
+    class NoOrder:
+        def forward(self, inputs, output_names=None, hooks=None): calls.append(('forward', torch.is_grad_enabled()))
+        def forward_with_gradient(self, inputs, output_names=None, hooks=None): calls.append(('forward_with_gradient', torch.is_grad_enabled()))
+    NoOrder.__module__ = 'ppq.somewhere'
+    p = RuntimeCalibrationPass(method='minmax')
+    with torch.enable_grad():
+        for ex in (RefLike(), Other(), NoOrder()):
+            p._forward(ex, torch.zeros(1), {}, None)
+    assert calls == [('forward_with_gradient', False), ('forward', False), ('forward', False)]
