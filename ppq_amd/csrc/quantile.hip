@@ -25,7 +25,9 @@
 //                             threshold with a known, sufficient number of keys beyond it, or ON a heavily tied answer).
 //                             With nothing open each returns on one load.
 //
-// The result is exact in every case; the hint only decides how much is read.  Hot path: 7 launches, 4 of them return on one load.
+// The result is exact in every case; the hint only decides how much is read.  Hot path: 7 launches, 4 of them return on one load;
+// ONE small tensor with an extreme q (a single-tensor call from the reference's percentile observer): 5 launches -- F1 F2 F3 are one
+// launch of one workgroup there (quantile_f123_single_kernel).
 #include <cmath>
 #include <cstdlib>
 #include "common.hpp"
@@ -1210,6 +1212,27 @@ __global__ __launch_bounds__(kBlock) void quantile_f3_kernel(const QSeq s) {
     quantile_f3_body(s, lds);
 }
 
+// ONE small tensor with an extreme q (the calibration call: n (1 - q) wanted keys, a few hundred): the filter + select A settle
+// it unless the sample misled them or the thresholds of an old hint became absurd, so the exact passes are a RARE fallback --
+// and three launches that each return on one load are then 13 us of device time (4.5 + 4.5 + 3.9 on B) plus three boundaries
+// behind a 5 us filter.  For such a sequence the three bodies run back to back in ONE launch of ONE workgroup: it returns on one
+// load in the common case (~2 us), and when a side is open it walks the tensor three times alone (G = 1: the ticket of every
+// pass is its own; an agent-scope fence + barrier between the passes makes the tail's plain stores visible to the next body's
+// loads).  That is ~0.5 ms for 6 MB -- acceptable for something that happens on the first batch of an unlucky observer, not for
+// a quantile the filter cannot help (a median): the host only routes here when both wanted counts fit the smallest list.
+__global__ __launch_bounds__(kBlock) void quantile_f123_single_kernel(const QSeq s) {
+    __shared__ union { F1Lds f1; F2Lds f2; F3Lds f3; } lds;
+    if (s.header[kGOpen] == 0u) return;
+    quantile_f1_body(s, lds.f1);
+    __threadfence(); __syncthreads();
+    quantile_f2_body(s, lds.f2);
+    __threadfence(); __syncthreads();
+    if (*(volatile const uint32_t*)&s.header[kGOpen3] != 0u) quantile_f3_body(s, lds.f3);
+}
+#ifndef PPQHIP_Q_SINGLE_ELEMS
+#define PPQHIP_Q_SINGLE_ELEMS (4ll << 20)
+#endif
+
 static int validate(int64_t n, const char* what) {
     if (n <= 0) { set_error("%s: tensor is empty", what); return PPQHIP_ERR_INVALID_VALUE; }
     if (n > 0x7fffffffLL) { set_error("%s: too many elements", what); return PPQHIP_ERR_INVALID_VALUE; }
@@ -1225,6 +1248,7 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
         const int count = (num_jobs - seq_base) < kQMaxJobs ? (num_jobs - seq_base) : kQMaxJobs;
         uint32_t tiles = 0, units = 0;
         int64_t elems = 0;
+        uint32_t wanted_max = 0;                          // most keys any side of any job needs listed
         for (int base = 0; base < count; base += kQInitMax) {
             QInitArgs a;
             a.count = (uint32_t)((count - base) < kQInitMax ? (count - base) : kQInitMax);
@@ -1243,6 +1267,9 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
                 };
                 QUpload& e = a.e[k];
                 e.x = src.x; e.dest = src.dest; e.hint = src.hint; e.n = (uint32_t)n; e.k_hi = pos(q); e.k_lo = pos(1 - q); e.pad = 0;
+                const uint32_t w_hi = e.n - e.k_hi, w_lo = e.k_lo + 1u;
+                if (w_hi > wanted_max) wanted_max = w_hi;
+                if (w_lo > wanted_max) wanted_max = w_lo;
                 tiles += q_job_tiles(e.n, aligned16(src.x));
                 units += q_job_units(e.n);
                 spec_at += 2 * (size_t)quantile_spec_cap((uint64_t)n);
@@ -1266,6 +1293,12 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
             if (gf > cus * kQFWgPerCu) gf = cus * kQFWgPerCu;
             hipLaunchKernelGGL(quantile_filter_kernel, dim3(gf), dim3(kQFBlock), 0, s, seq);
             hipLaunchKernelGGL(quantile_select_a_kernel, dim3(2 * (uint32_t)count), dim3(kQSABlock), 0, s, seq);
+        }
+        // (tiny all-open jobs -- below 256 K elements the exact passes ARE the algorithm -- keep their three parallel launches: one
+        //  workgroup alone took 119 us instead of 53 for [1,3,224,224])
+        if (count == 1 && !seq.all_open && elems <= PPQHIP_Q_SINGLE_ELEMS && wanted_max <= 4096u) {
+            hipLaunchKernelGGL(quantile_f123_single_kernel, dim3(1), dim3(kBlock), 0, s, seq);
+            continue;
         }
         uint32_t gF = tiles < cus * 4 ? tiles : cus * 4;
         if (gF < 1) gF = 1;
