@@ -1,8 +1,8 @@
 #!/bin/bash
 # Developer tool (round 5): the A/B libraries tools/r5_floor.sh measures on the GPU box.
 #   variants/lib_r04.so    : the kernels as committed at the end of round 4 (3e97a8c) -- the "before" of every comparison
-#   variants/lib_dev.so    : HEAD + -DPPQHIP_DEV_KNOBS (grid sweep of the one-shot histogram)
-#   variants/lib_fq*.so    : linear.hip with other tile shapes / without the reciprocal fast path
+#   variants/lib_dev.so    : HEAD + -DPPQHIP_DEV_KNOBS (env knobs: PPQHIP_DEV_HIST_WG / _SMALL / _ATOMIC, swept by tools/floor_table.py)
+#   variants/lib_<name>.so : one source file rebuilt with other -D flags (arguments, see the end of this file)
 set -e
 cd "$(dirname "$0")/.."
 R=$PWD
@@ -30,8 +30,9 @@ build() {  # name src defs...
   echo "built variants/lib_$name.so ($*)"
 }
 build dev hist.hip -DPPQHIP_DEV_KNOBS &
-build fqU1 linear.hip -DPPQHIP_FQ_U=1 &
-build fqU4 linear.hip -DPPQHIP_FQ_U=4 &
-build fqnorcp linear.hip -DPPQHIP_FQ_RCP=0 &
-build fqU1norcp linear.hip -DPPQHIP_FQ_RCP=0 -DPPQHIP_FQ_U=1 &
+# further A/B builds: name:file:"flags", e.g.  tools/r5_build_variants.sh fqS2:linear.hip:"-DPPQHIP_FQ_SMALL_U=2" fqnorcp:linear.hip:"-DPPQHIP_FQ_RCP=0"
+for spec in "$@"; do
+  name=${spec%%:*}; rest=${spec#*:}; file=${rest%%:*}; defs=${rest#*:}
+  build $name $file $defs &
+done
 wait
