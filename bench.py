@@ -469,24 +469,65 @@ def seam_variants(dev, batches, steps, bins, method):
     return out
 
 
+def inprocess_variants(dev, args):
+    """The headline topology with other calibration settings, timed IN THIS PROCESS (the convolutions are the headline's own:
+    MIOpen's find results are already here, no child, no second search): the reference's DEFAULT KL bin count (core/common.py:18:
+    4096; BASELINE quotes 2048) and the percentile observer (the quantile launch sequence in situ: one sequence per forward over
+    72 tensors, hints from the previous batch).  One warm pass, three timed passes of exactly `steps` steps (median), one more
+    pass with hipEvent pairs for the roofline entry of the variant's dominant kernel."""
+    from ppq_amd import _lib
+    out = []
+    for name, bins, method, steps, prefer in (('resnet50_kl_bins4096', 4096, 'kl', 8, None), ('resnet50_percentile', args.bins, 'percentile', 16, ('quantile_t',))):
+        try:
+            g = torch.Generator(device=dev).manual_seed(777)
+            bs = [torch.rand(args.batch, 3, 224, 224, device=dev, generator=g) for _ in range(steps)]
+            fresh = lambda: build_workload(dev, bins, method, args.cache_params, args.fuse_params, bool(args.channels_last))      # noqa: E731
+            graph, ex = fresh()
+            run_pass(graph, ex, bs, steps, method, False, False, True)     # a full-length warm pass: the allocator sees this variant's buffer sizes
+            times = []
+            for _ in range(3):
+                del graph, ex
+                graph, ex = fresh()
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                run_pass(graph, ex, bs, steps, method, False, False, True)
+                torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
+            del graph, ex
+            graph, ex = fresh()
+            torch.cuda.synchronize(); _lib.lib.ppqhip_prof_enable(1)
+            run_pass(graph, ex, bs, steps, method, False, False, True)
+            torch.cuda.synchronize(); _lib.lib.ppqhip_prof_enable(0)
+            roof = roofline_entry(collect_prof(), prefer=prefer) or {}
+            del graph, ex, bs
+            med = sorted(times)[1]
+            n = steps * args.batch
+            out.append({'workload': f'ResNet-50 topology, RuntimeCalibrationPass {method} {bins} bins, {steps} batches x {args.batch} (in process)',
+                        'name': name, 'value': round(n / med, 2), 'unit': 'samples/s', 'ms_per_step': round(med / steps * 1e3, 3), 'steps': steps,
+                        'values': [round(n / t, 2) for t in times], 'spread_pct': round(100.0 * (max(times) - min(times)) / med, 2),
+                        'roofline': {k: roof.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'launches', 'avg_launch_us',
+                                                              'algorithmic_bytes_per_launch')}})
+        except Exception as e:
+            out.append({'workload': name, 'name': name, 'error': f'{type(e).__name__}: {e}'})
+        torch.cuda.empty_cache()
+    return out
+
+
 def workload_variants(args):
     """BASELINE configs 3, 4, 5 as short child runs of this file: each line's value + the roofline entry of its dominant
-    kernel.  Children skip baselines, PMC passes and their own variants; MIOpen immediate mode keeps their warm-up short."""
+    kernel.  Children skip baselines, PMC passes and their own variants."""
     out = []
     for name, extra in (('resnet50_cfg3', ['--workload', 'resnet50_cfg3', '--steps', '8', '--batch', '32']),
                         ('vit_b16_fp8', ['--workload', 'vit_b16_fp8', '--steps', '8', '--batch', '16']),
                         ('yolov6s_int4_lsq', ['--workload', 'yolov6s_int4_lsq', '--steps', '8', '--batch', '8']),
-                        # the headline pass at the reference's DEFAULT KL bin count (core/common.py:18: 4096; BASELINE quotes 2048)
-                        ('resnet50_kl_bins4096', ['--workload', 'resnet50', '--bins', '4096', '--steps', '8', '--batch', '32']),
-                        # the percentile observer on the headline topology: the in-situ number of the quantile launch
-                        # sequence (quantile.hip; one sequence per forward over 72 tensors, hints from the previous batch)
-                        ('resnet50_percentile', ['--workload', 'resnet50', '--method', 'percentile', '--steps', '16', '--batch', '32'])):
+                        ):
         # every child warms ITSELF with MIOpen's find mode on (one complete untimed pass over one batch): the parent's own find
         # results live in its process until it exits, and a child in immediate mode on a fresh box runs the vendor library's
         # heuristic picks instead (BENCH_r04: config 3 at 26 ms / step in the driver's run against 11.5 in the builder's, whose
         # box had a user database from an earlier command); >= 8 timed steps, three timed passes (value = their median), spread reported
+        # (config 5 stays in immediate mode: the search over 56 convolutions x forward / data-gradient / weight-gradient costs the
+        #  child 160 s -- 183 s against 22 s of wall time -- and buys 6 % per replayed step: 0.330 vs 0.349 ms)
+        find = '0' if name == 'yolov6s_int4_lsq' else '1'
         cmd = [sys.executable, os.path.abspath(__file__), '--warmup', '1', '--repeats', '3', '--variants', '0', '--pmc', '0',
-               '--no-cpu-baseline', '--no-cpu-ops', '--settle-ms', '100', '--miopen-find', '1'] + extra
+               '--no-cpu-baseline', '--no-cpu-ops', '--settle-ms', '100', '--miopen-find', find] + extra
         try:
             t0 = time.perf_counter()
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
@@ -820,6 +861,7 @@ def main():
         g1 = torch.Generator(device=dev).manual_seed(99)
         variants += seam_variants(dev, [torch.rand(1, 3, 224, 224, device=dev, generator=g1) for _ in range(64)], 64, args.bins, args.method)
         torch.cuda.empty_cache()
+        variants += inprocess_variants(dev, args)
         variants += workload_variants(args)
 
     if world > 1:
