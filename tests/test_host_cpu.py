@@ -1426,3 +1426,19 @@ def test_calibration_pass_enters_the_reference_executor_below_its_cache_emptying
         for ex in (RefLike(), Other(), NoOrder()):
             p._forward(ex, torch.zeros(1), {}, None)
     assert calls == [('forward_with_gradient', False), ('forward', False), ('forward', False)]
+
+
+def test_only_parameter_shaped_tensors_join_the_queued_per_channel_minmax():
+    """the multi-tensor per-channel min/max launch takes one wave per ROW, so an activation [N, C, H, W] with short rows
+    is served better by the single-tensor kernel (several rows of a channel per wave); only tensors whose channel axis is the
+    outermost non-trivial one -- weights [Cout, Cin, kh, kw] on axis 0, a batch-1 activation on axis 1 -- are queued
+    (observer.TorchMinMaxObserver.observe asks CUDA.minmax_c_outer_is_one; pure geometry, no kernel)."""
+    import torch
+    from ppq_amd import CUDA
+    cases = [((64, 3, 7, 7), 0, True), ((1000, 2048), 0, True), ((1, 512, 56, 56), 1, True), ((1, 1, 197, 768), 2, True),
+             ((8, 512, 56, 56), 1, False), ((2, 197, 768), 2, False), ((32, 27), 1, False), ((5,), 0, True)]
+    for shape, axis, want in cases:
+        assert CUDA.minmax_c_outer_is_one(torch.zeros(shape), axis) is want, (shape, axis)
+    # a parameter-shaped tensor may additionally be `fresh` (overwritten, no seeding) when a channel fits one wave's chunk
+    assert CUDA.minmax_c_fresh_ok(torch.zeros(64, 3, 7, 7), 0) and not CUDA.minmax_c_fresh_ok(torch.zeros(8, 512, 56, 56), 1)
+    assert not CUDA.minmax_c_fresh_ok(torch.zeros(7, 9001), 0)          # outer == 1 but 9001 > 8192 elements per channel
