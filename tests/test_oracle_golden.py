@@ -540,3 +540,50 @@ def test_kl_near_tie_follows_the_float32_sum_order(golden_dir):
     # the oracle's own search (numpy float32 sums) returns one of the two, and says which
     _, _, ls, br = O.kl_search(hist, float(z['hist_scale']), return_losses=True)
     assert br in (1792, 1920)
+
+
+def test_reciprocal_quotient_safety_test_is_sound():
+    """The forward fake-quant kernels take rint(x * rc), rc ~ 1 / s, wherever `|t - rint(t)| + |t| 2^-20 <= 0.5` (common.hpp:
+    rne_tie_margin / round_quotient4) and the IEEE division elsewhere.  This is the claim behind that shortcut, checked in numpy's
+    IEEE float32 arithmetic on the inputs that could break it: for EVERY lane the test calls safe, rint(x * rc) == rint(x / s) --
+    with rc the correctly rounded reciprocal AND one ulp either side of it (v_rcp_f32 is specified to 1 ulp), x ON and within
+    4 ulps of every rounding tie (k + 1/2) s and every integer k s, k up to 2^22, plus random values; and the test is not vacuous:
+    nearly all random lanes are safe, the ties themselves never are."""
+    rng = np.random.default_rng(12)
+    scales = np.concatenate([rng.random(40).astype(np.float32) * 0.2 + 1e-4, np.float32([1.0, 0.1, 0.3, 1 / 3, 2.0 ** -7, 1e-8, 3e-5, 7.0, 1e6, 2.0 ** -99, 2.0 ** 99])])
+    checked = safe_random = total_random = 0
+    for s in scales:
+        s = np.float32(s)
+        k = np.concatenate([np.arange(-600, 600), rng.integers(-2 ** 22, 2 ** 22, 4000)]).astype(np.float64)
+        xs = []
+        for half in (0.5, 0.0):
+            base = ((k + half) * np.float64(s)).astype(np.float32)
+            for ulps in range(-4, 5):
+                v = base.copy()
+                for _ in range(abs(ulps)): v = np.nextafter(v, np.float32(np.inf if ulps > 0 else -np.inf), dtype=np.float32)
+                xs.append(v)
+        rnd = (rng.standard_normal(20000) * 40 * np.float64(s)).astype(np.float32)
+        xs.append(rnd)
+        x = np.concatenate(xs)
+        x = x[np.isfinite(x)]
+        with np.errstate(over='ignore', invalid='ignore'):
+            want = np.rint(x / s)                                    # the reference's arithmetic: IEEE float32 division, then RNE
+            rc0 = np.float32(1.0) / s
+            for rc in (rc0, np.nextafter(rc0, np.float32(np.inf), dtype=np.float32), np.nextafter(rc0, np.float32(0), dtype=np.float32)):
+                t = (x * rc).astype(np.float32)
+                r = np.rint(t)
+                d = (t - r).astype(np.float32)
+                m = (np.abs(t).astype(np.float64) * 2.0 ** -20 + np.abs(d).astype(np.float64)).astype(np.float32)   # == the fma's single rounding
+                safe = m <= np.float32(0.5)
+                assert np.array_equal(r[safe], want[safe]), (s, rc, int((r[safe] != want[safe]).sum()))
+                checked += int(safe.sum())
+        # the ties themselves are never called safe, random values nearly always are
+        tie = ((np.arange(-50, 50) + 0.5) * np.float64(s)).astype(np.float32)
+        tt = (tie * rc0).astype(np.float32)
+        mt = (np.abs(tt).astype(np.float64) * 2.0 ** -20 + np.abs((tt - np.rint(tt)).astype(np.float32)).astype(np.float64)).astype(np.float32)
+        on_tie = np.abs((tie / s) - np.rint(tie / s)) == 0.5
+        assert not np.any(mt[on_tie] <= np.float32(0.5))
+        tr = (rnd * rc0).astype(np.float32)
+        mr = (np.abs(tr).astype(np.float64) * 2.0 ** -20 + np.abs((tr - np.rint(tr)).astype(np.float32)).astype(np.float64)).astype(np.float32)
+        safe_random += int((mr <= np.float32(0.5)).sum()); total_random += rnd.size
+    assert checked > 5_000_000 and safe_random > 0.995 * total_random, (checked, safe_random, total_random)
