@@ -11,7 +11,9 @@ KL search, render), bracketed by barrier + torch.cuda.synchronize on both sides,
 Inputs (K batches of torch.rand(batch,3,224,224)) are resident in HBM before the timer starts.
 Weak scaling: every rank calibrates K batches of its own; statistics merge with two RCCL collectives per
 phase -- a 13-word layout probe (MAX) and ONE data all-reduce over one flat buffer (ppq_amd/distributed.py);
-value = N*K*batch / time.
+value = N*K*batch / time.  Strong scaling (`--total-samples S`, e.g. BASELINE config 3's "1024 samples sharded across 8"): the job is
+fixed, K = S / (N * batch) is derived, `scaling` is "strong"; each rank of a multi-GPU run keeps its own MIOpen user database /
+kernel cache so that N find-mode warm-ups do not serialise on one sqlite file.
 
 The timed pass is repeated `--repeats` times (default 3, each on a freshly built graph, each timing
 exactly K steps); `value` is the MEDIAN pass and `values` / `spread_pct` report all of them.
@@ -27,9 +29,14 @@ section 3 (N == 1 only).
 Because the driver keeps the SCALAR keys of `config` and drops nested ones, every figure of `config.variants` that matters is
 repeated as a flat scalar of `config` (N == 1, default run): `batch1_x256_samples_per_s`, `seam_{kernels,pass}_b{32,1}_samples_per_s`,
 `cfg3 / cfg4 / cfg5_samples_per_s` (+ their `_roofline_frac`, `_spread_pct`), `cfg5_replay_ms_per_step`, `kl4096_`, `percentile_`,
-`reuse_activations_samples_per_s`, and `B_<kernel>_rocprof_median_us` / `_frac_of_8TBps`: the MEDIAN device durations of the
-single-tensor launches on the north star's tensor B = [1,512,56,56], taken from a `rocprofv3 --kernel-trace` child of this file
-(`--b-child`; latency-bound launches of a few microseconds cannot be timed with event pairs).
+`reuse_activations_samples_per_s`, and the north star's own tensor (tools/north_star.py): `B_<kernel>_rocprof_median_us` / `_p10_us` /
+`_frac_of_8TBps` / `_over_floor` = the MEDIAN device duration of the single-tensor launch on B = [1,512,56,56] from a `rocprofv3
+--kernel-trace` child, its fraction of 8 TB/s and its ratio to the matching FLOOR kernel measured in the same child (`B_floor_empty_us`,
+`B_floor_read_us`, `B_floor_copy_us`, `B_floor_read_atomic_*_us`); `B_<kernel>_graph_us` = the same launch replayed 200x from one HIP graph /
+200 in THIS process (no profiler needed: an upper bound that exists on any box); `<kernel>_frac_x{2,4,8,16,32}` and
+`<kernel>_crosses_0p70_at_x` = the same launch on B x k and the smallest measured k at which it reaches 0.70 of 8 TB/s; `B_status` says
+whether the rocprofv3 child worked and, if not, why (stderr tail).  `roofline.rocprof_median_us` / `rocprof_frac` = the dominant kernel's
+median duration from a clean `rocprofv3 --kernel-trace` child pass of this command, next to the event-timed `avg_launch_us`.
 
 `config.variants` (N == 1, default run) also carries, each timed on this box in this run:
   * SURVEY 8(d)'s own protocol (batch 1 x 256 steps) with its wall time decomposed by phase / render and the eager step's
@@ -74,6 +81,19 @@ def maybe_spawn(args) -> None:
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.call(cmd, env=env))
+
+
+def per_rank_miopen_dirs() -> None:
+    """Every rank of a multi-GPU run warms its convolutions with MIOpen's find mode; with ONE user database / kernel cache the eight
+    searches serialise on one sqlite file (and lock-wait each other).  Give each rank its own directories, before MIOpen initialises
+    (whoever launched the ranks: torch.distributed.run from the driver, or maybe_spawn).  Single-rank runs keep the defaults."""
+    if int(os.environ.get('WORLD_SIZE', '1')) <= 1: return
+    r = os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0'))
+    base = os.path.join(tempfile.gettempdir(), f'ppq_miopen_{os.getuid()}_rank{r}')
+    for var, sub in (('MIOPEN_USER_DB_PATH', 'db'), ('MIOPEN_CUSTOM_CACHE_DIR', 'cache')):
+        if var not in os.environ:
+            os.makedirs(os.path.join(base, sub), exist_ok=True)
+            os.environ[var] = os.path.join(base, sub)
 
 
 def setup_dist(n_gpus: int, backend: str = 'nccl', single_device: bool = False):
@@ -343,74 +363,57 @@ def roofline_entry(prof_rows, prefer=None):
             'frac_of_measured_copy_ceiling': round(ach / 6290.0, 4)}      # MI355X_MICROARCH.md: 6.29 TB/s float4 copy
 
 
-def north_star_b_child(bins):
-    """`--b-child` (run under rocprofv3 --kernel-trace by north_star_b): the single-tensor entry points on B = [1,512,56,56],
-    300 launches each over 6 rotating inputs / outputs, in a fixed order the parent knows."""
-    from ppq_amd import CUDA, _lib
-    lib = _lib.lib
-    dev = 'cuda:0'
-    st = torch.cuda.current_stream().cuda_stream
-    g = torch.Generator(device=dev).manual_seed(7)
-    xs = [torch.randn(1, 512, 56, 56, device=dev, generator=g) for _ in range(6)]
-    outs = [torch.empty_like(xs[0]) for _ in range(6)]
-    n, C, epc = xs[0].numel(), 512, 56 * 56
-    sc = torch.rand(C, device=dev, generator=g) * 0.05 + 0.01
-    oc = torch.randint(0, 255, [C], device=dev, generator=g).float()
-    s1 = torch.tensor([0.03], device=dev); o1 = torch.zeros(1, device=dev)
-    hist = torch.zeros(bins, dtype=torch.int32, device=dev)
-    rows = torch.zeros(CUDA.hist_rows(), bins, dtype=torch.int32, device=dev)
-    slots = torch.tensor([float('inf'), float('-inf')], device=dev).repeat(CUDA.minmax_slots(), 1).contiguous()
-    hs = float(xs[0].abs().max()) / bins
-    P = lambda t: t.data_ptr()      # noqa: E731
-    for k in range(4000): outs[k % 6].copy_(xs[k % 6])            # clocks / caches in a steady state
-    torch.cuda.synchronize()
-    for _ in range(3):                                            # three interleaved rounds of 200: a slow stretch does not own one case
-        for k in range(200): lib.ppqhip_fq_linear_c(P(xs[k % 6]), P(sc), P(oc), P(outs[k % 6]), n, C, epc, 0, 255, 0, st)
-        torch.cuda.synchronize()
-        for k in range(200): lib.ppqhip_fq_linear_t(P(xs[k % 6]), P(s1), P(o1), P(outs[k % 6]), n, -128, 127, 0, st)
-        torch.cuda.synchronize()
-        for k in range(200): lib.ppqhip_hist_sym_t_rows(P(xs[k % 6]), n, hs, 1, P(rows), bins, st)
-        torch.cuda.synchronize()
-        for k in range(200): lib.ppqhip_hist_sym_t(P(xs[k % 6]), n, hs, 1, P(hist), bins, None, st)
-        torch.cuda.synchronize()
-        for k in range(200): lib.ppqhip_minmax_t_slots(P(xs[k % 6]), n, P(slots), st)
-        torch.cuda.synchronize()
-
-
-def north_star_b(bins, timeout_s: float = 180.0):
-    """The tensor BASELINE.json's north star names, B = [1,512,56,56] fp32 (6.4 MB), through the single-tensor entry points:
-    MEDIAN device durations from `rocprofv3 --kernel-trace` of a child of this file (`--b-child`) -- these launches are a few
-    microseconds long and latency-bound, event pairs cannot time them (their own overhead is as long as the kernel).  The same
-    numbers next to their floors (empty kernel, pure read, copy, read + atomic combine): profiles/r05_floor_table.txt."""
-    rocprof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
-    if rocprof is None: return None
-    work = tempfile.mkdtemp(prefix='ppq_b_', dir='/tmp')
+def north_star_b(bins):
+    """The tensor BASELINE.json's north star names, B = [1,512,56,56] fp32 (6.4 MB), and B x {2..32}, through the single-tensor entry
+    points, next to FLOOR kernels (empty / pure read / copy / read + atomic combine) measured the same way: tools/north_star.py.
+    Method 1: MEDIAN device durations from `rocprofv3 --kernel-trace` of a child (these launches are a few microseconds long and
+    latency-bound: event pairs cannot time them, their own overhead is as long as the kernel).  Method 2 (always, in this process,
+    no profiler): HIP-graph replay of back-to-back launches / count -- an upper bound that exists on any box.  Returns flat scalars
+    incl. `B_status` (why method 1 failed, when it did: BENCH_r05's line silently lost these keys)."""
     try:
-        cmd = [rocprof, '--output-format', 'csv', '--kernel-trace', '-d', work, '-o', 'b', '--', sys.executable, os.path.abspath(__file__),
-               '--b-child', '--bins', str(bins)]
-        subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
-        files = glob.glob(os.path.join(work, '**', '*kernel_trace.csv'), recursive=True)
-        if not files: return None
-        dur = {}
-        for r in csv.DictReader(open(files[0])):
-            name = r['Kernel_Name'].replace('void ', '').replace('ppqhip::', '').split('(')[0].split('<')[0]
-            key = (name, int(r['Grid_Size_X']) // max(1, int(r['Workgroup_Size_X'])))
-            dur.setdefault(key, []).append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
-        n = 512 * 56 * 56
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import north_star
+        m = north_star.measure(bins)
+        scal = north_star.flat_scalars(m)
+        os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+        try: north_star.report(m, os.path.join(ROOT, 'gpurun_out', 'frac_vs_size.txt'))
+        except Exception: pass
+        return scal
+    except Exception as e:      # never costs the bench line; the status key says why
+        return {'B_status': f'north_star failed: {type(e).__name__}: {e}', 'B_method': None}
 
-        def med(pred):
-            v = sorted(d for k, ds in dur.items() if pred(k) for d in ds)
-            return (v[len(v) // 2] / 1e3, v[len(v) // 10] / 1e3) if len(v) >= 100 else None
-        small = sorted({k[1] for k in dur if k[0] == 'hist_small_kernel'})
-        out = {'fq_linear_c': (8, med(lambda k: k[0] == 'fq_linear_c_tile_kernel')), 'fq_linear_t': (8, med(lambda k: k[0] == 'fq_linear_t_tile_kernel')),
-               'hist_sym_t_rows': (4, med(lambda k: k[0] == 'hist_small_kernel' and len(small) == 2 and k[1] == small[1])),
-               'hist_sym_t_oneshot': (4, med(lambda k: k[0] == 'hist_small_kernel' and len(small) == 2 and k[1] == small[0])),
-               'minmax_t': (4, med(lambda k: k[0] in ('minmax_small_kernel', 'minmax_persistent_kernel')))}
-        return {k: {'us': round(m[0], 2), 'p10_us': round(m[1], 2), 'GBps': round(bpe * n / m[0] / 1e3, 1),
-                    'frac_of_8TBps': round(bpe * n / m[0] / 1e3 / HBM_PEAK_GBPS, 3)}
-                for k, (bpe, m) in out.items() if m}
-    except (subprocess.TimeoutExpired, OSError, KeyError, ValueError):
-        return None
+
+def rocprof_kernel_median(kernel_name: str, child_args: list, timeout_s: float = 240.0):
+    """MEDIAN begin->end device duration [us] of the device kernel(s) behind `kernel_name` from a clean `rocprofv3 --kernel-trace`
+    child pass of this command (no counters): what the event-timed `avg_launch_us` is checked against.  (median, n, note)."""
+    prefixes = DEVICE_KERNELS.get(kernel_name)
+    rocprof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if prefixes is None or rocprof is None: return None, 0, 'rocprofv3 not available'
+    work = tempfile.mkdtemp(prefix='ppq_kt_', dir='/tmp')
+    try:
+        cmd = [rocprof, '--output-format', 'csv', '--kernel-trace', '-d', work, '-o', 'kt', '--', sys.executable, os.path.abspath(__file__)] + child_args
+        try:
+            r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), capture_output=True, text=True, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            return None, 0, f'timeout after {timeout_s:.0f} s'
+        files = glob.glob(os.path.join(work, '**', '*kernel_trace.csv'), recursive=True)
+        if not files: return None, 0, f'no kernel_trace.csv (rc={r.returncode}): {(r.stderr or "")[-200:]!r}'
+        counted_on = LAUNCHES_COUNTED_ON.get(kernel_name)
+        per_launch, cur = [], 0
+        rows = sorted(csv.DictReader(open(files[0])), key=lambda q: int(q['Start_Timestamp']))
+        for q in rows:                                # a logical launch = consecutive device kernels of the family (hist + reduce ..)
+            name = q['Kernel_Name'].replace('void ', '')
+            if not name.startswith(prefixes): continue
+            d = int(q['End_Timestamp']) - int(q['Start_Timestamp'])
+            if counted_on is None: per_launch.append(d)
+            elif name.startswith(counted_on): per_launch.append(cur + d); cur = 0
+            else: cur += d
+        if not per_launch: return None, 0, 'kernel not found in the trace'
+        per_launch.sort()
+        big = [d for d in per_launch if d >= 0.25 * per_launch[-1]]       # the multi-tensor launches of the timed forwards, not warm-up crumbs
+        return round(big[len(big) // 2] / 1e3, 2), len(big), 'clean rocprofv3 --kernel-trace child pass of this command (no counters)'
+    except Exception as e:
+        return None, 0, f'{type(e).__name__}: {e}'
     finally:
         shutil.rmtree(work, ignore_errors=True)
 
@@ -685,6 +688,9 @@ def main():
     ap.add_argument('--steps', type=int, default=8)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--batch', type=int, default=32)
+    ap.add_argument('--total-samples', type=int, default=0,
+                    help='STRONG scaling: a fixed job of this many samples sharded over the ranks (steps = total / (ranks x batch), overrides --steps; '
+                         'BASELINE config 3 = --workload resnet50_cfg3 --total-samples 1024 --gpus 8); scaling is reported as "strong"')
     ap.add_argument('--bins', type=int, default=2048)
     ap.add_argument('--method', type=str, default='kl')
     ap.add_argument('--workload', type=str, default='resnet50', choices=sorted(WORKLOADS),
@@ -695,7 +701,7 @@ def main():
     ap.add_argument('--variants', type=int, default=1, help="also time SURVEY 8(d)'s own protocol (batch 1 x 256 steps) once and report it in config.variants")
     ap.add_argument('--pmc', type=int, default=1, help='measure roofline.traffic with two rocprofv3 --pmc child passes of this command')
     ap.add_argument('--pmc-child', action='store_true', help=argparse.SUPPRESS)
-    ap.add_argument('--b-child', action='store_true', help=argparse.SUPPRESS)
+    ap.add_argument('--kt-child', action='store_true', help=argparse.SUPPRESS)
     ap.add_argument('--host-selftest', action='store_true', help='CPU-only check of spawn + rendezvous + merge (gloo); no GPU work')
     ap.add_argument('--backend', type=str, default='nccl')
     ap.add_argument('--single-device', type=int, default=0, help='debug: put every rank on cuda:0 (use with --backend gloo)')
@@ -717,11 +723,16 @@ def main():
 
     global WORKLOAD
     WORKLOAD = args.workload
+    if args.total_samples > 0:          # strong scaling: the job is fixed, every rank takes total / (ranks x batch) batches of it
+        ranks = int(os.environ.get('WORLD_SIZE', max(1, args.gpus)))
+        per = ranks * args.batch
+        if args.total_samples % per: raise SystemExit(f'--total-samples {args.total_samples} is not a multiple of ranks x batch = {ranks} x {args.batch}')
+        args.steps = args.total_samples // per
+    per_rank_miopen_dirs()
     if WORKLOADS[WORKLOAD][1] is not None: args.method = WORKLOADS[WORKLOAD][1]
     if WORKLOAD != 'resnet50':              # the reference-CPU legs and the batch-1 variant describe config 2 only
         args.no_cpu_baseline = args.no_cpu_ops = True
         args.variants = 0
-    if args.b_child: return north_star_b_child(args.bins)
     maybe_spawn(args)
     if args.host_selftest: return host_selftest(args)
     rank, world, local = setup_dist(args.gpus, args.backend, bool(args.single_device))
@@ -753,7 +764,7 @@ def main():
     # timed region(s): `repeats` independent passes of exactly K steps each
     global TRACE_STEPS
     times, trace, p, graph = [], None, None, None
-    repeats = 1 if (args.trace_steps or args.pmc_child) else max(1, args.repeats)
+    repeats = 1 if (args.trace_steps or args.pmc_child or args.kt_child) else max(1, args.repeats)
     for rep in range(repeats):
         if args.trace_steps:
             TRACE_STEPS = []
@@ -779,7 +790,7 @@ def main():
         times.append(elapsed)
         del ex
     elapsed = sorted(times)[len(times) // 2]
-    if args.pmc_child: return                      # the rocprofv3 --pmc child: counters only, no JSON line
+    if args.pmc_child or args.kt_child: return     # the rocprofv3 children: counters / kernel trace only, no JSON line
     n_obs = sum(1 for op in graph.operations.values() if hasattr(op, 'config') for c, v in op.config_with_variable
                 if not v.is_parameter and int(getattr(c.state, 'value', c.state)) == 4)      # activation configs this pass calibrated
     scale_checksum = float(sum(float(c.scale.sum()) for op in graph.operations.values() if hasattr(op, 'config')
@@ -873,6 +884,12 @@ def main():
                  '--method', args.method, '--workload', args.workload, '--hip-graph', '0', '--miopen-find', '0', '--fuse-params', str(args.fuse_params),
                  '--batch-observations', str(args.batch_observations), '--channels-last', str(args.channels_last)]
         roof['traffic'], roof['traffic_source'] = pmc_traffic(roof['kernel'], child)
+        kt_child = [a for a in child if a != '--pmc-child']
+        kt_child[kt_child.index('--steps') + 1] = str(min(args.steps, 4))
+        med, n_med, note = rocprof_kernel_median(roof['kernel'], kt_child + ['--kt-child'])
+        roof['rocprof_median_us'], roof['rocprof_launches'], roof['rocprof_source'] = med, n_med, note
+        if med:
+            roof['rocprof_frac'] = round(roof['algorithmic_bytes_per_launch'] / (med * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
 
     cpu = cpu_ops = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -910,10 +927,7 @@ def main():
                 key = {'resnet50_cfg3': 'cfg3', 'vit_b16_fp8': 'cfg4', 'yolov6s_int4_lsq': 'cfg5'}[v['name']]
                 scalars[f'{key}_roofline_frac'] = v['roofline'].get('frac')
                 scalars[f'{key}_spread_pct'] = v.get('spread_pct')
-        nsb = north_star_b(args.bins)             # rocprofv3 --kernel-trace medians of a child (None without rocprofv3)
-        for k_, r_ in (nsb or {}).items():
-            scalars[f'B_{k_}_rocprof_median_us'] = r_['us']; scalars[f'B_{k_}_rocprof_p10_us'] = r_['p10_us']
-            scalars[f'B_{k_}_frac_of_8TBps'] = r_['frac_of_8TBps']
+        scalars.update(north_star_b(args.bins))   # B_* keys: rocprofv3 medians + graph-replay bound + floors + B_status
     if rank == 0:
         samples = world * args.steps * args.batch
         out = {
@@ -921,16 +935,26 @@ def main():
                        else f'calibration samples/sec (RuntimeCalibrationPass, {args.method}, {args.bins} bins, {WORKLOAD})'),
             'value': round(samples / elapsed, 2), 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32' if WORKLOAD != 'vit_b16_fp8' else 'f32 (FP8 E4M3 simulated)', 'data': 'synthetic',
+            'scaling': 'strong' if args.total_samples > 0 else 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if WORKLOAD != 'vit_b16_fp8' else 'f32 (FP8 E4M3 simulated)', 'data': 'synthetic',
             'repeats': len(times), 'values': [round(samples / t, 2) for t in times],
             'spread_pct': round(100.0 * (max(times) - min(times)) / elapsed, 2),
             'config': {'workload': (f'ResNet-50 topology (53 Conv + 1 Gemm, BN folded, seeded He init), '
                                     f'RuntimeCalibrationPass {args.method} {args.bins} bins, per-tensor INT8 activations, '
-                                    f'per-channel INT8 weights, {args.steps} batches x {args.batch} x 3x224x224 per GPU') if WORKLOAD == 'resnet50'
-                       else f'{WORKLOADS[WORKLOAD][0]}; RuntimeCalibrationPass {args.method}, {args.bins} bins, {args.steps} batches x {args.batch} x 3x224x224 per GPU',
+                                    f'per-channel INT8 weights, {args.steps} batches x {args.batch} x 3x224x224 per GPU'
+                                    + (f' = a fixed job of {args.total_samples} samples sharded over {world} ranks' if args.total_samples else '')) if WORKLOAD == 'resnet50'
+                       else (f'{WORKLOADS[WORKLOAD][0]}; RuntimeCalibrationPass {args.method}, {args.bins} bins, {args.steps} batches x {args.batch} x 3x224x224 per GPU'
+                             + (f' = a fixed job of {args.total_samples} samples sharded over {world} ranks' if args.total_samples else '')),
                        'samples': samples, 'batch': args.batch, 'observed_tensors': n_obs,
                        'parallelism': f'dp{world} (batches sharded; per phase 1 layout-probe MAX + 1 data all-reduce over one flat buffer)',
                        'rccl_ranks': world, 'backend': args.backend if world > 1 else None, 'merge': merge_stats,
+                       'total_samples': args.total_samples or None,
+                       # the merges as flat scalars (the driver keeps scalar keys): one layout probe + one data all-reduce per phase
+                       'merge_phase1_ms': merge_stats[0].get('ms') if len(merge_stats) > 0 else None,
+                       'merge_phase2_ms': merge_stats[1].get('ms') if len(merge_stats) > 1 else None,
+                       'merge_collectives_per_phase': merge_stats[0].get('collectives') if merge_stats else None,
+                       'merge_phase1_bytes': (merge_stats[0].get('min_f32_bytes') if merge_stats else None),
+                       'merge_phase2_bytes': (merge_stats[1].get('sum_int32_bytes') if len(merge_stats) > 1 else None),
                        **scalars,
                        'variants': variants,
                        'async_observe': bool(args.async_observe), 'cache_params': bool(args.cache_params),

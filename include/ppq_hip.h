@@ -337,6 +337,12 @@ typedef struct ppqhip_hist_job {
 int ppqhip_hist_t_rows_multi(const ppqhip_hist_job* jobs, int num_jobs, int asymmetric,
                              int clip_outliers, int64_t num_bins, void* stream);
 int ppqhip_hist_rows_finish(const int32_t* rows, int64_t num_bins, int32_t* hist, void* stream);
+/* test aid (tests/test_gpu_kernels.py: all 2^32 float patterns): the histogram kernels compute floor(a / hist_scale) from a
+ * reciprocal multiply with a proven exactness test and a true-division fallback (ppq_amd/csrc/hist.hip: Binner::bins4 / bin1), where
+ * the reference divides (sort.cu:84-86 / :133-135).  This runs BOTH forms of that device code on every element of x (n % 4 == 0,
+ * 16-B aligned) and counts raw bin indices that differ: out[0] packed path, out[1] scalar-tail path, out[2] one offending bit
+ * pattern.  `out`: device, 3 x uint64, zeroed by the caller.  asymmetric = 0: a = |x|; 1: a = x - min_value. */
+int ppqhip_check_bin_rule(const float* x, int64_t n, float min_value, float hist_scale, int asymmetric, uint64_t* out, void* stream);
 int64_t ppqhip_minmax_slots(void);
 int ppqhip_minmax_t_slots(const float* x, int64_t n, float* slots, void* stream);
 int ppqhip_minmax_slots_finish(const float* slots, float* minmax, void* stream);

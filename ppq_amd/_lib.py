@@ -78,6 +78,7 @@ PROTOTYPES = {
     'ppqhip_hist_sym_t_rows': (c_int, [c_f32p, c_i64, c_flt, c_int, c_i32p, c_i64, c_vp]),
     'ppqhip_hist_asym_t_rows': (c_int, [c_f32p, c_i64, c_flt, c_flt, c_int, c_i32p, c_i64, c_vp]),
     'ppqhip_hist_rows_finish': (c_int, [c_i32p, c_i64, c_i32p, c_vp]),
+    'ppqhip_check_bin_rule': (c_int, [c_f32p, c_i64, c_flt, c_flt, c_int, c_vp, c_vp]),
     'ppqhip_minmax_slots': (c_i64, []),
     'ppqhip_minmax_t_slots': (c_int, [c_f32p, c_i64, c_f32p, c_vp]),
     'ppqhip_minmax_slots_finish': (c_int, [c_f32p, c_f32p, c_vp]),

@@ -106,16 +106,11 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
 
     @ staticmethod
     def _forward_fn(executor):
-        """What one calibration forward calls.  The reference's ``TorchExecutor.forward`` (executor/torch.py:325-410) is its
-        PUBLIC ``forward_with_gradient`` (:412-456, the same loop over ``_executing_order``) wrapped in ``torch.no_grad()`` and
-        ``@empty_ppq_cache`` -- ``torch.cuda.empty_cache(); gc.collect()`` before EVERY batch (core/defs.py:43-55): ~8 ms of host
-        time per call (most of a batch-1 step) and, because it frees device memory, illegal inside a HIP-graph capture.  On that
-        executor the pass therefore calls ``forward_with_gradient`` under its own ``torch.no_grad()``: the same operations on the
-        same tensors, without emptying the allocator between batches.  Any other executor (this package's harness, a user's
-        own) is called through ``forward`` as before."""
-        cls = type(executor)
-        if cls.__module__.startswith('ppq.') and hasattr(executor, 'forward_with_gradient') and hasattr(executor, '_executing_order'):
-            return executor.forward_with_gradient
+        """What one calibration forward calls: the executor's public ``forward``.  (The reference's ``TorchExecutor.forward``,
+        executor/torch.py:365-410, is its ``forward_with_gradient`` under ``@torch.no_grad()`` -- the same loop over
+        ``_executing_order``; only ``tracing_operation_meta`` (:579-580) carries ``@empty_ppq_cache``.  Rounds 4-5 called
+        ``forward_with_gradient`` here in the belief that ``forward`` emptied the allocator before every batch; it does not, and
+        the batch-1 seam figures (94.7 -> 325 samples/s) come from the HIP-graph replay of that loop, not from a skipped flush.)"""
         return executor.forward
 
     def _forward(self, executor, data, hooks, output_names):

@@ -38,7 +38,7 @@ int check_hip(hipError_t e, const char* what);
 enum KernelId : int {
     K_FQ_LINEAR_T = 0, K_FQ_LINEAR_C, K_FQ_LINEAR_T_BWD, K_FQ_LINEAR_C_BWD, K_FQ_FLOAT_T, K_FQ_FLOAT_C,
     K_FQ_FLOAT_BWD, K_HIST_SYM_T, K_HIST_ASYM_T, K_HIST_SYM_C, K_QUANTILE, K_ISOTONE, K_MINMAX_T,
-    K_MINMAX_C, K_MSE_SEARCH, K_KL_LOSSES, K_TENSOR_CLIP, K_ROUNDING_LOSS, K_CHANNEL_SUM, K_FLOAT_SCALE_SEARCH, K_NUM
+    K_MINMAX_C, K_MSE_SEARCH, K_KL_LOSSES, K_TENSOR_CLIP, K_ROUNDING_LOSS, K_CHANNEL_SUM, K_FLOAT_SCALE_SEARCH, K_LSQ_FINISH, K_NUM
 };
 extern const char* const kKernelNames[K_NUM];
 

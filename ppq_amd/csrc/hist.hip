@@ -402,6 +402,32 @@ __global__ __launch_bounds__(kHistBlock) void hist_small_kernel(const float* __r
     }
 }
 
+// ---- exactness self-check of the reciprocal bin rule (test aid: tests/test_gpu_kernels.py sweeps all 2^32 float patterns) ----
+// Every float4 goes through Binner::bins4 (the packed reciprocal path with its fallback) AND through Binner::exact_bin (the
+// reference's floor(a / hs), sort.cu:84-86) element by element; every element also through bin1 (the scalar-tail form).  RAW bin
+// indices are compared (before clipping / clamping: a stronger statement than equal histograms).  out[0] / out[1]: elements whose
+// bins4 / bin1 index differs from exact_bin; out[2]: bit pattern of one offending element.
+template <bool ASYM>
+__global__ __launch_bounds__(kBlock) void check_bin_rule_kernel(const float4* __restrict__ x, uint32_t nvec, float a, float hs,
+                                                                unsigned long long* __restrict__ out) {
+    Binner<ASYM, true, false> acc;
+    acc.init(nullptr, 1);
+    acc.set_rule(a, hs);
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < nvec; i += stride) {
+        const float4 v = x[i];
+        int b[4];
+        acc.bins4(v, b);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int want = acc.exact_bin(ASYM ? (e[k] - a) : __builtin_fabsf(e[k]));
+            if (b[k] != want) { atomicAdd(&out[0], 1ull); out[2] = __float_as_uint(e[k]); }
+            if (acc.bin1(e[k]) != want) { atomicAdd(&out[1], 1ull); out[2] = __float_as_uint(e[k]); }
+        }
+    }
+}
+
 // histograms too large for LDS: global atomics (the reference's strategy)
 __device__ __forceinline__ bool bin_of(float v, const BinRule& r, int* b_out) {
     const float a = r.asym ? (v - r.a) : __builtin_fabsf(v);
@@ -828,6 +854,19 @@ int ppqhip_hist_t_rows_multi(const ppqhip_hist_job* jobs, int num_jobs, int asym
     LaunchScope scope(asymmetric ? K_HIST_ASYM_T : K_HIST_SYM_T, bytes, s);
     if (int st = launch_hist_multi(jobs, num_jobs, (int)num_bins, clip_outliers ? 1 : 0, asymmetric ? 1 : 0, s)) return st;
     return finish_launch("hist_t_rows_multi");
+}
+
+int ppqhip_check_bin_rule(const float* x, int64_t n, float min_value, float hist_scale, int asymmetric, uint64_t* out, void* stream) {
+    if (n <= 0 || n > 0x7fffffffLL || (n & 3) || !aligned16(x) || out == nullptr) {
+        set_error("check_bin_rule: n must be a positive multiple of 4 below 2^31, x 16-B aligned, out non-null"); return PPQHIP_ERR_INVALID_VALUE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nvec = (uint32_t)(n >> 2);
+    if (asymmetric) hipLaunchKernelGGL((check_bin_rule_kernel<true>), dim3(stream_grid(nvec, kBlock)), dim3(kBlock), 0, s, (const float4*)x, nvec,
+                                       min_value, hist_scale, (unsigned long long*)out);
+    else hipLaunchKernelGGL((check_bin_rule_kernel<false>), dim3(stream_grid(nvec, kBlock)), dim3(kBlock), 0, s, (const float4*)x, nvec,
+                            0.f, hist_scale, (unsigned long long*)out);
+    return finish_launch("check_bin_rule");
 }
 
 int ppqhip_hist_rows_finish(const int32_t* rows, int64_t num_bins, int32_t* hist, void* stream) {

@@ -339,6 +339,7 @@ __global__ __launch_bounds__(kLsqFinishBlock) void lsq_finish_kernel(const float
 constexpr int kLsqFinishMax = 96;
 struct LsqFinishJob { const float* partial; float* gs; uint32_t count; float grad_factor; };      // 24 B
 struct LsqFinishArgs { LsqFinishJob job[kLsqFinishMax]; };
+static_assert(sizeof(LsqFinishArgs) <= 4096, "kernel arguments are limited to 4 KB");
 __global__ __launch_bounds__(kLsqFinishBlock) void lsq_finish_multi_kernel(const LsqFinishArgs args) {
     __shared__ double lds[kLsqFinishBlock / kWave];
     const LsqFinishJob& j = args.job[blockIdx.x];
@@ -883,6 +884,9 @@ int ppqhip_lsq_finish_multi(const ppqhip_lsq_finish_job* jobs, int num_jobs, voi
     if (num_jobs <= 0) return PPQHIP_OK;
     if (jobs == nullptr) { set_error("lsq_finish_multi: jobs is null"); return PPQHIP_ERR_INVALID_VALUE; }
     hipStream_t s = (hipStream_t)stream;
+    double bytes = 0.0;
+    for (int k = 0; k < num_jobs; k++) if (jobs[k].n > 0) bytes += 4.0 * (double)lsq_t_grid(jobs[k].n);      // the partial sums it folds
+    LaunchScope scope(K_LSQ_FINISH, bytes, s);
     for (int base = 0; base < num_jobs; base += kLsqFinishMax) {
         const int count = (num_jobs - base) < kLsqFinishMax ? (num_jobs - base) : kLsqFinishMax;
         LsqFinishArgs args;

@@ -30,7 +30,7 @@ int finish_launch(const char* what) { return check_hip(hipGetLastError(), what);
 const char* const kKernelNames[K_NUM] = {
     "fq_linear_t", "fq_linear_c", "fq_linear_t_bwd", "fq_linear_c_bwd", "fq_float_t", "fq_float_c",
     "fq_float_bwd", "hist_sym_t", "hist_asym_t", "hist_sym_c", "quantile_t", "isotone_t", "minmax_t",
-    "minmax_c", "mse_search", "kl_losses", "tensor_clip", "rounding_loss", "channel_sum", "float_scale_search"};
+    "minmax_c", "mse_search", "kl_losses", "tensor_clip", "rounding_loss", "channel_sum", "float_scale_search", "lsq_finish"};
 
 int num_cu() {
     static std::mutex mu;

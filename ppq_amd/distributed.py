@@ -129,7 +129,7 @@ def merge_observers(observers: Sequence, group=None, even_if_single_rank: bool =
         dist.all_gather(all_rows, rows, group=group)
         width = [int(b.shape[1]) for b in flat_bufs]
         cap = [int(max(int(r[k]) for r in all_rows)) for k in range(len(flat_bufs))]
-        mine = torch.cat([torch.cat([b.reshape(b.shape[0], -1).float(),
+        mine = torch.cat([torch.cat([b.reshape(b.shape[0], width[k]).float(),        # (a rank may bring ZERO rows: no -1 here)
                                      torch.zeros(cap[k] - b.shape[0], width[k], dtype=torch.float32, device=device)]).reshape(-1)
                           for k, b in enumerate(flat_bufs)])
         everyone = [torch.empty_like(mine) for _ in range(world)]

@@ -854,16 +854,14 @@ class _HipExtension:
     @ staticmethod
     def minmax_c_outer_is_one(value, channel_axis: int) -> bool:
         """True for parameter-shaped tensors: the channel axis is the outermost one that is not 1 (one row per channel)."""
-        v = _dense(value, channel_axis)
-        C, epc = _geometry(v.shape, channel_axis)
-        return v.numel() == C * epc
+        C, epc = _geometry(value.shape, channel_axis)      # a shape question: no layout copy of a non-contiguous tensor for it
+        return value.numel() == C * epc
 
     @ staticmethod
     def minmax_c_fresh_ok(value, channel_axis: int) -> bool:
         """True when ``MinMax_C_Multi(fresh=True)`` will OVERWRITE this item's mins / maxs (see there)."""
-        v = _dense(value, channel_axis)
-        C, epc = _geometry(v.shape, channel_axis)
-        return v.numel() == C * epc and epc <= 8192
+        C, epc = _geometry(value.shape, channel_axis)
+        return value.numel() == C * epc and epc <= 8192
 
     @ staticmethod
     def ChannelSum(value, channel_axis: int, sums) -> None:
@@ -1173,6 +1171,14 @@ class CUDA:
     def RoundingLoss_LC_B(tensor, dy, scales, offsets, channel_axis: int, minimum: int = -128, maximum: int = 127,
                           rounding: int = 0):
         return HIP_EXTENSION.RoundingLoss_LC_B(tensor, dy, scales, offsets, minimum, maximum, channel_axis, rounding)
+
+    @ staticmethod
+    def OrderPreservingObserve(tensor):
+        """ppq/core/ffi.py:257-261, kept for surface completeness: the reference wires this name to ``RoundingLoss_LC_B`` with ONE
+        argument, so every call fails in the extension's argument check (pybind: TypeError) -- nothing in ppq calls it.  Same
+        wiring, same outcome here."""
+        if not tensor.is_contiguous(): tensor = tensor.contiguous()
+        return CUDA_COMPLIER.CUDA_EXTENSION.RoundingLoss_LC_B(tensor)
 
     @ staticmethod
     def compute_mse_loss(histogram: list, start: int, step: int, end: int) -> float:

@@ -10,6 +10,8 @@ kernels.  HIP path only: a CPU tensor raises.
 """
 from typing import List
 
+import warnings
+
 import torch
 from torch.autograd import Function
 
@@ -523,13 +525,20 @@ class LearnedStepSizePass(QuantizationOptimizationPass):
             opt = None
             if self.fused_adam:                        # ONE multi-tensor kernel per step instead of the foreach form's 6-8 small ones
                 try: opt = torch.optim.Adam(uniq, lr=self.lr, capturable=True, fused=True)
-                except (RuntimeError, ValueError, TypeError) as e: self.stats['fused_adam_error'] = f'{type(e).__name__}: {str(e)[:200]}'
+                except (RuntimeError, ValueError, TypeError) as e:
+                    self.stats['fused_adam_error'] = f'{type(e).__name__}: {str(e)[:200]}'
+                    if not getattr(LearnedStepSizePass, '_warned_fused_adam', False):
+                        LearnedStepSizePass._warned_fused_adam = True
+                        warnings.warn(f'LearnedStepSizePass: fused Adam unavailable ({self.stats["fused_adam_error"]}); using the foreach capturable form')
             if opt is None: opt = torch.optim.Adam(uniq, lr=self.lr, capturable=True)
             else: self.stats['fused_adam_blocks'] = self.stats.get('fused_adam_blocks', 0) + 1
         else: opt = torch.optim.Adam(uniq, lr=self.lr)
 
         def train_step(qt_input, fp_output) -> None:
             opt.zero_grad()
+            # a step that aborted between a backward and its flush (a failed graph capture) must not leak half-built state into
+            # this one: partial sums whose kernels never ran would be finished and ADDED to the scale gradients
+            if act_group is not None: act_group.live.clear()
             for g in groups: g.prepare()
             with torch.enable_grad():
                 outs = block_forward(executor, block.rps, qt_input, names, with_gradient=True)

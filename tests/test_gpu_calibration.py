@@ -1074,6 +1074,25 @@ def test_bench_two_ranks_on_one_gpu():
         assert key in one
 
 
+def test_bench_strong_scaling_mode_two_ranks_on_one_gpu():
+    """BASELINE config 3 is a FIXED job ("1024 samples sharded across 8"): `--total-samples S` derives the steps per rank from the
+    job and the rank count and reports `scaling: strong`.  Two gloo ranks on this one GPU, 32 samples: 2 ranks x 4 steps x batch 4;
+    the same job on one rank is 8 steps -- and, the statistics being sums / minima over samples, a job that is not a multiple of
+    ranks x batch is refused rather than silently shrunk."""
+    small = ['--warmup', '1', '--repeats', '1', '--no-cpu-baseline', '--no-cpu-ops', '--pmc', '0', '--settle-ms', '0', '--variants', '0', '--miopen-find', '0',
+             '--workload', 'resnet50_cfg3', '--batch', '4', '--total-samples', '32']
+    two = _run_bench('--gpus', '2', '--backend', 'gloo', '--single-device', '1', *small)
+    assert two['scaling'] == 'strong' and two['n_gpus'] == 2 and two['steps'] == 4 and two['config']['samples'] == 32
+    assert two['config']['total_samples'] == 32 and two['config']['merge_collectives_per_phase'] == 1
+    assert two['config']['merge_phase1_ms'] > 0 and two['config']['merge_phase2_bytes'] == 72 * 2048 * 4
+    one = _run_bench(*small)
+    assert one['scaling'] == 'strong' and one['n_gpus'] == 1 and one['steps'] == 8 and one['config']['samples'] == 32
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--batch', '5', '--total-samples', '32'], capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and 'not a multiple' in (r.stderr + r.stdout)
+
+
 @pytest.mark.parametrize('workload', ['resnet50_cfg3', 'yolov6s_int4_lsq'])
 def test_bench_two_ranks_on_one_gpu_configs_3_and_5(workload):
     """BASELINE configs 3 (ResNet-50, MSE search, asymmetric, histograms merged with an all-reduce) and 5 (YOLOv6-s-like INT4 LSQ,

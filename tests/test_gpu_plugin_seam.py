@@ -191,8 +191,7 @@ def test_hip_graph_replay_through_the_reference_executor(topology, size, steps):
     """Seam B at SURVEY 8(d)'s literal protocol size (batch 1) with ``use_hip_graph=True``: what is captured is the REFERENCE's
     TorchExecutor loop (executor/torch.py:457-577) -- its operation table, its per-weight fake-quant calls into these kernels,
     this package's hooks / observers / one statistics launch per forward -- and the remaining batches are graph replays.  The pass
-    enters through ``forward_with_gradient`` under ``no_grad`` (``forward`` = the same loop behind ``torch.cuda.empty_cache();
-    gc.collect()``, which cannot be captured: calibration._forward_fn).  Must really replay, and leave the eager seam's scales:
+    enters through the executor's public ``forward`` (``forward_with_gradient`` under ``no_grad``: calibration._forward_fn).  Must really replay, and leave the eager seam's scales:
     exactly on the small topology; on ResNet-50 up to what the vendor convolutions' own run-to-run rounding can move a KL
     arg-min (most scales equal, every scale within one candidate step = 128 / chosen range <= 12.5 %)."""
     import ppq_amd

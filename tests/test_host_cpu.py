@@ -323,6 +323,93 @@ def test_merge_guards_the_int32_histogram_limit():
         assert fits == [2_000_000_000, 10, 15] and widened == 1
 
 
+def _world8_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ppq_amd import distributed as D
+
+    class Ob:
+        def __init__(self, bufs): self.bufs = bufs
+        def reducible(self): return self.bufs
+
+    class RowSet:
+        def __init__(self, rows): self.rows, self.got = rows, None
+        def reducible(self): return []
+        def gatherable(self): return [self.rows]
+        def take_gathered(self, merged): self.got = merged[0]
+    g = torch.Generator().manual_seed(500 + rank)
+    # (1) the ordinary two-phase payload at ResNet-50 size: 72 ranges, 72 x 2048 int32 histograms, percentile sums, FP8 SSEs, row sets
+    rngs = [torch.stack([-torch.rand(1, generator=g), torch.rand(1, generator=g)]).reshape(2) for _ in range(72)]
+    chan = torch.stack([torch.randn(64, generator=g) - 1, torch.randn(64, generator=g) + 1])
+    hists = [torch.randint(0, 1000, [2048], generator=g, dtype=torch.int32) for _ in range(72)]
+    pct = torch.tensor([1.0 + rank, -2.0 - rank, 1.0])
+    sse = torch.arange(8, dtype=torch.float64) * (rank + 1)
+    rows = RowSet(torch.tensor([[100.0 * rank + i, float(i)] for i in range((rank * 3) % 5)]).reshape(-1, 2))     # ragged: 0,3,1,4,2,0,3,1 rows
+    obs = [Ob([(r[0:1], 'min'), (r[1:2], 'max')]) for r in rngs] + [Ob([(chan[0], 'min'), (chan[1], 'max')])] + \
+          [Ob([(h, 'sum')]) for h in hists] + [Ob([(pct, 'sum')]), Ob([(sse, 'sum')]), rows]
+    issued = D.merge_observers(obs)
+    stats1 = dict(D.last_merge_stats)
+    digest = (float(sum(float(r[0]) for r in rngs)), float(sum(float(r[1]) for r in rngs)), float(chan[0].sum()), float(chan[1].sum()),
+              int(sum(int(h.sum()) for h in hists)), pct.tolist(), sse.tolist(), rows.got.tolist())
+    # (2) forced widening: 8 x 3e8 = 2.4e9 could wrap -> int64 sum; the true sums fit (bin 0) ...
+    fits = torch.tensor([300_000_000 if rank == 0 else 100_000_000, rank, 1], dtype=torch.int32)
+    D.merge_observers([Ob([(fits, 'sum')])])
+    widened = D.last_merge_stats.get('sum_int32_widened', 0)
+    # ... and a real overflow raises on every rank
+    big = torch.tensor([300_000_000, 1], dtype=torch.int32)
+    try: D.merge_observers([Ob([(big, 'sum')])]); overflow = 'no error'
+    except OverflowError as e: overflow = str(e)
+    # (3) one rank (5) lacks an observer: the documented error on EVERY rank, no hang
+    obs3 = [Ob([(torch.zeros(16, dtype=torch.int32), 'sum')])]
+    if rank != 5: obs3.append(Ob([(torch.zeros(16, dtype=torch.int32), 'sum')]))
+    try: D.merge_observers(obs3); mismatch = 'no error'
+    except RuntimeError as e: mismatch = str(e)
+    q.put((rank, issued, stats1.get('world_size'), digest, fits.tolist(), widened, overflow, mismatch))
+    dist.destroy_process_group()
+
+
+def test_merge_observers_gloo_world8():
+    """The merge at the world size the north star names (8 ranks): layout probe, one MIN + one SUM per dtype +
+    the ragged row-set gather (two ranks contribute ZERO rows), the forced int32 -> int64 widening, a real overflow, and a rank with
+    a missing observer -- the merged statistics equal the single-process reduction over the eight shards on every rank."""
+    import torch.multiprocessing as mp
+    world = 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_world8_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)])
+    for p in procs: p.join(timeout=60)
+    mins = maxs = 0.0; cmin = cmax = None; total = 0; want_rows = []
+    lo_sum, hi_sum = torch.zeros(72), torch.zeros(72)
+    per = []
+    for rank in range(world):
+        g = torch.Generator().manual_seed(500 + rank)
+        rngs = [torch.stack([-torch.rand(1, generator=g), torch.rand(1, generator=g)]).reshape(2) for _ in range(72)]
+        chan = torch.stack([torch.randn(64, generator=g) - 1, torch.randn(64, generator=g) + 1])
+        hists = [torch.randint(0, 1000, [2048], generator=g, dtype=torch.int32) for _ in range(72)]
+        per.append((torch.stack(rngs), chan, sum(int(h.sum()) for h in hists)))
+        want_rows += [[100.0 * rank + i, float(i)] for i in range((rank * 3) % 5)]
+    all_r = torch.stack([p_[0] for p_ in per])                      # [world, 72, 2]
+    want_lo = float(sum(float(v) for v in all_r[:, :, 0].min(0).values)); want_hi = float(sum(float(v) for v in all_r[:, :, 1].max(0).values))
+    want_cmin = float(torch.stack([p_[1][0] for p_ in per]).min(0).values.sum()); want_cmax = float(torch.stack([p_[1][1] for p_ in per]).max(0).values.sum())
+    want_total = sum(p_[2] for p_ in per)
+    for rank, issued, ws, digest, fits, widened, overflow, mismatch in res:
+        assert issued == 6 and ws == 8
+        lo, hi, cmn, cmx, tot, pct, sse, rows = digest
+        assert abs(lo - want_lo) < 1e-4 and abs(hi - want_hi) < 1e-4 and abs(cmn - want_cmin) < 1e-3 and abs(cmx - want_cmax) < 1e-3
+        assert tot == want_total
+        assert pct == [float(sum(1 + r for r in range(8))), float(sum(-2 - r for r in range(8))), 8.0]
+        assert sse == [float(k * 36) for k in range(8)]
+        assert rows == want_rows
+        assert fits == [1_000_000_000, 28, 8] and widened == 1
+        assert 'reaches 2^31' in overflow, overflow
+        assert 'different statistics layouts' in mismatch, mismatch
+
+
 def test_merge_is_noop_without_process_group():
     from ppq_amd.distributed import merge_observers, shard_batches
 
@@ -1399,11 +1486,10 @@ def test_isotone_pass_marks_the_same_configs_as_the_reference(monkeypatch):
     assert marked >= 20
 
 
-def test_calibration_pass_enters_the_reference_executor_below_its_cache_emptying_wrapper():
-    """RuntimeCalibrationPass._forward_fn: on the reference's own TorchExecutor (a class of a `ppq.` module with the public
-    `forward_with_gradient` next to `forward` and an `_executing_order`) the pass calls `forward_with_gradient` -- `forward` is the
-    same loop behind `torch.cuda.empty_cache(); gc.collect()` (core/defs.py:43-55), which no HIP graph can capture -- and runs it
-    under its own no_grad; every other executor (this package's harness, a user's) is entered through `forward`."""
+def test_calibration_pass_enters_every_executor_through_its_public_forward():
+    """RuntimeCalibrationPass._forward_fn: the reference's ``TorchExecutor.forward`` is ``forward_with_gradient`` under
+    ``@torch.no_grad()`` (executor/torch.py:365-410; ``@empty_ppq_cache`` decorates only ``tracing_operation_meta``, :579-580), so
+    the pass calls ``forward`` on the reference's executor as on any other -- under its own no_grad."""
     import torch
     from ppq_amd.calibration import RuntimeCalibrationPass
     calls = []
@@ -1416,16 +1502,22 @@ def test_calibration_pass_enters_the_reference_executor_below_its_cache_emptying
 
     class Other(RefLike): pass
     Other.__module__ = 'ppq_amd.harness'
-
-    class NoOrder:
-        def forward(self, inputs, output_names=None, hooks=None): calls.append(('forward', torch.is_grad_enabled()))
-        def forward_with_gradient(self, inputs, output_names=None, hooks=None): calls.append(('forward_with_gradient', torch.is_grad_enabled()))
-    NoOrder.__module__ = 'ppq.somewhere'
     p = RuntimeCalibrationPass(method='minmax')
     with torch.enable_grad():
-        for ex in (RefLike(), Other(), NoOrder()):
+        for ex in (RefLike(), Other()):
             p._forward(ex, torch.zeros(1), {}, None)
-    assert calls == [('forward_with_gradient', False), ('forward', False), ('forward', False)]
+    assert calls == [('forward', False), ('forward', False)]
+
+
+def test_cuda_mirror_carries_order_preserving_observe_with_the_reference_wiring():
+    """ppq/core/ffi.py:257-261: `CUDA.OrderPreservingObserve(tensor)` forwards ONE argument to `RoundingLoss_LC_B` -- every call
+    fails in the extension's argument check (TypeError from pybind there, from the Python signature here); nothing in ppq calls it.
+    The name exists for surface completeness (missing 4)."""
+    import torch
+    from ppq_amd import CUDA
+    assert callable(CUDA.OrderPreservingObserve)
+    with pytest.raises(TypeError):
+        CUDA.OrderPreservingObserve(torch.zeros(4))
 
 
 def test_only_parameter_shaped_tensors_join_the_queued_per_channel_minmax():
