@@ -26,8 +26,10 @@
 //                             With nothing open each returns on one load.
 //
 // The result is exact in every case; the hint only decides how much is read.  Hot path: 7 launches, 4 of them return on one load;
-// ONE small tensor with an extreme q (a single-tensor call from the reference's percentile observer): 5 launches -- F1 F2 F3 are one
-// launch of one workgroup there (quantile_f123_single_kernel).
+// ONE small tensor with an extreme q and no hint: 5 launches -- F1 F2 F3 are one launch of one workgroup there
+// (quantile_f123_single_kernel).  ONE tensor WITH a hint (what the reference's percentile observer calls per tensor and batch
+// through install_into_ppq()): two launches, see "ONE hinted tensor" below -- 26.4 -> 10.1 us on [1,512,56,56], 0.36 -> 0.59 of
+// 8 TB/s on 32 x that (rocprofv3 medians, profiles/r06_*).
 #include <cmath>
 #include <cstdlib>
 #include "common.hpp"
@@ -1233,10 +1235,780 @@ __global__ __launch_bounds__(kBlock) void quantile_f123_single_kernel(const QSeq
 #define PPQHIP_Q_SINGLE_ELEMS (4ll << 20)
 #endif
 
+// ---- ONE hinted tensor: two launches ----------------------------------------------------------------------------------
+// What the reference's percentile observer does per tensor per batch (observer/range.py:349 -> CUDA.Quantile -> sort.cu:42-59)
+// arrives here as ONE tensor with the hint of its observer.  The general sequence above spends five launches on it -- init,
+// sample (returns on one load), filter, select A, F1..F3 (return on one load): 26 us of device time on [1,512,56,56], of which
+// the filter's read is 5 -- because each launch decides on the DEVICE what the next one has to do (is the hint usable? did the
+// lists settle both sides?), and the host cannot know without a synchronisation.  This path keeps every decision on the device
+// and still launches only twice:
+//   quantile_hot_filter_kernel   the filter with its arguments by value (no job table, no prefix arrays, no init launch).  The
+//                                hint is read by every workgroup; a usable one filters the tensor in one pass and every workgroup
+//                                leaves its keys in ITS OWN record (count, tie count, six keys inline; more keys in its slot) --
+//                                no reservation atomics, nothing shared, no fences: the kernel boundary publishes the records.
+//                                It also publishes the thresholds it used and zeroes the state of the launch behind it.
+//   quantile_hot_select_kernel   one workgroup per CU.  Workgroup 0 (big lists: workgroups 0 and 1, one side each) reads the records
+//                                -- thread t holds the keys of filter workgroup t in registers --, counts ONE histogram round on
+//                                fixed bit positions of (key - T - 1), picks the 2^11-key-wide bin of the wanted rank, collects the
+//                                handful of keys of that bin and lets one wavefront finish on them (select A's rules decide
+//                                settled / keep-the-hint); the other workgroups poll ONE word.
+//                                Settled (the common case): workgroup 0 writes dest and the hint, everybody returns.  Not
+//                                settled (no usable hint yet, a list that overflowed or came up short): the SAME launch runs
+//                                the exact radix select over the whole tensor -- 12 + 12 + 8 key bits, three levels whose chunks
+//                                are handed out through a counter, so nothing waits for a workgroup that is not resident --
+//                                and leaves a hint computed from the exact histograms (F2's rule: a threshold that lists ~1.5x
+//                                the wanted keys; F3's rule: ON a heavily tied answer), so the next batch is settled by the filter.
+// What shaped the select (s_memrealtime stamps, tools/quantile_hot_stamps.py): a single workgroup's chain of barrier-separated
+// LDS stages costs 0.3-0.6 us per stage whatever it computes; __shfl-based scans are ds_bpermute round trips (DPP instead); 512
+// LDS atomics on one address serialise (one per wavefront instead); values that are wave uniform but live in vector registers
+// turn every test into an EXEC-mask branch (readfirstlane); one CU pulls ~64 B/clk, so what it reads must be compact.
+// Results are exact in every case, as everywhere in this file: the hint only decides how much is read.
+#ifndef PPQHIP_QH_POLL_SLEEP
+#define PPQHIP_QH_POLL_SLEEP 2                      // s_sleep argument of the workgroups that wait for the decision
+#endif
+#ifndef PPQHIP_QH_POLL_FIRST
+#define PPQHIP_QH_POLL_FIRST 32                     // .. before their first look
+#endif
+#ifndef PPQHIP_QH_SELECT_WGS
+#define PPQHIP_QH_SELECT_WGS 0                      // grid of the select launch; 0: one workgroup per CU
+#endif
+#ifdef PPQHIP_QH_TIMING                             // developer builds: s_memrealtime stamps (10 ns) of the selecting workgroup -> ws[32 + i]
+#define QH_STAMP(i) do { if (threadIdx.x == 0) { a.ws[32 + (i)] = (uint32_t)wall_clock64(); a.ws[48 + (i)] = (uint32_t)__builtin_readcyclecounter(); } } while (0)
+#else
+#define QH_STAMP(i) do { } while (0)
+#endif
+constexpr int kQHBlock = 512;                       // both kernels
+constexpr uint32_t kQHStage = 2048;                 // keys a workgroup can stage per side (== its slot)
+constexpr uint32_t kQHInline = 6;                   // keys per side inside the record
+constexpr uint32_t kQHMaxWg = 512;                  // filter grid limit (records, slots)
+constexpr uint32_t kQHListMax = 16384;              // longest list a hint may keep producing
+constexpr uint32_t kQHWantedMax = 8192;             // the host routes here only when both wanted counts are at most this
+// workspace layout (uint32 words)
+enum { kQHEnabled = 0, kQHTHi = 1, kQHTLo = 2, kQHUses = 3,      // written by the filter's workgroup 0 (uses: hint word 7 as it found it)
+       kQHZero0 = 4,                                // first word the filter zeroes
+       kQHLoFlag = 4,                               // workgroup 1 -> workgroup 0 (split select): 0 pending, 1 settled, 2 open
+       kQHLoKey = 5, kQHLoKeep = 6,
+       kQHDecision = 7,                             // workgroup 0 -> everybody: 0 pending, 1 all settled, 0x10 | open mask
+       kQHNext = 12,                                // [3] next chunk of each exact level
+       kQHDone = 16 };                              // [3] chunks counted per exact level
+constexpr uint32_t kQHOffH0 = 64;                                   // hist of key >> 20 (both sides select from it)
+constexpr uint32_t kQHOffH1 = kQHOffH0 + kQ1;                       // [2][4096]: (key >> 8) & 0xFFF of the side's bucket
+constexpr uint32_t kQHOffH2 = kQHOffH1 + 2 * kQ2;                   // [2][256]: key & 0xFF of the side's 24-bit prefix
+constexpr uint32_t kQHZeroEnd = kQHOffH2 + 2 * kQ3;
+constexpr uint32_t kQHOffRec = kQHZeroEnd;                          // [kQHMaxWg][2][8]: per side count, tie count, the first six keys (one 64-B line per workgroup)
+constexpr uint32_t kQHOffHeads = kQHOffRec + kQHMaxWg * 16;         // [kQHMaxWg][2][32]: the first 32 keys of every slot, contiguous; read when a side holds more than six
+constexpr uint32_t kQHOffSlots = kQHOffHeads + kQHMaxWg * 2 * 32;   // [kQHMaxWg][2][kQHStage]: the whole slot, read when it holds more than 32 keys
+constexpr size_t kQHWords = (size_t)kQHOffSlots + (size_t)kQHMaxWg * 2 * kQHStage;
+static_assert(kQHOffRec % 4 == 0 && kQHOffHeads % 4 == 0 && kQHOffSlots % 4 == 0, "16-B alignment of records and slots");
+
+struct QHot {
+    const float* x;
+    float* dest;
+    uint32_t* hint;
+    uint32_t* ws;
+    uint32_t n, k_hi, k_lo, wgs;     // wgs: grid of the filter (records to gather)
+    uint32_t split, heads, pad0, pad1;   // split: two selecting workgroups, one per side; heads: the slots' first 32 keys are requested with the records
+};
+
+template <int K, bool PING, bool NT>
+__global__ __launch_bounds__(kQHBlock) void quantile_hot_filter_kernel(const QHot a) {
+    __shared__ uint32_t staged[2][kQHStage];
+    __shared__ uint32_t staged_n[2], ties[2];
+    const uint32_t G = gridDim.x, g = blockIdx.x, n = a.n;
+    const uint32_t full_rows = (n >> 2) / kQHBlock;                   // rows of kQHBlock float4
+    uint32_t r, r1;
+    even_split(full_rows, G, g, r, r1);
+    const float4* xv = reinterpret_cast<const float4*>(a.x) + threadIdx.x;
+    float4 bufa[K], bufb[K];
+    auto fetch = [&](float4 (&buf)[K], uint32_t row) {                 // clamped rows: straight-line loads (see hist_small_kernel)
+#pragma unroll
+        for (int k = 0; k < K; k++) buf[k] = gload4<NT>(xv + (size_t)umin(row + (uint32_t)k, r1 - 1u) * kQHBlock);
+    };
+    if (r < r1) fetch(bufa, r);                                        // in flight while the hint is read
+    // the hint: ONE scalar load of its eight words (a short-circuit && chain compiles to five dependent round trips)
+    const uint32_t* __restrict__ H = a.hint;
+    const uint32_t h0 = H[kHValidHi], t_hi = H[kHTHi], h2 = H[kHValidLo], t_lo = H[kHTLo], h4 = H[kHN], h5 = H[kHKHi], h6 = H[kHKLo], h7 = H[kHUses];
+    const bool enabled = ((h0 == 1u) & (h2 == 1u) & (h4 == n) & (h5 == a.k_hi) & (h6 == a.k_lo) & (t_lo <= t_hi)) != 0;   // the same in every workgroup
+    if (threadIdx.x < 2) { staged_n[threadIdx.x] = 0; ties[threadIdx.x] = 0; }
+    {   // the state of the launch behind this one: flags, barrier counter, exact histograms (zeroed whether needed or not)
+        constexpr uint32_t words = kQHZeroEnd - kQHZero0;
+        for (uint32_t i = g * kQHBlock + threadIdx.x; i < words; i += G * kQHBlock) a.ws[kQHZero0 + i] = 0u;
+        if (g == 0 && threadIdx.x == 0) *reinterpret_cast<uint4*>(a.ws) = make_uint4(enabled ? 1u : 0u, t_hi, t_lo, h7);
+    }
+    if (!enabled) return;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS counters are zero; the loads stay in flight
+    const uint32_t span = t_hi - t_lo;                                 // key - t_lo > span <=> outside [t_lo, t_hi]
+    int tie_hi = 0, tie_lo = 0;                                        // wave uniform
+    auto rare = [&](uint32_t key) {
+        const int w = key > t_hi ? 0 : 1;
+        const uint32_t at = atomicAdd(&staged_n[w], 1u);
+        if (at < kQHStage) staged[w][at] = key;
+    };
+    auto consume = [&](const float4 (&buf)[K], uint32_t cnt) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if ((uint32_t)k < cnt) {                                   // block uniform
+                const uint32_t q0 = f2key(buf[k].x), q1 = f2key(buf[k].y), q2 = f2key(buf[k].z), q3 = f2key(buf[k].w);
+                const uint32_t d0 = q0 - t_lo, d1 = q1 - t_lo, d2 = q2 - t_lo, d3 = q3 - t_lo;
+                if ((k & 1) == 0) {        // ties on the thresholds: a lower bound is all the select needs -> one element in eight
+                    tie_hi += popc_mask(__builtin_amdgcn_ballot_w64(q0 == t_hi));
+                    tie_lo += popc_mask(__builtin_amdgcn_ballot_w64(q0 == t_lo));
+                }
+                if (umax(umax(d0, d1), umax(d2, d3)) > span) {
+                    if (d0 > span) rare(q0);
+                    if (d1 > span) rare(q1);
+                    if (d2 > span) rare(q2);
+                    if (d3 > span) rare(q3);
+                }
+            }
+        }
+    };
+    if (r < r1) {
+        if (PING) {
+            for (;;) {
+                fetch(bufb, r + K);
+                consume(bufa, umin((uint32_t)K, r1 - r));
+                r += K;
+                if (r >= r1) break;
+                fetch(bufa, r + K);
+                consume(bufb, umin((uint32_t)K, r1 - r));
+                r += K;
+                if (r >= r1) break;
+            }
+        } else {
+            for (;;) {
+                consume(bufa, umin((uint32_t)K, r1 - r));
+                r += K;
+                if (r >= r1) break;
+                fetch(bufa, r);
+            }
+        }
+    }
+    if (g == G - 1) {                                                  // the ragged rest: < kQHBlock float4 + n % 4 elements
+        for (uint32_t i = full_rows * kQHBlock * 4u + threadIdx.x; i < n; i += kQHBlock) {
+            const uint32_t key = f2key(gload1(a.x + i));
+            if (key - t_lo > span) rare(key);
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (tie_hi) atomicAdd(&ties[0], (uint32_t)tie_hi);
+        if (tie_lo) atomicAdd(&ties[1], (uint32_t)tie_lo);
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {                                            // the record of both sides: one 64-B store
+        const uint32_t side = threadIdx.x >> 3, j = threadIdx.x & 7u, c = staged_n[side];
+        a.ws[kQHOffRec + g * 16u + threadIdx.x] = j == 0 ? c : (j == 1 ? ties[side] : ((j - 2u) < umin(c, kQHInline) ? staged[side][j - 2u] : 0u));
+    }
+    if (threadIdx.x < 64) {                                            // the heads of both slots: one 256-B store (read when a side holds more than the record does)
+        const uint32_t side = threadIdx.x >> 5, i = threadIdx.x & 31u, c = staged_n[side];
+        if ((c > kQHInline || a.heads) && i < c) a.ws[kQHOffHeads + g * 64u + threadIdx.x] = staged[side][i];
+    }
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+        const uint32_t c = umin(staged_n[side], kQHStage);
+        if (c > 32u) {
+            uint32_t* slot = a.ws + kQHOffSlots + ((size_t)g * 2 + side) * kQHStage;
+            for (uint32_t i = threadIdx.x; i < c; i += kQHBlock) slot[i] = staged[side][i];
+        }
+    }
+}
+
+constexpr uint32_t kQHBins = 2048;                  // the select's one histogram round: 11-bit digits ..
+constexpr int kQHDigitShift = 11;                   // .. of (key - T - 1) >> 11, saturating: bins of 2^-12 relative width over the half binade above T
+                                                    // (the answer is the wanted-th largest of ~1.5 x wanted keys: it lies in the dense third next to T)
+constexpr uint32_t kQHSurvCap = 2048;               // keys of the chosen bin ("survivors") a wavefront finishes on
+constexpr uint32_t kQHThreadKeys = 32;              // keys of a slot its own thread keeps in registers (8 16-B loads)
+constexpr uint32_t kQHBigCap = 8192;                // LDS room per side for the keys of slots longer than that
+constexpr uint32_t kQHWaveKeys = kQHSurvCap;
+struct QHSelLds {
+    uint32_t hist[2][kQHBins + 64];                 // + one trash counter per lane: the adds of a pass are unconditional
+    uint32_t surv[2][kQHSurvCap];
+    uint32_t big[2][kQHBigCap];
+    uint32_t bigdesc[2][kQHMaxWg][2];               // slots copied into `big`: (workgroup << 16 | count), offset
+    uint32_t wavehist[2][320];                      // wave_select: 256 counters + 64 trash counters per wave
+    uint32_t total[2], tie[2], nsurv[2], nbig[2], nbigdesc[2], flags;
+    uint32_t bin[2], rin[2], result[2];
+    uint32_t sc[2][8];
+};
+struct QHExactLds {
+    uint32_t h[2 * (kQ1 + kQTrash)];
+};
+
+// Wave64 inclusive scan / reductions on the DPP path (row_shr 1,2,4,8 inside each row of 16 lanes, then row_bcast 15 / 31 across
+// the rows): six VALU instructions.  The __shfl_up / __shfl_xor forms compile to ds_bpermute_b32 -- a ~120-cycle LDS-crossbar round
+// trip each, and a scan is six of them in a dependent chain.
+template <typename Op>
+__device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t v, const uint32_t identity, Op op) {
+#define PPQ_DPP(ctrl, rows) (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, ctrl, rows, 0xf, false)
+    v = op(v, PPQ_DPP(0x111, 0xf));        // row_shr:1
+    v = op(v, PPQ_DPP(0x112, 0xf));        // row_shr:2
+    v = op(v, PPQ_DPP(0x114, 0xf));        // row_shr:4
+    v = op(v, PPQ_DPP(0x118, 0xf));        // row_shr:8
+    v = op(v, PPQ_DPP(0x142, 0xa));        // row_bcast:15 into rows 1 and 3
+    v = op(v, PPQ_DPP(0x143, 0xc));        // row_bcast:31 into rows 2 and 3
+#undef PPQ_DPP
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) { return wave_scan_dpp(v, 0u, [](uint32_t a, uint32_t b) { return a + b; }); }
+__device__ __forceinline__ uint32_t wave_all_min(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_dpp(v, 0xFFFFFFFFu, [](uint32_t a, uint32_t b) { return a < b ? a : b; }), 63);
+}
+__device__ __forceinline__ uint32_t wave_all_max(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_dpp(v, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; }), 63);
+}
+__device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// The rank-th smallest (0-based) of keys[0..count) in LDS, 1 <= count <= kQHWaveKeys, by ONE wavefront and without a barrier.
+// Up to 64 keys: one key per lane, its rank counted against the other lanes' keys (v_readlane).  More: <= 32 keys per lane in
+// registers, radix select on (key - min) with 8-bit digits over a 256-counter LDS histogram private to the wave (`hist`: 320
+// words, 16-B aligned).  count / rank must be wave uniform (they are made scalar here: values picked by wave index arrive in
+// vector registers, and every test on them would become an EXEC-mask branch with its own LDS wait).
+__device__ __forceinline__ uint32_t wave_select(const uint32_t* keys, uint32_t count, uint32_t rank, uint32_t* hist) {
+    count = rfl(count); rank = rfl(rank);
+    const uint32_t lane = threadIdx.x & 63u;
+    if (count <= 64u) {
+        const uint32_t mine = keys[umin(lane, count - 1u)];
+        uint32_t below = 0u;
+        for (uint32_t i = 0; i < count; i++) {                          // scalar trip count
+            const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)i);
+            below += (o < mine || (o == mine && i < lane)) ? 1u : 0u;
+        }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(lane < count && below == rank);      // exactly one lane
+        return (uint32_t)__builtin_amdgcn_readlane((int)mine, m ? __builtin_ctzll(m) : 0);
+    }
+    constexpr int S = (int)(kQHWaveKeys / 64u);
+    const int slots = (int)((count + 63u) >> 6);        // wave uniform: registers in use
+    uint32_t d[S];
+    uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+    for (int j = 0; j < S; j++) d[j] = keys[umin((uint32_t)j * 64u + lane, count - 1u)];       // unconditional: one pipelined burst
+#pragma unroll
+    for (int j = 0; j < S; j++) { mn = umin(mn, d[j]); mx = umax(mx, d[j]); }                   // (clamped slots repeat the last key)
+    mn = wave_all_min(mn); mx = wave_all_max(mx);
+    if (mn == mx) return mn;
+    int pos = 32 - __builtin_clz(mx - mn);
+    uint32_t prefix = 0u;
+    uint4* hist4 = reinterpret_cast<uint4*>(hist);
+    const uint32_t trash = 256u + lane;                 // per-lane counter for "not this round": the adds stay unconditional
+    while (pos > 0) {                                   // wave uniform
+        const int w = pos > 8 ? 8 : pos, shift = pos - w;
+        hist4[lane] = make_uint4(0u, 0u, 0u, 0u);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < S; j++) {
+            if (j < slots) {
+                const uint32_t dj = d[j] - mn;
+                const bool in = (uint32_t)j * 64u + lane < count;
+                const uint32_t head = pos >= 32 ? 0u : dj >> pos;
+                const bool match = in && head == prefix;
+                atomicAdd(&hist[match ? ((dj >> shift) & ((1u << w) - 1u)) : trash], 1u);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint4 c = hist4[lane];
+        const uint32_t sum = c.x + c.y + c.z + c.w;
+        const uint32_t inc = wave_scan_add(sum);
+        const uint32_t excl = inc - sum;
+        const bool hit = rank >= excl && rank < inc;    // exactly one lane (rank < the number of matching keys)
+        uint32_t digit = lane * 4u, rin = rank - excl;
+        if (rin >= c.x) { rin -= c.x; digit++; if (rin >= c.y) { rin -= c.y; digit++; if (rin >= c.z) { rin -= c.z; digit++; } } }
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+        const int src = m ? __builtin_ctzll(m) : 0;
+        digit = (uint32_t)__builtin_amdgcn_readlane((int)digit, src);
+        rank = (uint32_t)__builtin_amdgcn_readlane((int)rin, src);
+        prefix = (prefix << w) | digit;
+        pos = shift;
+    }
+    return mn + prefix;
+}
+
+// Both sides of the filter's records -> settled?  (select A's rules.)  All 512 threads of ONE workgroup call; the results are
+// block uniform.  Thread t holds the keys of workgroup t's slots in registers (both sides: the record and the first 32 keys of each
+// slot are requested together, ONE round trip; longer slots go through LDS).  The lo side runs on ~key, so that both sides read
+// "the rank-th smallest of the keys ABOVE a threshold".  One histogram round on fixed bit positions of (key - T - 1) finds the
+// 2^13-key-wide bin of the answer; the keys of that bin are few and one wavefront per side finishes on them.
+__device__ __forceinline__ void hot_select_records(const QHot& a, const uint32_t (&T)[2], const uint32_t sides, QHSelLds& L, uint32_t (&key_out)[2], bool (&done)[2],
+                                                   bool (&keep)[2]) {
+    const uint32_t n = a.n, t = threadIdx.x, lane = t & 63u;
+    uint4 r4[4];                                                       // the 64-B record of workgroup t
+    uint4 k4[2][kQHThreadKeys / 4];
+    r4[0] = r4[1] = r4[2] = r4[3] = make_uint4(0u, 0u, 0u, 0u);
+    if (t < a.wgs) {
+        const uint4* rec = reinterpret_cast<const uint4*>(a.ws + kQHOffRec) + (size_t)t * 4;
+        r4[0] = rec[0]; r4[1] = rec[1]; r4[2] = rec[2]; r4[3] = rec[3];
+        if (a.heads) {                                                 // (the filter wrote every head in this mode)
+#pragma unroll
+            for (int w = 0; w < 2; w++) {
+                if (!(sides & (1u << w))) continue;
+                const uint4* head = reinterpret_cast<const uint4*>(a.ws + kQHOffHeads) + ((size_t)t * 2 + w) * (kQHThreadKeys / 4);
+#pragma unroll
+                for (uint32_t i = 0; i < kQHThreadKeys / 4; i++) k4[w][i] = head[i];
+            }
+        }
+    }
+    if (t < 2) { L.total[t] = 0u; L.tie[t] = 0u; L.nsurv[t] = 0u; L.nbig[t] = 0u; L.nbigdesc[t] = 0u; L.flags = 0u; }
+    {
+        uint4* z = reinterpret_cast<uint4*>(&L.hist[0][0]);           // (2 x 2112 words = 1056 uint4)
+        z[t] = make_uint4(0u, 0u, 0u, 0u); z[kQHBlock + t] = make_uint4(0u, 0u, 0u, 0u);
+        if (t < 2u * (kQHBins + 64u) / 4u - 2u * kQHBlock) z[2 * kQHBlock + t] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    uint32_t cnt[2] = {r4[0].x, r4[2].x}, tie[2] = {r4[0].y, r4[2].y};
+    uint32_t c[2] = {umin(cnt[0], kQHStage), umin(cnt[1], kQHStage)};
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        if (!(sides & (1u << w))) { c[w] = 0u; tie[w] = 0u; cnt[w] = 0u; continue; }                   // (block uniform: the other workgroup's side)
+        // six keys came with the record; a longer slot's first 32 were requested with it (big tensors: `heads`) or are fetched
+        // now (a second round trip, only for the threads that need it)
+        if (!a.heads) {
+            k4[w][0] = make_uint4(r4[2 * w].z, r4[2 * w].w, r4[2 * w + 1].x, r4[2 * w + 1].y);
+            k4[w][1] = make_uint4(r4[2 * w + 1].z, r4[2 * w + 1].w, 0u, 0u);
+            if (c[w] > kQHInline && c[w] <= kQHThreadKeys) {
+                const uint4* head = reinterpret_cast<const uint4*>(a.ws + kQHOffHeads) + ((size_t)t * 2 + w) * (kQHThreadKeys / 4);
+#pragma unroll
+                for (uint32_t i = 0; i < kQHThreadKeys / 4; i++) k4[w][i] = head[umin(i, (c[w] - 1u) >> 2)];
+            }
+        }
+    }
+    __syncthreads();
+    QH_STAMP(8);
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        // (one LDS atomic per wavefront: 512 adds on one address serialise at ~5 cycles each -- 4 us measured)
+        const uint32_t wc = wave_scan_add(c[w]), wt = wave_scan_add(tie[w]);
+        if (lane == 63u) { if (wc) atomicAdd(&L.total[w], wc); if (wt) atomicAdd(&L.tie[w], wt); }
+        if (cnt[w] > kQHStage) atomicOr(&L.flags, 1u << w);                              // the workgroup could not stage all its keys
+        if (c[w] > kQHThreadKeys) {
+            const uint32_t base = atomicAdd(&L.nbig[w], c[w]);
+            if (base + c[w] <= kQHBigCap) {
+                const uint32_t at = atomicAdd(&L.nbigdesc[w], 1u);
+                L.bigdesc[w][at][0] = (t << 16) | c[w]; L.bigdesc[w][at][1] = base;
+            } else atomicOr(&L.flags, 1u << w);
+        }
+    }
+    const uint32_t Tp[2] = {T[0], ~T[1]};
+    // every key this thread holds of side w: f(key', valid), key' = the key (hi) / ~key (lo); straight-line code up to the
+    // wave's longest slot (a scalar trip count)
+    auto for_my_keys = [&](int w, auto f) {
+        const uint32_t cw = c[w] <= kQHThreadKeys ? c[w] : 0u;
+        const uint32_t cmax = wave_all_max(cw);
+        const uint32_t flip = w ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+        for (uint32_t i = 0; i < kQHThreadKeys / 4; i++) {
+            if (4u * i < cmax) {
+                f(k4[w][i].x ^ flip, 4u * i + 0u < cw); f(k4[w][i].y ^ flip, 4u * i + 1u < cw);
+                f(k4[w][i].z ^ flip, 4u * i + 2u < cw); f(k4[w][i].w ^ flip, 4u * i + 3u < cw);
+            }
+        }
+    };
+    auto digit_of = [&](int w, uint32_t kp) { return umin((kp - Tp[w] - 1u) >> kQHDigitShift, kQHBins - 1u); };
+    const uint32_t trash = kQHBins + lane;
+    // the histogram round does not wait for the totals (whether a side selects at all is decided behind the next barrier)
+#pragma unroll
+    for (int w = 0; w < 2; w++)
+        if (sides & (1u << w)) for_my_keys(w, [&](uint32_t kp, bool valid) { atomicAdd(&L.hist[w][valid ? digit_of(w, kp) : trash], 1u); });
+    __syncthreads();
+    QH_STAMP(9);
+    uint32_t nbigkeys[2] = {0u, 0u};
+    if (L.nbigdesc[0] | L.nbigdesc[1]) {                               // block uniform: long slots, wavefront v copies the v-th, (v + 8)-th ..
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+            const uint32_t nb = L.nbigdesc[w];
+            for (uint32_t b = t >> 6; b < nb; b += kQHBlock / kWave) {
+                const uint32_t g = L.bigdesc[w][b][0] >> 16, cg = L.bigdesc[w][b][0] & 0xFFFFu;
+                const uint32_t* slot = a.ws + kQHOffSlots + ((size_t)g * 2 + w) * kQHStage;
+                uint32_t* dst = L.big[w] + L.bigdesc[w][b][1];
+                for (uint32_t i = lane; i < cg; i += 4u * kWave) {
+                    uint32_t k[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) k[u] = slot[umin(i + u * kWave, cg - 1u)];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) if (i + u * kWave < cg) dst[i + u * kWave] = k[u];
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+            nbigkeys[w] = umin(L.nbig[w], kQHBigCap);
+            for (uint32_t i = t; i < nbigkeys[w]; i += kQHBlock) atomicAdd(&L.hist[w][digit_of(w, L.big[w][i] ^ (w ? 0xFFFFFFFFu : 0u))], 1u);
+        }
+        __syncthreads();
+    }
+    const uint32_t flags = L.flags;
+    uint32_t total[2], rank[2], wanted[2];
+    int how[2];                                                        // 0: open, 1: the threshold itself, 2: select
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        const uint32_t k = w ? a.k_lo : a.k_hi;
+        total[w] = L.total[w];
+        wanted[w] = w ? k + 1u : n - k;
+        // hi: the (k - (n - total))-th smallest listed key; lo: the k-th smallest = the (total - 1 - k)-th smallest of the ~keys
+        rank[w] = w ? total[w] - 1u - k : k - (n - total[w]);
+        done[w] = false; keep[w] = false; key_out[w] = T[w]; how[w] = 0;
+        if ((flags & (1u << w)) || !(sides & (1u << w))) continue;
+        const uint32_t limit = umin(q_list_limit(wanted[w], quantile_spec_cap(n)), kQHListMax);
+        if (total[w] >= wanted[w]) {
+            how[w] = 2; done[w] = true;
+            keep[w] = total[w] - wanted[w] >= (wanted[w] >> 3) + 8u && total[w] <= limit;
+        } else if (wanted[w] - total[w] <= L.tie[w]) { how[w] = 1; done[w] = true; keep[w] = true; }     // the tie value itself
+    }
+    {   // the bin of the rank: half h of the workgroup scans side h (thread lt owns bins [8 lt, 8 lt + 8))
+        const uint32_t half = rfl(t >> 8), lt = t & 255u, wl = rfl(lt >> 6);
+        const uint4* h4 = reinterpret_cast<const uint4*>(&L.hist[half][0]);       // ((kQHBins + 64) * 4 B: 16-B aligned rows)
+        const uint4 c0 = h4[2u * lt], c1 = h4[2u * lt + 1u];
+        const uint32_t b[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        const uint32_t sum = b[0] + b[1] + b[2] + b[3] + b[4] + b[5] + b[6] + b[7];
+        const uint32_t inc = wave_scan_add(sum);
+        if (lane == 63u) L.sc[half][wl] = inc;
+        __syncthreads();
+    QH_STAMP(12);
+        uint32_t woff = 0u;
+#pragma unroll
+        for (uint32_t ww = 0; ww < 4; ww++) woff += ww < wl ? L.sc[half][ww] : 0u;
+        const uint32_t excl = woff + inc - sum, r = half ? rank[1] : rank[0];
+        if ((half ? how[1] : how[0]) == 2 && r >= excl && r < excl + sum) {             // one thread of the half
+            uint32_t rin = r - excl, digit = lt * 8u;
+#pragma unroll
+            for (int j = 0; j < 7; j++) if (digit == lt * 8u + (uint32_t)j && rin >= b[j]) { rin -= b[j]; digit++; }
+            L.bin[half] = digit; L.rin[half] = rin;
+        }
+    }
+    __syncthreads();
+    QH_STAMP(13);
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        if (how[w] != 2) continue;
+        const uint32_t bin = L.bin[w];
+        // key' lies in the bin <=> key' - (T' + 1 + (bin << shift)) < 2^shift (the saturating last bin: no upper end)
+        const uint32_t lo = Tp[w] + 1u + (bin << kQHDigitShift), width = bin == kQHBins - 1u ? 0xFFFFFFFFu - lo : (1u << kQHDigitShift) - 1u;
+        auto take = [&](uint32_t kp) { const uint32_t at = atomicAdd(&L.nsurv[w], 1u); if (at < kQHSurvCap) L.surv[w][at] = kp; };
+        {
+            const uint32_t cw = c[w] <= kQHThreadKeys ? c[w] : 0u;
+            const uint32_t cmax = wave_all_max(cw);
+            const uint32_t flip = w ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+            for (uint32_t i = 0; i < kQHThreadKeys / 4; i++) {
+                if (4u * i < cmax) {
+                    const uint32_t k0 = k4[w][i].x ^ flip, k1 = k4[w][i].y ^ flip, k2 = k4[w][i].z ^ flip, k3 = k4[w][i].w ^ flip;
+                    const bool m0 = k0 - lo <= width && 4u * i + 0u < cw, m1 = k1 - lo <= width && 4u * i + 1u < cw;
+                    const bool m2 = k2 - lo <= width && 4u * i + 2u < cw, m3 = k3 - lo <= width && 4u * i + 3u < cw;
+                    if (m0 | m1 | m2 | m3) {                               // rare: one divergent region per four keys
+                        if (m0) take(k0);
+                        if (m1) take(k1);
+                        if (m2) take(k2);
+                        if (m3) take(k3);
+                    }
+                }
+            }
+        }
+        for (uint32_t i = t; i < nbigkeys[w]; i += kQHBlock) { const uint32_t kp = L.big[w][i] ^ (w ? 0xFFFFFFFFu : 0u); if (kp - lo <= width) take(kp); }
+    }
+    __syncthreads();
+    QH_STAMP(14);
+    {   // wavefront 0 finishes the hi side, wavefront 4 (another SIMD) the lo side
+        const uint32_t wid = rfl(t >> 6), side = wid >> 2;
+        const uint32_t ns = side ? L.nsurv[1] : L.nsurv[0];
+        if ((wid & 3u) == 0u && (side ? how[1] : how[0]) == 2 && ns >= 1u && ns <= kQHSurvCap) {
+            const uint32_t kp = wave_select(L.surv[side], ns, side ? L.rin[1] : L.rin[0], L.wavehist[side]);
+            if (lane == 0u) L.result[side] = side ? ~kp : kp;
+        }
+    }
+    __syncthreads();
+    QH_STAMP(15);
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        if (how[w] != 2) continue;
+        const uint32_t ns = L.nsurv[w];
+        if (ns >= 1u && ns <= kQHSurvCap) key_out[w] = L.result[w];
+        else { done[w] = false; keep[w] = false; }                     // a bin too crowded for one wavefront (ties, saturation): exact passes
+    }
+}
+
+// One CHUNK of the tensor (kQHChunkRows rows of kQHBlock float4 = 64 KB; the last one also owns the n % 4 elements behind the
+// last float4): on_tile(sample, valid) once per four rows, on_elem(value, valid) for every slot -- trip counts are block uniform.
+constexpr uint32_t kQHChunkRows = 8, kQHChunkVec = kQHChunkRows * kQHBlock;
+template <typename FT, typename FE>
+__device__ __forceinline__ void hot_walk_chunk(const float* __restrict__ x, uint32_t n, uint32_t c, uint32_t chunks, FT on_tile, FE on_elem) {
+    const uint32_t nvec = n >> 2;
+    const float4* xv = reinterpret_cast<const float4*>(x);
+#pragma unroll
+    for (uint32_t half = 0; half < kQHChunkRows / 4; half++) {
+        const uint32_t v0 = c * kQHChunkVec + half * 4u * kQHBlock + threadIdx.x;
+        float4 b[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) b[u] = gload4<false>(xv + umin(v0 + u * kQHBlock, nvec - 1u));        // nvec >= 1: n >= 2^18
+        on_tile(b[0].x, v0 < nvec);
+#pragma unroll
+        for (uint32_t u = 0; u < 4; u++) {
+            const bool in = v0 + u * kQHBlock < nvec;
+            on_elem(b[u].x, in); on_elem(b[u].y, in); on_elem(b[u].z, in); on_elem(b[u].w, in);
+        }
+    }
+    if (c == chunks - 1u) {                                            // block uniform
+        const uint32_t i = (nvec << 2) + threadIdx.x;
+        const bool in = i < n;
+        const float v = in ? gload1(x + i) : 0.f;
+        on_tile(v, in);
+        on_elem(v, in);
+    }
+}
+
+// The exact passes do not depend on which workgroups are resident: they hand out their chunks through a counter, so a level is
+// complete when its chunks are -- whoever counted them.  (A grid barrier that waits for WORKGROUPS would hang as soon as two of
+// these launches, from two streams, share the chip.)
+__global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHot a) {
+    __shared__ union { QHSelLds s; QHExactLds e; } L;
+    __shared__ uint32_t scratch[32], sel[2], bcast[4];
+    const uint32_t n = a.n;
+    uint32_t* ws = a.ws;
+    // Workgroup 0 selects; the others wait for its decision.  (Workgroups of a grid are dispatched in index order, so workgroup 0
+    // is resident whenever any other one is; an arrival ticket instead -- measured: a returning device atomic ahead of the
+    // records, +0.8 us on every call -- would not need that, the exact passes below do not need it either.)
+#ifdef PPQHIP_QH_TIMING
+    const uint32_t stamp0 = (uint32_t)wall_clock64(), stamp0c = (uint32_t)__builtin_readcyclecounter();
+#endif
+    const uint4 hdr = *reinterpret_cast<const uint4*>(ws);
+    const uint32_t role = blockIdx.x == 0 ? 0u : ((a.split && blockIdx.x == 1) ? 1u : 0xFFFFFFFFu);
+    const bool enabled = hdr.x != 0u;
+    const uint32_t T[2] = {hdr.y, hdr.z};
+    uint32_t key_sel[2] = {T[0], T[1]};
+    bool done_sel[2] = {false, false}, keep_sel[2] = {false, false};
+    // ---- the decision: workgroup 0 publishes, everybody else polls ----
+    uint32_t open_mask;
+    if (role == 1u) {                                                  // (split select: the lo side, handed to workgroup 0)
+        if (enabled) hot_select_records(a, T, 2u, L.s, key_sel, done_sel, keep_sel);
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&ws[kQHLoKey], key_sel[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws[kQHLoKeep], keep_sel[1] ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&ws[kQHLoFlag], done_sel[1] ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (role == 0u) {
+#ifdef PPQHIP_QH_TIMING
+        if (threadIdx.x == 0) { a.ws[32] = stamp0; a.ws[48] = stamp0c; }
+#endif
+        QH_STAMP(1);
+        if (enabled) hot_select_records(a, T, a.split ? 1u : 3u, L.s, key_sel, done_sel, keep_sel);
+        QH_STAMP(6);
+        if (a.split) {
+            if (threadIdx.x == 0) {
+                uint32_t f;
+                while ((f = __hip_atomic_load(&ws[kQHLoFlag], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                bcast[0] = f;
+                bcast[1] = __hip_atomic_load(&ws[kQHLoKey], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bcast[2] = __hip_atomic_load(&ws[kQHLoKeep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            done_sel[1] = bcast[0] == 1u; key_sel[1] = bcast[1]; keep_sel[1] = bcast[2] != 0u;
+            __syncthreads();
+        }
+        open_mask = (done_sel[0] ? 0u : 1u) | (done_sel[1] ? 0u : 2u);
+        if (threadIdx.x == 0)
+            __hip_atomic_store(&ws[kQHDecision], open_mask ? (0x10u | open_mask) : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (threadIdx.x == 0) {
+            uint32_t d;
+            if (role != 1u) __builtin_amdgcn_s_sleep(PPQHIP_QH_POLL_FIRST);          // the decision is microseconds away
+            while ((d = __hip_atomic_load(&ws[kQHDecision], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(PPQHIP_QH_POLL_SLEEP);
+            bcast[3] = d;
+        }
+        __syncthreads();
+        open_mask = bcast[3] == 1u ? 0u : (bcast[3] & 3u);
+        if (open_mask == 0u) return;
+    }
+    // ---- not settled: exact radix select over the whole tensor (12 + 12 + 8 key bits) ----
+    // prefix / rank per side after each level; every workgroup arrives at the same numbers from the same global histograms
+    uint32_t top[2] = {0u, 0u}, r0k[2] = {0u, 0u}, p24[2] = {0u, 0u}, r24[2] = {0u, 0u}, low[2] = {0u, 0u};
+    if (open_mask != 0u) {
+        __syncthreads();
+        uint32_t* he = L.e.h;
+        const uint32_t kk[2] = {a.k_hi, a.k_lo};
+        const uint32_t chunks = ((n >> 2) + kQHChunkVec - 1u) / kQHChunkVec;
+        for (int level = 0; level < 3; level++) {
+            for (uint32_t i = threadIdx.x; i < 2u * (kQ1 + kQTrash); i += kQHBlock) he[i] = 0u;
+            __syncthreads();
+            uint32_t mine = 0;
+            const int shift = level == 1 ? 8 : 0, pshift = level == 1 ? 20 : 8;
+            const uint32_t dmask = level == 1 ? 0xFFFu : 0xFFu;
+            const int nb = level == 2 ? kQ3 : kQ1;
+            // a settled side matches nothing: no prefix has bit 31 set after the shift
+            const uint32_t p_hi = (open_mask & 1u) ? (level == 1 ? top[0] : p24[0]) : 0xFFFFFFFFu;
+            const uint32_t p_lo = (open_mask & 2u) ? (level == 1 ? top[1] : p24[1]) : 0xFFFFFFFFu;
+            WaveBinCounter<false, true, true> acc;
+            acc.init(reinterpret_cast<int*>(he), kQ1);
+            HotCounter hi_c, lo_c;
+            hi_c.init(he, nb);
+            lo_c.init(he + kQ1 + kQTrash, nb);
+            for (;;) {
+                if (threadIdx.x == 0) bcast[0] = __hip_atomic_fetch_add(&ws[kQHNext + level], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                const uint32_t c = bcast[0];
+                __syncthreads();
+                if (c >= chunks) break;
+                mine++;
+                if (level == 0) {
+                    hot_walk_chunk(a.x, n, c, chunks,
+                                   [&](float v, bool in) { acc.elect((int)(f2key(v) >> 20), in); },
+                                   [&](float v, bool in) { acc.template commit<false>((int)(f2key(v) >> 20), in); });
+                } else {
+                    hot_walk_chunk(a.x, n, c, chunks,
+                                   [&](float v, bool in) {
+                                       const uint32_t key = f2key(v);
+                                       hi_c.elect((int)((key >> shift) & dmask), in && (key >> pshift) == p_hi);
+                                       lo_c.elect((int)((key >> shift) & dmask), in && (key >> pshift) == p_lo);
+                                   },
+                                   [&](float v, bool in) {
+                                       const uint32_t key = f2key(v);
+                                       const int d = (int)((key >> shift) & dmask);
+                                       if (in && (key >> pshift) == p_hi) hi_c.add(d);
+                                       if (in && (key >> pshift) == p_lo) lo_c.add(d);
+                                   });
+                }
+            }
+            if (level == 0) acc.flush_hot(); else { hi_c.flush(); lo_c.flush(); }
+            __syncthreads();
+            if (mine) {                             // this workgroup's counts -> the global histograms of the level
+                for (int i = threadIdx.x; i < nb; i += kQHBlock) {
+                    const uint32_t c0 = he[i], c1 = he[kQ1 + kQTrash + i];
+                    if (level == 0) { if (c0) atomicAdd(&ws[kQHOffH0 + i], c0); }
+                    else {
+                        uint32_t* Hg = ws + (level == 1 ? kQHOffH1 : kQHOffH2);
+                        if (c0) atomicAdd(&Hg[i], c0);
+                        if (c1) atomicAdd(&Hg[nb + i], c1);
+                    }
+                }
+            }
+            // the level is complete when all its chunks are counted: publish mine, wait for the rest
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                if (mine) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add(&ws[kQHDone + level], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                while (__hip_atomic_load(&ws[kQHDone + level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunks) __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            for (int w = 0; w < 2; w++) {
+                if (!(open_mask & (1u << w))) continue;                 // block uniform
+                if (level == 0) {
+                    select_bin<kQHBlock>(ws + kQHOffH0, kQ1, kk[w], scratch, sel);
+                    top[w] = sel[0]; r0k[w] = sel[1];
+                } else if (level == 1) {
+                    select_bin<kQHBlock>(ws + kQHOffH1 + w * kQ2, kQ2, r0k[w], scratch, sel);
+                    p24[w] = (top[w] << 12) | sel[0]; r24[w] = sel[1];
+                } else {
+                    select_bin<kQHBlock>(ws + kQHOffH2 + w * kQ3, kQ3, r24[w], scratch, sel);
+                    low[w] = sel[0];
+                }
+                __syncthreads();
+            }
+        }
+    }
+    if (role != 0u) return;
+    // ---- role 0 writes the results and the hint (the only writer of either in this launch) ----
+    uint32_t out_key[2], out_valid[2], out_T[2];
+    for (int w = 0; w < 2; w++) {
+        if (!(open_mask & (1u << w))) { out_key[w] = key_sel[w]; out_valid[w] = keep_sel[w] ? 1u : 0u; out_T[w] = T[w]; continue; }
+        // the side went through the exact passes: leave a threshold that works (rules of F2's and F3's tails)
+        const uint32_t V = (p24[w] << 8) | low[w];
+        out_key[w] = V;
+        const uint32_t k = w ? a.k_lo : a.k_hi;
+        const uint32_t inb = ws[kQHOffH0 + top[w]];
+        const uint32_t outer = w ? k - r0k[w] : n - (k - r0k[w]) - inb;
+        const uint32_t wanted = w ? k + 1u : n - k;
+        const uint32_t target = wanted + (wanted >> 1) + 32u;
+        const uint32_t limit = umin(q_list_limit(wanted, quantile_spec_cap(n)), kQHListMax);
+        const uint32_t need_in = target > outer ? target - outer : 1u;
+        const uint32_t r = w ? umin(inb, need_in) - 1u : (inb > need_in ? inb - need_in : 0u);
+        select_bin<kQHBlock>(ws + kQHOffH1 + w * kQ2, kQ2, r, scratch, sel);
+        const uint32_t m = sel[0], q24 = (top[w] << 12) | m;
+        uint32_t listed, Tn;
+        bool ok;
+        if (w) { listed = outer + (r - sel[1]) + ws[kQHOffH1 + kQ2 + m]; ok = q24 < 0xFFFFFFu; Tn = (q24 + 1u) << 8; }
+        else { listed = outer + inb - (r - sel[1]); ok = q24 > 0u; Tn = (q24 << 8) - 1u; }
+        ok = ok && listed <= limit;
+        const uint32_t mult = ws[kQHOffH2 + w * kQ3 + low[w]];
+        if (mult / 16u >= wanted + 16u) { Tn = V; ok = true; }          // a heavy tie: the threshold ON the value (1 key in 8 is counted)
+        out_valid[w] = ok ? 1u : 0u; out_T[w] = Tn;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.dest[0] = key2f(out_key[0]); a.dest[1] = key2f(out_key[1]);
+        uint32_t* H = a.hint;
+        const uint32_t uses = hdr.w;
+        H[kHValidHi] = out_valid[0]; H[kHTHi] = out_T[0]; H[kHValidLo] = out_valid[1]; H[kHTLo] = out_T[1];
+        H[kHN] = n; H[kHKHi] = a.k_hi; H[kHKLo] = a.k_lo;
+        if (enabled && !(open_mask & 1u)) H[kHUses] = uses + 1u;
+    }
+    QH_STAMP(7);
+}
+
+#ifndef PPQHIP_Q_HOT
+#define PPQHIP_Q_HOT 1
+#endif
+#ifndef PPQHIP_QH_SMALL_ELEMS
+#define PPQHIP_QH_SMALL_ELEMS (4ll << 20)       // up to here every load of a workgroup's share is issued up front (<= 8 per lane)
+#endif
+#ifndef PPQHIP_QH_SPLIT_WANTED
+#define PPQHIP_QH_SPLIT_WANTED 2048
+#endif
+#ifndef PPQHIP_QH_NT_ELEMS
+#define PPQHIP_QH_NT_ELEMS (48ll << 20)
+#endif
+static bool quantile_hot_enabled() {
+#ifdef PPQHIP_DEV_KNOBS                     // measurement builds only: A/B against the general sequence
+    if (const char* e = getenv("PPQHIP_DEV_Q_HOT")) return atoi(e) != 0;
+#endif
+    return true;
+}
+static void quantile_hot_launch(const QHot& a0, hipStream_t s) {
+    QHot a = a0;
+    const uint32_t full_rows = (a.n >> 2) / kQHBlock;
+    uint32_t cap = (uint32_t)num_cu() * 2u;
+    if (cap > kQHMaxWg) cap = kQHMaxWg;
+    if ((int64_t)a.n <= PPQHIP_QH_SMALL_ELEMS) {
+        uint32_t g = (full_rows + 1) / 2;
+        if (g > cap) g = cap;
+        if (g < 1) g = 1;
+        const uint32_t share = (full_rows + g - 1) / g;
+        a.wgs = g;
+        if (share <= 2) hipLaunchKernelGGL((quantile_hot_filter_kernel<2, false, false>), dim3(g), dim3(kQHBlock), 0, s, a);
+        else if (share <= 4) hipLaunchKernelGGL((quantile_hot_filter_kernel<4, false, false>), dim3(g), dim3(kQHBlock), 0, s, a);
+        else hipLaunchKernelGGL((quantile_hot_filter_kernel<8, false, false>), dim3(g), dim3(kQHBlock), 0, s, a);
+    } else {
+        uint32_t g = full_rows / 4;
+        if (g > cap) g = cap;
+        if (g < 1) g = 1;
+        a.wgs = g;
+        // a filter workgroup is expected to list ~1.5 x wanted / g keys per side: more than the record holds -> the heads travel with
+        // the records; lists of thousands of keys -> the two sides are selected by two workgroups
+        const uint32_t wanted = a.n - a.k_hi > a.k_lo + 1u ? a.n - a.k_hi : a.k_lo + 1u;
+        a.heads = (wanted + wanted / 2u) / g >= 4u ? 1u : 0u;
+        a.split = (wanted >= PPQHIP_QH_SPLIT_WANTED && num_cu() >= 2) ? 1u : 0u;
+        if ((int64_t)a.n >= PPQHIP_QH_NT_ELEMS) hipLaunchKernelGGL((quantile_hot_filter_kernel<2, true, true>), dim3(g), dim3(kQHBlock), 0, s, a);
+        else hipLaunchKernelGGL((quantile_hot_filter_kernel<2, true, false>), dim3(g), dim3(kQHBlock), 0, s, a);
+    }
+    const uint32_t gs = PPQHIP_QH_SELECT_WGS > 0 ? (uint32_t)PPQHIP_QH_SELECT_WGS : (uint32_t)num_cu();
+    hipLaunchKernelGGL(quantile_hot_select_kernel, dim3(gs), dim3(kQHBlock), 0, s, a);
+}
+
 static int validate(int64_t n, const char* what) {
     if (n <= 0) { set_error("%s: tensor is empty", what); return PPQHIP_ERR_INVALID_VALUE; }
     if (n > 0x7fffffffLL) { set_error("%s: too many elements", what); return PPQHIP_ERR_INVALID_VALUE; }
     return PPQHIP_OK;
+}
+
+// index rule of _Quantile_T, sort.cu:13-19: __float2int_rn(num_of_elements * q), clipped to [0, n-1]
+static uint32_t quantile_pos(int64_t n, float f) {
+    float p = nearbyintf((float)n * f);
+    if (!(p > 0.f)) return 0u;                      // also NaN
+    if (p >= (float)(n - 1)) return (uint32_t)(n - 1);
+    return (uint32_t)p;
 }
 
 static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, float q, void* workspace, hipStream_t s,
@@ -1258,13 +2030,7 @@ static int quantile_multi_impl(const ppqhip_quantile_job* jobs, int num_jobs, fl
                 const ppqhip_quantile_job& src = jobs[seq_base + base + (int)k];
                 const int64_t n = src.n;
                 elems += n;
-                // index rule of _Quantile_T, sort.cu:13-19: __float2int_rn(num_of_elements * q), clipped to [0, n-1]
-                auto pos = [n](float f) -> uint32_t {
-                    float p = nearbyintf((float)n * f);
-                    if (!(p > 0.f)) return 0u;                      // also NaN
-                    if (p >= (float)(n - 1)) return (uint32_t)(n - 1);
-                    return (uint32_t)p;
-                };
+                auto pos = [n](float f) -> uint32_t { return quantile_pos(n, f); };
                 QUpload& e = a.e[k];
                 e.x = src.x; e.dest = src.dest; e.hint = src.hint; e.n = (uint32_t)n; e.k_hi = pos(q); e.k_lo = pos(1 - q); e.pad = 0;
                 const uint32_t w_hi = e.n - e.k_hi, w_lo = e.k_lo + 1u;
@@ -1317,7 +2083,9 @@ extern "C" {
 
 int64_t ppqhip_quantile_workspace_bytes(int64_t n) {
     // (also what ppqhip_isotone_t asks for: its 16 KB of partials fit the sequence prefix)
-    return (int64_t)kQPrefBytes + ((int64_t)kQWords + 2 * (int64_t)quantile_spec_cap((uint64_t)(n > 0 ? n : 0))) * 4;
+    const int64_t seq = (int64_t)kQPrefBytes + ((int64_t)kQWords + 2 * (int64_t)quantile_spec_cap((uint64_t)(n > 0 ? n : 0))) * 4;
+    const int64_t hot = (int64_t)kQHWords * 4;       // the two-launch path of one hinted tensor lays the same memory out its own way
+    return seq > hot ? seq : hot;
 }
 
 int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, uint32_t* hint, void* workspace, void* stream) {
@@ -1325,6 +2093,17 @@ int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, uint32_t*
     if (workspace == nullptr) { set_error("quantile_t: workspace is null"); return PPQHIP_ERR_INVALID_VALUE; }
     hipStream_t s = (hipStream_t)stream;
     LaunchScope scope(K_QUANTILE, 4.0 * (double)n, s);
+#if PPQHIP_Q_HOT
+    if (hint != nullptr && dest != nullptr && aligned16(x) && n >= kQSpeculateMinElems && quantile_hot_enabled()) {
+        QHot a;
+        a.x = x; a.dest = dest; a.hint = hint; a.ws = (uint32_t*)workspace; a.n = (uint32_t)n;
+        a.k_hi = quantile_pos(n, q); a.k_lo = quantile_pos(n, 1 - q); a.wgs = 0; a.split = 0; a.heads = 0; a.pad0 = a.pad1 = 0;
+        if (a.n - a.k_hi <= kQHWantedMax && a.k_lo + 1u <= kQHWantedMax) {
+            quantile_hot_launch(a, s);
+            return finish_launch("quantile_t");
+        }
+    }
+#endif
     ppqhip_quantile_job job;
     job.x = x; job.dest = dest; job.hint = hint; job.n = n;
     return quantile_multi_impl(&job, 1, q, workspace, s, "quantile_t");
