@@ -435,20 +435,23 @@ def seam_variants(dev, batches, steps, bins, method):
         from ppq_amd.calibration import RuntimeCalibrationPass as OurPass
         from oracle import reference_import as RI
         RI.load(stage)
-        ppq_amd.install_plugins_into_ppq(observers=False)
         import ppq.lib as PFL
         from ppq.quantization.optim import RuntimeCalibrationPass as RefPass
         n = max(8, steps)                                   # the reference asserts calib_steps >= 8 and cycles the loader
-        for stack in ('kernels', 'pass'):
+        for stack in ('kernels', 'fast', 'observers', 'pass'):
+            ppq_amd.uninstall_from_ppq()
+            if stack == 'fast': ppq_amd.install_into_ppq(fast_observers=True)
+            elif stack == 'observers': ppq_amd.install_plugins_into_ppq(observers=True)
+            else: ppq_amd.install_plugins_into_ppq(observers=False)
             times, checksum = [], None
             for rep in range(3):
                 rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(harness.resnet50_graph(seed=0)), dev, batches[0], bins=bins, method=method)
                 # small batches: 'auto' -- the pass times one eager step and captures the REFERENCE executor's loop into a HIP graph
                 # when that step is launch-bound (batch 1); at batch >= 16 the step is GPU-bound and stays eager, as in the headline
-                p = RefPass(method=method) if stack == 'kernels' else OurPass(method=method, check_steps=False,
-                                                                             use_hip_graph='auto' if batches[0].shape[0] < 16 else False)
+                p = RefPass(method=method) if stack != 'pass' else OurPass(method=method, check_steps=False,
+                                                                          use_hip_graph='auto' if batches[0].shape[0] < 16 else False)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
-                if stack == 'kernels': p.optimize(graph=rg, dataloader=batches, executor=rex, calib_steps=n, collate_fn=None)
+                if stack != 'pass': p.optimize(graph=rg, dataloader=batches, executor=rex, calib_steps=n, collate_fn=None)
                 else: PFL.Pipeline([p]).optimize(graph=rg, dataloader=batches, executor=rex, calib_steps=n, collate_fn=None, verbose=False)
                 torch.cuda.synchronize(); times.append(time.perf_counter() - t0)
                 checksum = float(sum(RI.activation_scales(rg).values()))
@@ -457,6 +460,8 @@ def seam_variants(dev, batches, steps, bins, method):
             best = min(times[1:])
             samples = n * batches[0].shape[0]
             out.append({'workload': {'kernels': "UNMODIFIED reference (its executor, RuntimeCalibrationPass and observers) with libppq_hip.so as its kernel extension: install_into_ppq()",
+                                     'fast': "the same with the reference's min/max collection wrapped (one ppqhip_minmax_t pass instead of value.min() + value.max()): install_into_ppq(fast_observers=True)",
+                                     'observers': "reference executor + the reference's OWN RuntimeCalibrationPass building ppq_amd's observers from its OBSERVER_TABLE: install_plugins_into_ppq(observers=True)",
                                      'pass': "reference executor + BaseGraph driving ppq_amd's RuntimeCalibrationPass + observers inside ppq.lib.Pipeline: install_plugins_into_ppq()"}[stack]
                                     + f'; ResNet-50 {method} {bins} bins, {n} x {batches[0].shape[0]}',
                         'seam': stack, 'samples': samples, 'value': round(samples / best, 2), 'unit': 'samples/s',
@@ -911,6 +916,8 @@ def main():
             'reuse_activations_samples_per_s': val(lambda v: 'reuse_activations' in str(v.get('workload', ''))),
             f'seam_kernels_b{args.batch}_samples_per_s': val(lambda v: v.get('seam') == 'kernels' and v.get('samples', 0) > 64),
             f'seam_pass_b{args.batch}_samples_per_s': val(lambda v: v.get('seam') == 'pass' and v.get('samples', 0) > 64),
+            f'seam_fast_b{args.batch}_samples_per_s': val(lambda v: v.get('seam') == 'fast' and v.get('samples', 0) > 64),
+            f'seam_observers_b{args.batch}_samples_per_s': val(lambda v: v.get('seam') == 'observers' and v.get('samples', 0) > 64),
             'seam_kernels_b1_samples_per_s': val(lambda v: v.get('seam') == 'kernels' and v.get('samples', 0) == 64),
             'seam_pass_b1_samples_per_s': val(lambda v: v.get('seam') == 'pass' and v.get('samples', 0) == 64),
             'cfg3_samples_per_s': val(lambda v: v.get('name') == 'resnet50_cfg3'),

@@ -967,10 +967,17 @@ class ENABLE_CUDA_KERNEL:
         PPQ_CONFIG.USING_CUDA_KERNEL = self._state
 
 
-def install_into_ppq() -> None:
+def install_into_ppq(fast_observers: bool = False) -> None:
     """Route an importable, unmodified PPQ through these kernels: the two lines a PPQ user adds.  ``CUDA_COMPLIER.complie()``
     -- which would JIT-build ppq/csrc with nvcc -- is shadowed on the singleton, so ``with ENABLE_CUDA_KERNEL():`` keeps
-    working in scripts written for the reference."""
+    working in scripts written for the reference.
+
+    ``fast_observers=True`` (opt-in, still no reference file touched): the reference's ``TorchMinMaxObserver.observe`` --
+    also phase 1 of its histogram / MSE observers -- reads every per-tensor activation TWICE with torch (``value.min()``,
+    ``value.max()``, observer/range.py:86-98) and appends two 1-element tensors per batch; wrapped, it accumulates both into one
+    float32[2] with ONE pass of ``ppqhip_minmax_t`` and hands the collectors views of that accumulator once.  The rendered
+    range is the same number (min / max are exact and order independent); the one difference: a NaN in an activation is
+    ignored instead of poisoning the range.  INTEGRATION.md section 3 has the measured effect."""
     from ppq.core import PPQ_CONFIG as REF_CONFIG
     from ppq.core.ffi import CUDA_COMPLIER as REF_COMPLIER
     REF_COMPLIER.__CUDA_EXTENTION__ = HIP_EXTENSION
@@ -992,6 +999,25 @@ def install_into_ppq() -> None:
             with quantile_hint_owner(self): return original(self, value)
         observe.__wrapped__ = original
         RefPercentile.observe = observe
+    if fast_observers and 'minmax_observe' not in _SAVED_KERNEL_STATE:
+        from ppq.core import QuantizationProperty as RefProperty, QuantizationStates as RefStates
+        from ppq.quantization.observer.range import TorchMinMaxObserver as RefMinMax
+        original_mm = RefMinMax.observe
+        _SAVED_KERNEL_STATE['minmax_observe'] = original_mm
+
+        def observe_minmax(self, value):
+            cfg = self._quant_cfg
+            if (isinstance(value, torch.Tensor) and value.is_cuda and value.dtype == torch.float32 and value.numel() > 0
+                    and cfg.state == RefStates.INITIAL and cfg.policy.has_property(RefProperty.PER_TENSOR)):
+                acc = getattr(self, '_ppq_amd_minmax', None)
+                if acc is None or acc.device != value.device or not self._min_val_collector:
+                    acc = self._ppq_amd_minmax = torch.tensor([float('inf'), float('-inf')], dtype=torch.float32, device=value.device)
+                    self._min_val_collector.append(acc[0:1]); self._max_val_collector.append(acc[1:2])    # views: later batches land in them
+                HIP_EXTENSION.MinMax_T(value, acc)
+                return
+            return original_mm(self, value)
+        observe_minmax.__wrapped__ = original_mm
+        RefMinMax.observe = observe_minmax
 
 
 _SAVED_PLUGIN_STATE: dict = {}       # what install_plugins_into_ppq(observers=True) replaced, for uninstall_from_ppq
@@ -1012,6 +1038,9 @@ def uninstall_from_ppq() -> None:
     if 'percentile_observe' in _SAVED_KERNEL_STATE:
         from ppq.quantization.observer.range import TorchPercentileObserver as RefPercentile
         RefPercentile.observe = _SAVED_KERNEL_STATE.pop('percentile_observe')
+    if 'minmax_observe' in _SAVED_KERNEL_STATE:
+        from ppq.quantization.observer.range import TorchMinMaxObserver as RefMinMax
+        RefMinMax.observe = _SAVED_KERNEL_STATE.pop('minmax_observe')
     if _SAVED_PLUGIN_STATE:
         import ppq.quantization.observer as ref_observer
         import ppq.quantization.optim.calibration as ref_calibration

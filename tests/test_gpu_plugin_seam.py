@@ -275,3 +275,43 @@ def test_finetuning_passes_plugged_into_the_reference_executor():
             a, b = oa.inputs[-1].value, ob.inputs[-1].value
             span = float(a.abs().max()) + 1e-6
             assert float((a - b).abs().max()) <= 2e-3 * span, (na, float((a - b).abs().max()), span)
+
+
+@pytest.mark.parametrize('method,symmetric', [('kl', True), ('mse', False), ('minmax', True), ('minmax', False)])
+def test_fast_observers_option_renders_the_same_scales(method, symmetric):
+    """install_into_ppq(fast_observers=True) wraps the reference's TorchMinMaxObserver.observe (observer/range.py:86-98; also
+    phase 1 of its histogram / MSE observers): ONE ppqhip_minmax_t pass into a float32[2] instead of value.min() + value.max().
+    The reference's own pass on the reference's own observers must render the very same scales and offsets, on recorded
+    activations (ReplayExecutor), and uninstall must put the reference's method back."""
+    import ppq_amd
+    from ppq_amd import harness
+    RI.load()
+    import ppq.quantization.observer.range as ref_range
+    from ppq.core import QuantizationPolicy, QuantizationProperty as QP
+    from ppq.quantization.optim import RuntimeCalibrationPass as RefPass
+    original = ref_range.TorchMinMaxObserver.observe
+    g = torch.Generator().manual_seed(29)
+    batches = [torch.rand(4, 3, 32, 32, generator=g).to(DEV) - 0.3 for _ in range(8)]
+
+    def asym(cfg, v):
+        if symmetric or v.is_parameter: return
+        cfg.policy = QuantizationPolicy(QP.ASYMMETRICAL + QP.LINEAR + QP.PER_TENSOR)
+        cfg.quant_min, cfg.quant_max = 0, 255
+    ppq_amd.install_into_ppq()
+    rg, rex = RI.quantize_reference_graph(RI.to_reference_graph(harness.small_cnn_graph(seed=0)), DEV, batches[0], bins=2048, method=method, mutate=asym)
+    replay = RI.ReplayExecutor(rex)
+    RefPass(method=method).optimize(graph=rg, dataloader=batches, executor=replay, calib_steps=8, collate_fn=None)
+    want = _scales(rg)
+    assert len(want) >= 4
+    try:
+        ppq_amd.install_into_ppq(fast_observers=True)
+        assert ref_range.TorchMinMaxObserver.observe is not original
+        replay.reset_activation_configs()
+        RefPass(method=method).optimize(graph=rg, dataloader=batches, executor=replay, calib_steps=8, collate_fn=None)
+        got = _scales(rg)
+        assert got.keys() == want.keys()
+        for k in want:                                                       # the same numbers, not close ones
+            assert torch.equal(got[k][0], want[k][0]) and torch.equal(got[k][1], want[k][1]), (k, got[k], want[k])
+    finally:
+        ppq_amd.uninstall_from_ppq()
+    assert ref_range.TorchMinMaxObserver.observe is original
