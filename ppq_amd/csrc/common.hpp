@@ -53,6 +53,8 @@ struct LaunchScope {
 
 int finish_launch(const char* what);   // hipGetLastError -> status
 void* scratch(hipStream_t stream, size_t bytes);   // device scratch private to (device, stream)
+constexpr size_t kZeroedArenaBytes = 32 * 16384 * sizeof(int);      // 32 partial rows of the largest LDS histogram (2 MB)
+void* zeroed_arena(hipStream_t stream, size_t bytes);   // private to (device, stream), all zero between launches (users re-zero what they dirty); may return nullptr
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -336,9 +336,12 @@ void hist_persistent_kernel(const HistJobs jobs) {
 // operations on a line, ~15 ns each -- tools/floor_table.py, `floor_atomic`) or into the workgroup's OWN row of a persistent
 // accumulator (no contention at all, so the grid can cover every CU; atomics instead of a load-add-store keep the row's
 // read latency out of the chain).
-template <bool ASYM, bool CLIP, int kSmallK>       // kSmallK: loads in flight per lane = rows of a share fetched at once (2 | 4 | 8)
+// PING (mid-size tensors, tens of MB: a share of many rows): two register tiles of kSmallK rows ping-pong, as in the persistent kernel, but
+// still one tensor with its arguments by value, own-row / shared atomics at the end and no job table -- the persistent kernel's
+// generality costs ~2-3 us per launch there (Bx8: 13.7 us against a 10.8 us read; profiles/r06_frac_vs_size_first.txt).
+template <bool ASYM, bool CLIP, int kSmallK, bool PING = false, bool NT = false>       // kSmallK: loads in flight per lane and tile (2 | 4 | 8)
 __global__ __launch_bounds__(kHistBlock) void hist_small_kernel(const float* __restrict__ x, uint32_t n, float a, float hs, int bins,
-                                                                 int copies, int* __restrict__ dst, int own_row) {
+                                                                 int copies, int* __restrict__ dst, uint32_t row_mod) {
     extern __shared__ int lds[];
     const uint32_t G = gridDim.x, g = blockIdx.x;
     const uint32_t nvec = n >> 2;
@@ -356,14 +359,13 @@ __global__ __launch_bounds__(kHistBlock) void hist_small_kernel(const float* __r
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS only: the loads stay in flight
         zeroed = true;
     };
-    for (uint32_t r = r0; r < r1; r += kSmallK) {
-        float4 buf[kSmallK];
-        const uint32_t cnt = min((uint32_t)kSmallK, r1 - r);          // workgroup uniform
-        // straight-line loads with a clamped row index (the last row of the share is fetched again instead of branching): a
-        // load under `if (k < cnt)` lands in its own basic block and the compiler waits for ALL earlier loads in front of it
+    // straight-line loads with a clamped row index (the last row of the share is fetched again instead of branching): a
+    // load under `if (k < cnt)` lands in its own basic block and the compiler waits for ALL earlier loads in front of it
+    auto fetch = [&](float4 (&buf)[kSmallK], uint32_t r) {
 #pragma unroll
-        for (int k = 0; k < kSmallK; k++) buf[k] = xv[(size_t)min(r + (uint32_t)k, r1 - 1) * kHistBlock];
-        zero_lds();
+        for (int k = 0; k < kSmallK; k++) buf[k] = load4<NT>(xv + (size_t)min(r + (uint32_t)k, r1 - 1) * kHistBlock);
+    };
+    auto consume = [&](const float4 (&buf)[kSmallK], uint32_t cnt) {      // cnt: workgroup uniform
 #pragma unroll
         for (int k = 0; k < kSmallK; k++) {
             if ((uint32_t)k < cnt) {
@@ -376,6 +378,31 @@ __global__ __launch_bounds__(kHistBlock) void hist_small_kernel(const float* __r
                     acc.template commit<true>(b[2], true); acc.template commit<true>(b[3], true);
                 }
             }
+        }
+    };
+    if (PING) {
+        if (r0 < r1) {
+            float4 bufa[kSmallK], bufb[kSmallK];
+            uint32_t r = r0;
+            fetch(bufa, r);
+            zero_lds();
+            for (;;) {
+                fetch(bufb, r + kSmallK);
+                consume(bufa, min((uint32_t)kSmallK, r1 - r));
+                r += kSmallK;
+                if (r >= r1) break;
+                fetch(bufa, r + kSmallK);
+                consume(bufb, min((uint32_t)kSmallK, r1 - r));
+                r += kSmallK;
+                if (r >= r1) break;
+            }
+        }
+    } else {
+        for (uint32_t r = r0; r < r1; r += kSmallK) {
+            float4 buf[kSmallK];
+            fetch(buf, r);
+            zero_lds();
+            consume(buf, min((uint32_t)kSmallK, r1 - r));
         }
     }
     zero_lds();
@@ -392,7 +419,7 @@ __global__ __launch_bounds__(kHistBlock) void hist_small_kernel(const float* __r
         }
     }
     acc.flush_hot();
-    int* row = own_row ? dst + (size_t)g * bins : dst;
+    int* row = dst + (size_t)(row_mod ? g % row_mod : 0u) * bins;     // row_mod: 0 one shared histogram, G own rows, R partial rows
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     for (int b = threadIdx.x; b < bins; b += kHistBlock) {
@@ -684,8 +711,86 @@ static int dev_knob(const char* name, int fallback) {
     return fallback;
 }
 
+#ifndef PPQHIP_HIST_STREAM_K
+#define PPQHIP_HIST_STREAM_K 2                  // rows per register tile of the ping-pong form
+#endif
+#ifndef PPQHIP_HIST_STREAM_ELEMS
+#define PPQHIP_HIST_STREAM_ELEMS (0x7fffffffll) // single tensors up to here take the ping-pong form of hist_small_kernel when they have own rows
+#endif
+// mid-size and large single tensors with own rows: hist_small_kernel<.., PING>
+// partial rows of the one-shot form: the grid adds with device atomics into row g % R of the zero-kept arena (R rows instead of
+// one: 512 workgroups on ONE row serialise on its 128 lines -- floor_atomic 6.5 us against 3.4 us for 8 rows, profiles/r05_floor_table_head.txt),
+// this kernel adds the R rows into the caller's histogram and hands the arena back zeroed.  One thread per bin.
+__global__ __launch_bounds__(kBlock) void hist_partial_reduce_kernel(int* __restrict__ partial, int R, int bins, int* __restrict__ hist) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= bins) return;
+    int v[32];
+    const int hv = hist[b];                                                // (in flight with the rows: one round trip)
+#pragma unroll
+    for (int r = 0; r < 32; r++) v[r] = r < R ? partial[(size_t)r * bins + b] : 0;
+    int t = 0;
+#pragma unroll
+    for (int r = 0; r < 32; r++) { t += v[r]; if (r < R && v[r] != 0) partial[(size_t)r * bins + b] = 0; }
+    if (t) hist[b] = hv + t;
+}
+#ifndef PPQHIP_HIST_ONESHOT_ROWS
+#define PPQHIP_HIST_ONESHOT_ROWS 8
+#endif
+
+static bool launch_hist_stream(const float* x, int64_t n, BinRule rule, hipStream_t s, int32_t* rows, int32_t* hist = nullptr) {
+    const int kk = dev_knob("PPQHIP_DEV_HIST_STREAM", PPQHIP_HIST_STREAM_K);
+    int R = 0;
+    bool direct = false;
+    if (rows == nullptr) {                                                // one-shot: partial rows in the zero-kept arena
+        R = dev_knob("PPQHIP_DEV_HIST_ONESHOT", PPQHIP_HIST_ONESHOT_ROWS);
+        if (R == 0 || hist == nullptr) return false;
+        if (R > 32) R = 32;
+        // (measured and not kept: every workgroup adding into the caller's histogram -- 512 adds per line are +3.7 us behind a 34 us
+        // stream, a wash against the 4.7 us a dependent reduce launch costs whatever it reads, and +6.7 us on Bx4 / Bx8;
+        // profiles/r06_hist_variants.txt.  PPQHIP_DEV_HIST_ONESHOT=-1 in a developer build still selects it.)
+        if (R < 0) { direct = true; rows = hist; }
+        else {
+            rows = (int32_t*)zeroed_arena(s, sizeof(int) * (size_t)R * rule.bins);
+            if (rows == nullptr) return false;                            // (first use inside a graph capture: the reduce-launch form)
+        }
+    }
+    if (kk <= 0 || n > PPQHIP_HIST_STREAM_ELEMS || !aligned16(x)) return false;
+    const uint32_t full_rows = (uint32_t)((n >> 2) / kHistBlock);
+    uint32_t g = full_rows / (2u * (uint32_t)kk);                         // at least two tiles per workgroup
+    const uint32_t cap = (uint32_t)(num_cu() * kHistWgPerCu);
+    if (g > cap) g = cap;
+    g = (uint32_t)dev_knob("PPQHIP_DEV_HIST_WG", (int)g);
+    if (g > (uint32_t)kHistRows) g = kHistRows;
+    if (g < 1) g = 1;
+    const int copies = pick_copies(rule.bins, kHistBlock);
+    const bool nt = n >= PPQHIP_HIST_NT_ELEMS;
+    const uint32_t row_mod = direct ? 0u : (R ? (uint32_t)R : (uint32_t)kHistRows);
+#define PPQ_LAUNCH_HIST_STREAM_K(A, C, K)                                                                             \
+    do {                                                                                                              \
+        if (nt) hipLaunchKernelGGL((hist_small_kernel<A, C, K, true, true>), dim3(g), dim3(kHistBlock), lds_bytes(rule.bins, copies), s, x, \
+                                   (uint32_t)n, rule.a, rule.hs, rule.bins, copies, rows, row_mod);                  \
+        else hipLaunchKernelGGL((hist_small_kernel<A, C, K, true, false>), dim3(g), dim3(kHistBlock), lds_bytes(rule.bins, copies), s, x, \
+                                (uint32_t)n, rule.a, rule.hs, rule.bins, copies, rows, row_mod);                     \
+    } while (0)
+#define PPQ_LAUNCH_HIST_STREAM(A, C)                                                                                  \
+    do {                                                                                                              \
+        if (kk >= 4) PPQ_LAUNCH_HIST_STREAM_K(A, C, 4);                                                               \
+        else PPQ_LAUNCH_HIST_STREAM_K(A, C, 2);                                                                       \
+    } while (0)
+    switch ((rule.asym ? 2 : 0) | (rule.clip ? 1 : 0)) {
+        case 0: PPQ_LAUNCH_HIST_STREAM(false, false); break;
+        case 1: PPQ_LAUNCH_HIST_STREAM(false, true); break;
+        case 2: PPQ_LAUNCH_HIST_STREAM(true, false); break;
+        default: PPQ_LAUNCH_HIST_STREAM(true, true); break;
+    }
+#undef PPQ_LAUNCH_HIST_STREAM
+#undef PPQ_LAUNCH_HIST_STREAM_K
+    if (R > 0) hipLaunchKernelGGL(hist_partial_reduce_kernel, dim3((rule.bins + kBlock - 1) / kBlock), dim3(kBlock), 0, s, (int*)rows, R, rule.bins, (int*)hist);
+    return true;
+}
+
 static bool launch_hist_small(const float* x, int64_t n, BinRule rule, int32_t* hist, hipStream_t s, int32_t* rows) {
-    if (!dev_knob("PPQHIP_DEV_HIST_SMALL", 1) || n > PPQHIP_HIST_SMALL_ELEMS || !aligned16(x)) return false;
+    if (!dev_knob("PPQHIP_DEV_HIST_SMALL", 1) || n > dev_knob("PPQHIP_DEV_HIST_SMALL_ELEMS", (int)PPQHIP_HIST_SMALL_ELEMS) || !aligned16(x)) return false;
     const uint32_t full_rows = (uint32_t)((n >> 2) / kHistBlock);
     uint32_t g;
     if (rows) g = (full_rows + 1) / 2;                                   // own rows: no contention, two loads per lane
@@ -697,7 +802,7 @@ static bool launch_hist_small(const float* x, int64_t n, BinRule rule, int32_t* 
     if (g < 1) g = 1;
     const int copies = pick_copies(rule.bins, kHistBlock);
     int* dst = rows ? rows : hist;
-    const int own = rows ? 1 : 0;
+    const uint32_t own = rows ? (uint32_t)kHistRows : 0u;             // (g < kHistRows: g % kHistRows == g)
     const uint32_t share = (full_rows + g - 1) / g;                         // rows of the largest share: all of them in flight when <= 8
 #define PPQ_LAUNCH_HIST_SMALL_K(A, C, K)                                                                              \
     hipLaunchKernelGGL((hist_small_kernel<A, C, K>), dim3(g), dim3(kHistBlock), lds_bytes(rule.bins, copies), s, x,  \
@@ -722,6 +827,7 @@ static bool launch_hist_small(const float* x, int64_t n, BinRule rule, int32_t* 
 static int launch_hist_one(const float* x, int64_t n, BinRule rule, int32_t* hist, void* workspace, hipStream_t s,
                            int32_t* rows) {
     if (launch_hist_small(x, n, rule, hist, s, rows)) return PPQHIP_OK;
+    if (launch_hist_stream(x, n, rule, s, rows, hist)) return PPQHIP_OK;
     HistJobs args;
     args.count = 1; args.bins = rule.bins; args.copies = pick_copies(rule.bins, kHistBlock);
     HistJob& d = args.job[0];

@@ -79,6 +79,27 @@ void* scratch(hipStream_t stream, size_t bytes) {
     return slot.first;
 }
 
+// A second arena per (device, stream) whose contract is that it is ALL ZERO between launches: kernels that accumulate into it
+// with atomics hand it back zeroed (the one-shot histogram's partial rows: hist_partial_reduce_kernel re-zeroes what it read).
+// Zeroed once when allocated; fixed size (the largest user's need), so it never moves under a captured graph.
+static std::map<std::pair<int, hipStream_t>, void*> g_zeroed;
+void* zeroed_arena(hipStream_t stream, size_t bytes) {
+    if (bytes > kZeroedArenaBytes) { set_error("zeroed_arena: %zu bytes asked of a %zu-byte arena", bytes, (size_t)kZeroedArenaBytes); return nullptr; }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    void*& p = g_zeroed[{dev, stream}];
+    if (p == nullptr) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (stream != nullptr && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return nullptr;   // (callers fall back)
+        void* q = nullptr;
+        if (hipMalloc(&q, kZeroedArenaBytes) != hipSuccess) { set_error("zeroed_arena: hipMalloc failed"); return nullptr; }
+        if (hipMemset(q, 0, kZeroedArenaBytes) != hipSuccess) { (void)hipFree(q); set_error("zeroed_arena: hipMemset failed"); return nullptr; }
+        p = q;
+    }
+    return p;
+}
+
 // ---- profiling aid ------------------------------------------------------------------------
 struct ProfRecord {
     int id;
