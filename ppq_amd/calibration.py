@@ -155,7 +155,7 @@ class RuntimeCalibrationPass(QuantizationOptimizationPass):
         (ResNet-50, 256 samples): batch 1 x 256 steps 127 -> 326 samples/s, batch 8 x 32 steps
         973 -> 1385, batch 32 x 8 steps: the eager loop is already GPU-bound and capture costs more
         than it saves.  ``use_hip_graph='auto'`` therefore times one eager step and captures only
-        when the loop is launch-bound."""
+        when the loop is launch-bound (profiles/HISTORY.md section 6)."""
         import torch
         batches = self._batches(dataloader)
         if self._replay and not self._recording:
