@@ -15,7 +15,7 @@ value = N*K*batch / time.  Strong scaling (`--total-samples S`, e.g. BASELINE co
 fixed, K = S / (N * batch) is derived, `scaling` is "strong"; each rank of a multi-GPU run keeps its own MIOpen user database /
 kernel cache so that N find-mode warm-ups do not serialise on one sqlite file.
 
-The timed pass is repeated `--repeats` times (default 3, each on a freshly built graph, each timing
+The timed pass is repeated `--repeats` times (default 5, each on a freshly built graph, each timing
 exactly K steps); `value` is the MEDIAN pass and `values` / `spread_pct` report all of them.
 
 Rank 0 prints ONE JSON line; `roofline` describes the dominant ppq_amd kernel of the timed workload
@@ -493,7 +493,7 @@ def inprocess_variants(dev, args):
             graph, ex = fresh()
             run_pass(graph, ex, bs, steps, method, False, False, True)     # a full-length warm pass: the allocator sees this variant's buffer sizes
             times = []
-            for _ in range(3):
+            for _ in range(5):          # (five: on shared hosts one pass in three or four runs 1.5-2x slow -- r06 run 2: 2904, 1657, 1660 samples/s)
                 del graph, ex
                 graph, ex = fresh()
                 torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -506,7 +506,7 @@ def inprocess_variants(dev, args):
             torch.cuda.synchronize(); _lib.lib.ppqhip_prof_enable(0)
             roof = roofline_entry(collect_prof(), prefer=prefer) or {}
             del graph, ex, bs
-            med = sorted(times)[1]
+            med = sorted(times)[len(times) // 2]
             n = steps * args.batch
             out.append({'workload': f'ResNet-50 topology, RuntimeCalibrationPass {method} {bins} bins, {steps} batches x {args.batch} (in process)',
                         'name': name, 'value': round(n / med, 2), 'unit': 'samples/s', 'ms_per_step': round(med / steps * 1e3, 3), 'steps': steps,
@@ -534,7 +534,10 @@ def workload_variants(args):
         # (config 5 stays in immediate mode: the search over 56 convolutions x forward / data-gradient / weight-gradient costs the
         #  child 160 s -- 183 s against 22 s of wall time -- and buys 6 % per replayed step: 0.330 vs 0.349 ms)
         find = '0' if name == 'yolov6s_int4_lsq' else '1'
-        cmd = [sys.executable, os.path.abspath(__file__), '--warmup', '1', '--repeats', '3', '--variants', '0', '--pmc', '0',
+        # config 5's timed pass is 0.24 s of host-driven work (27 captures, 27 eager first steps, 189 replays): three passes spread 10-20 %
+        # by max - min (BENCH_r05: 21.9 %); seven passes, value = their median, spread = (p90 - p10) / median, all seven in `values`
+        reps = '7' if name == 'yolov6s_int4_lsq' else '3'
+        cmd = [sys.executable, os.path.abspath(__file__), '--warmup', '1', '--repeats', reps, '--variants', '0', '--pmc', '0',
                '--no-cpu-baseline', '--no-cpu-ops', '--settle-ms', '100', '--miopen-find', find] + extra
         try:
             t0 = time.perf_counter()
@@ -546,6 +549,7 @@ def workload_variants(args):
             roof = j.get('roofline') or {}
             out.append({'workload': j['config']['workload'], 'name': name, 'metric': j['metric'], 'value': j['value'], 'unit': j['unit'],
                         'ms_per_step': j['ms_per_step'], 'steps': j['steps'], 'values': j.get('values'), 'spread_pct': j.get('spread_pct'),
+                        'range_pct': j.get('range_pct'),
                         'child_wall_s': round(time.perf_counter() - t0, 1),
                         'roofline': {k: roof.get(k) for k in ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'launches', 'avg_launch_us',
                                                               'algorithmic_bytes_per_launch')}})
@@ -666,7 +670,9 @@ def main_lsq(args, rank, world, dev):
             'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(elapsed / total_steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32 (INT4 / INT8 simulated)', 'data': 'synthetic',
             'repeats': len(times), 'values': [round(samples / t, 2) for t in times],
-            'spread_pct': round(100.0 * (max(times) - min(times)) / elapsed, 2),
+            # >= 7 passes: the spread is the inter-decile range (the second smallest / second largest of seven), the full range is kept too
+            'spread_pct': round(100.0 * ((sorted(times)[-2] - sorted(times)[1]) if len(times) >= 7 else (max(times) - min(times))) / elapsed, 2),
+            'range_pct': round(100.0 * (max(times) - min(times)) / elapsed, 2),
             'config': {'workload': f'{WORKLOADS[WORKLOAD][0]}; {blocks} blocks x {args.steps} Adam steps x batch {args.batch} x 3x{size}x{size} per GPU '
                                    f'(timed: the whole pass incl. its target / input collection)', 'samples': samples, 'batch': args.batch,
                        'blocks': blocks, 'optimizer_steps': total_steps, 'kept_blocks': sum(1 for _, a, b in p.report if b <= a),
@@ -700,7 +706,7 @@ def main():
     ap.add_argument('--method', type=str, default='kl')
     ap.add_argument('--workload', type=str, default='resnet50', choices=sorted(WORKLOADS),
                     help='resnet50 = BASELINE config 2 (the metric); resnet50_cfg3 / vit_b16_fp8 = configs 3 / 4 at size')
-    ap.add_argument('--repeats', type=int, default=3, help='timed passes (each exactly K steps); value = median')
+    ap.add_argument('--repeats', type=int, default=5, help='timed passes (each exactly K steps); value = median')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-cpu-ops', action='store_true')
     ap.add_argument('--variants', type=int, default=1, help="also time SURVEY 8(d)'s own protocol (batch 1 x 256 steps) once and report it in config.variants")
@@ -934,6 +940,7 @@ def main():
                 key = {'resnet50_cfg3': 'cfg3', 'vit_b16_fp8': 'cfg4', 'yolov6s_int4_lsq': 'cfg5'}[v['name']]
                 scalars[f'{key}_roofline_frac'] = v['roofline'].get('frac')
                 scalars[f'{key}_spread_pct'] = v.get('spread_pct')
+                if v.get('range_pct') is not None: scalars[f'{key}_range_pct'] = v.get('range_pct')
         scalars.update(north_star_b(args.bins))   # B_* keys: rocprofv3 medians + graph-replay bound + floors + B_status
     if rank == 0:
         samples = world * args.steps * args.batch
