@@ -267,6 +267,10 @@ int ppqhip_quantile_t_multi(const ppqhip_quantile_job* jobs, int num_jobs, float
  * out[0] bytes before job 0's state, [1] words per job, [2] side records, [3] filter record, [4] tickets,
  * [5] byte offset of the job table, [6] / [7] word offsets of the list / tie counters in the filter record. */
 void ppqhip_quantile_debug_layout(int64_t* out);
+/* the same for the two-launch path of one hinted tensor (quantile.hip "ONE hinted tensor"), in uint32 words: out[0] words of the
+ * whole layout, [1] first record, [2] first head, [3] first slot, [4] filter workgroups at most, [5] keys per slot, [6] first word
+ * the filter does NOT zero (the header, flags and exact histograms lie below it), [7] keys per head. */
+void ppqhip_quantile_hot_layout(int64_t* out);
 
 /* replaces Isotone_T, sort.cu:61-73: dest = [max, 2nd max, min, 2nd min] (with multiplicity).
  * `workspace`: device scratch of ppqhip_quantile_workspace_bytes(n) bytes (shared sizing). */

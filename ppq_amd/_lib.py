@@ -71,6 +71,7 @@ PROTOTYPES = {
     'ppqhip_quantile_multi_workspace_bytes': (c_i64, [c_int, c_i64]),
     'ppqhip_quantile_t_multi': (c_int, [c_vp, c_int, c_flt, c_vp, c_vp]),
     'ppqhip_quantile_debug_layout': (None, [c_vp]),
+    'ppqhip_quantile_hot_layout': (None, [c_vp]),
     'ppqhip_minmax_t_slots_multi': (c_int, [c_vp, c_int, c_vp]),
     'ppqhip_hist_t_rows_multi': (c_int, [c_vp, c_int, c_int, c_int, c_i64, c_vp]),
     'ppqhip_channel_sum': (c_int, [c_f32p, c_i64, c_i64, c_i64, c_f64p, c_vp]),

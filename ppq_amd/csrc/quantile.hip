@@ -2122,6 +2122,11 @@ void ppqhip_quantile_debug_layout(int64_t* out) {
     out[5] = (int64_t)kQPrefTable; out[6] = kPCnt; out[7] = kPTie;
 }
 
+void ppqhip_quantile_hot_layout(int64_t* out) {
+    out[0] = (int64_t)kQHWords; out[1] = kQHOffRec; out[2] = kQHOffHeads; out[3] = kQHOffSlots; out[4] = kQHMaxWg; out[5] = kQHStage;
+    out[6] = kQHZeroEnd; out[7] = kQHThreadKeys;
+}
+
 int ppqhip_quantile_t_multi(const ppqhip_quantile_job* jobs, int num_jobs, float q, void* workspace, void* stream) {
     if (num_jobs <= 0) return PPQHIP_OK;
     if (jobs == nullptr || workspace == nullptr) {

@@ -66,6 +66,9 @@ constexpr int kMinMaxMultiMax = 96;              // jobs per launch (2.3 KB of k
 #ifndef PPQHIP_MM_BLOCK
 #define PPQHIP_MM_BLOCK 256
 #endif
+#ifndef PPQHIP_MM_STREAM
+#define PPQHIP_MM_STREAM 1                 // single tensors beyond 16 MB: the ping-pong form of minmax_small_kernel
+#endif
 #ifndef PPQHIP_MM_WGPC
 #define PPQHIP_MM_WGPC 8
 #endif
@@ -167,7 +170,11 @@ __global__ __launch_bounds__(kMMBlock) void minmax_persistent_kernel(const MinMa
 // The single-tensor launch for LATENCY-bound sizes (see hist_small_kernel, hist.hip: direct arguments instead of the 2.3 KB job
 // table and its two dependent scalar-load rounds, every load of the share in flight before anything else).  The workgroup's slot
 // is read FIRST, so the read-modify-write at the end is no dependent load -> store chain.  K: rows of kMMBlock float4 per share.
-template <int K>
+// PING (mid-size and large single tensors, round 6): two register tiles of K rows ping-pong -- the persistent kernel's streaming loop
+// without its job table.  A small gain here, unlike the histogram's (the persistent min/max kernel was within 4-10 % of the read
+// floor already): interleaved A/B Bx4 6.28 -> 5.92 us, Bx16 19.9 -> 19.3, Bx32 32.4 -> 31.9 (0.805 of 8 TB/s), Bx8 equal at the
+// 10th percentile (10.3 us), profiles/r06_minmax_stream_ab.txt.
+template <int K, bool PING = false, bool NT = false>
 __global__ __launch_bounds__(kMMBlock) void minmax_small_kernel(const float* __restrict__ x, uint32_t n, float* __restrict__ slots) {
     __shared__ float lds[32];
     const uint32_t G = gridDim.x, g = blockIdx.x;
@@ -178,14 +185,38 @@ __global__ __launch_bounds__(kMMBlock) void minmax_small_kernel(const float* __r
     even_split(full_rows, G, g, r0, r1);
     const float4* xv = reinterpret_cast<const float4*>(x) + threadIdx.x;
     float mn = INFINITY, mx = -INFINITY;
-    for (uint32_t r = r0; r < r1; r += K) {
-        float4 buf[K];
+    auto fetch = [&](float4 (&buf)[K], uint32_t r) {
 #pragma unroll
-        for (int k = 0; k < K; k++) buf[k] = xv[(size_t)min(r + (uint32_t)k, r1 - 1) * kMMBlock];      // clamped: duplicates are harmless
+        for (int k = 0; k < K; k++) buf[k] = load4<NT>(xv + (size_t)min(r + (uint32_t)k, r1 - 1) * kMMBlock);      // clamped: duplicates are harmless
+    };
+    auto fold = [&](const float4 (&buf)[K]) {
 #pragma unroll
         for (int k = 0; k < K; k++) {
             mn = fminf(fminf(mn, buf[k].x), fminf(buf[k].y, fminf(buf[k].z, buf[k].w)));
             mx = fmaxf(fmaxf(mx, buf[k].x), fmaxf(buf[k].y, fmaxf(buf[k].z, buf[k].w)));
+        }
+    };
+    if (PING) {
+        if (r0 < r1) {
+            float4 bufa[K], bufb[K];
+            uint32_t r = r0;
+            fetch(bufa, r);
+            for (;;) {
+                fetch(bufb, r + K);
+                fold(bufa);
+                r += K;
+                if (r >= r1) break;
+                fetch(bufa, r + K);
+                fold(bufb);
+                r += K;
+                if (r >= r1) break;
+            }
+        }
+    } else {
+        for (uint32_t r = r0; r < r1; r += K) {
+            float4 buf[K];
+            fetch(buf, r);
+            fold(buf);
         }
     }
     if (g == G - 1) {                                                  // the ragged rest: < kMMBlock float4 + n % 4 elements
@@ -569,6 +600,18 @@ int ppqhip_minmax_t_slots(const float* x, int64_t n, float* slots, void* stream)
         else hipLaunchKernelGGL((minmax_small_kernel<8>), dim3(grid), dim3(kMMBlock), 0, s, x, (uint32_t)n, slots);
         return finish_launch("minmax_t_slots");
     }
+#if PPQHIP_MM_STREAM
+    if (aligned16(x)) {                                           // beyond 16 MB: the same kernel with two ping-pong tiles of two rows
+        const uint32_t full_rows = (uint32_t)((n >> 2) / kMMBlock);
+        uint32_t grid = full_rows / 8;                            // >= two tile pairs per workgroup
+        const uint32_t cap = (uint32_t)(num_cu() * PPQHIP_MM_WGPC);
+        if (grid > cap) grid = cap;
+        if (grid < 1) grid = 1;
+        if (n >= (48ll << 20)) hipLaunchKernelGGL((minmax_small_kernel<2, true, true>), dim3(grid), dim3(kMMBlock), 0, s, x, (uint32_t)n, slots);
+        else hipLaunchKernelGGL((minmax_small_kernel<2, true, false>), dim3(grid), dim3(kMMBlock), 0, s, x, (uint32_t)n, slots);
+        return finish_launch("minmax_t_slots");
+    }
+#endif
     MinMaxJobs args;
     args.count = 1;
     args.job[0].x = x; args.job[0].slots = slots; args.job[0].n = (uint32_t)n; args.job[0].first_tile = 0;

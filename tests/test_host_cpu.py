@@ -863,6 +863,63 @@ def test_quantile_workspace_sizing_covers_the_layout():
         assert int(_lib.lib.ppqhip_quantile_workspace_bytes(n)) >= prefix + (words + 2 * cap(n)) * 4 >= 65536   # (isotone's partials fit too)
 
 
+def test_quantile_hot_path_layout_fits_the_workspace():
+    """The two-launch path of one hinted tensor (quantile.hip) lays the SAME workspace out its own way: header + exact histograms
+    (zeroed by the filter), one 64-B record, one 256-B head pair and two slots per filter workgroup.  ppqhip_quantile_workspace_bytes
+    must cover it for every n, regions must not overlap and must keep the alignment the 16-B loads of the select rely on."""
+    import ctypes
+    from ppq_amd import _lib
+    lay = (ctypes.c_int64 * 8)()
+    _lib.lib.ppqhip_quantile_hot_layout(lay)
+    words, rec, heads, slots, wgs, stage, zero_end, head_keys = (int(v) for v in lay)
+    assert zero_end <= rec and rec + wgs * 16 <= heads and heads + wgs * 2 * head_keys <= slots and slots + wgs * 2 * stage == words
+    assert rec % 4 == 0 and heads % 4 == 0 and slots % 4 == 0 and stage % 4 == 0 and head_keys % 4 == 0
+    assert zero_end >= 64 + 4096 + 2 * 4096 + 2 * 256                      # header + the three exact histograms
+    for n in (1, 262144, 1605632, 51380224, 2 ** 31 - 1):
+        assert int(_lib.lib.ppqhip_quantile_workspace_bytes(n)) >= words * 4, n
+
+
+def test_fast_observers_option_wraps_and_restores_the_reference_method():
+    """install_into_ppq(fast_observers=True) replaces TorchMinMaxObserver.observe on the reference's class (no file touched) and
+    uninstall_from_ppq() puts the reference's own function back; without a device tensor the wrapper defers to it (the host path
+    of the reference is untouched)."""
+    if not os.path.isdir('/root/reference'):
+        pytest.skip('reference not present on this machine')
+    import subprocess
+    import sys
+    code = r'''
+import importlib.machinery, os, sys
+from unittest.mock import MagicMock
+os.environ['PROTOCOL_BUFFERS_PYTHON_IMPLEMENTATION'] = 'python'
+for n in ['onnx','onnx.helper','onnx.numpy_helper','onnx.mapping','onnx.onnx_pb','onnx.checker','onnx.external_data_helper','onnx.shape_inference','onnx.version_converter']:
+    m = MagicMock(); m.__spec__ = importlib.machinery.ModuleSpec(n, None); m.__path__ = []; sys.modules[n] = m
+sys.path.insert(0, '/root/reference'); sys.path.insert(0, %r)
+import torch, ppq
+import ppq_amd
+from ppq.quantization.observer.range import TorchMinMaxObserver, TorchHistObserver
+from ppq.core import QuantizationPolicy, QuantizationProperty as QP, QuantizationStates, TensorQuantizationConfig, RoundingPolicy
+from ppq.IR import Variable
+original = TorchMinMaxObserver.observe
+ppq_amd.install_into_ppq()
+assert TorchMinMaxObserver.observe is original
+ppq_amd.install_into_ppq(fast_observers=True)
+assert TorchMinMaxObserver.observe is not original and TorchMinMaxObserver.observe.__wrapped__ is original
+assert TorchHistObserver.observe is not TorchMinMaxObserver.observe                     # phase 1 of the hist observer reaches it through super()
+cfg = TensorQuantizationConfig(policy=QuantizationPolicy(QP.SYMMETRICAL + QP.LINEAR + QP.PER_TENSOR), rounding=RoundingPolicy.ROUND_HALF_EVEN,
+                               num_of_bits=8, quant_min=-128, quant_max=127, observer_algorithm='minmax', state=QuantizationStates.INITIAL)
+ob = TorchMinMaxObserver(Variable(name='v'), cfg)
+for k in range(3): ob.observe(torch.arange(12, dtype=torch.float32).reshape(3, 4) - 4.0 * k)          # host tensors: the reference's own path
+assert len(ob._min_val_collector) == 3 and not hasattr(ob, '_ppq_amd_minmax')
+ob.render_quantization_config()
+assert abs(float(cfg.scale) - 2 * 11.0 / 255) < 1e-7
+ppq_amd.uninstall_from_ppq()
+assert TorchMinMaxObserver.observe is original
+print('OK')
+''' % ROOT
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'OK' in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
 def test_to_int_dispatch_and_no_cpu_path():
     """PPQLinearQuant_toInt mirrors the reference's dispatch (qfunction/linear.py:218-238): non-linear configs raise, fewer than
     8 bits raise, and -- like every kernel-backed function here -- a host tensor is never computed on the CPU (with a device it
