@@ -1041,6 +1041,8 @@ def uninstall_from_ppq() -> None:
     if 'minmax_observe' in _SAVED_KERNEL_STATE:
         from ppq.quantization.observer.range import TorchMinMaxObserver as RefMinMax
         RefMinMax.observe = _SAVED_KERNEL_STATE.pop('minmax_observe')
+    from . import observer as _observer
+    _observer.SIBLING_PREFETCH = False
     if _SAVED_PLUGIN_STATE:
         import ppq.quantization.observer as ref_observer
         import ppq.quantization.optim.calibration as ref_calibration
@@ -1068,7 +1070,9 @@ def install_plugins_into_ppq(observers: bool = True) -> None:
       observers, so PPQ's OWN ``RuntimeCalibrationPass`` builds them; its two-phase test is by exact type
       (optim/calibration.py:196: ``type(ob) not in {TorchHistObserver, TorchMSEObserver}``), so the two names that module
       imported are re-bound to the classes now in the table (the per-channel extensions 'kl_channel' / 'mse_channel'
-      are two-phase too and therefore need this package's pass)."""
+      are two-phase too and therefore need this package's pass).  PPQ's pass renders the observers one by one; with
+      ``observer.SIBLING_PREFETCH`` (switched on here) the first of those renders fetches the ranges of ALL live observers with one
+      copy and searches all their histograms with one launch per group, the others finish on host values -- same numbers."""
     install_into_ppq()
     from ppq.executor.base import QuantOPRuntimeHook
     from ppq.quantization.optim.base import QuantizationOptimizationPass as RefPass
@@ -1088,6 +1092,8 @@ def install_plugins_into_ppq(observers: bool = True) -> None:
         ref_observer.OBSERVER_TABLE.update(observer.OBSERVER_TABLE)
         ref_calibration.TorchHistObserver = observer.TorchHistObserver
         ref_calibration.TorchMSEObserver = observer.TorchMSEObserver
+        # PPQ's pass renders observer by observer: let the first render fetch what all of them need (observer.SIBLING_PREFETCH)
+        observer.SIBLING_PREFETCH = True
 
 
 class CUDA:

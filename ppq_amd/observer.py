@@ -23,6 +23,8 @@ what PPQ's own ``RuntimeCalibrationPass`` does when these classes are registered
 """
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import weakref
+
 import numpy as np
 import torch
 
@@ -228,6 +230,35 @@ class ObservationQueue:
         self._bytes = 0
 
 
+# Observers driven by a pass that renders them ONE BY ONE (PPQ's own RuntimeCalibrationPass after
+# install_plugins_into_ppq(observers=True): optim/calibration.py renders operation by operation) pay a device synchronisation
+# per observer: 316 of them per ResNet-50 render, 68 ms per pass.  With SIBLING_PREFETCH on, the first
+# stand-alone render that finds its host values missing fetches them for EVERY live observer in the same state at once (steps
+# 1-2 of render_observers: one copy of all ranges, one search launch + one copy per group of histograms); the siblings'
+# own renders then finish on host values.  Results are the same numbers; an observer that observes again drops what was
+# prefetched for it (observe() invalidates), so a sibling of another, still collecting pass is never rendered stale.
+SIBLING_PREFETCH = False
+_LIVE_OBSERVERS: "weakref.WeakSet" = weakref.WeakSet()
+_PREFETCHING = False
+
+
+def _prefetch_siblings(ob) -> None:
+    global _PREFETCHING
+    if not SIBLING_PREFETCH or _PREFETCHING: return
+    _PREFETCHING = True
+    try:
+        def device_of(o):
+            t = getattr(o, '_hist', None) if getattr(o, '_hist', None) is not None else getattr(o, '_range', None)
+            return None if t is None else t.device
+        dev = device_of(ob)
+        # range and histogram observers only (the FP8 'floating' observer's batched search keeps no per-observation invalidation)
+        sibs = [o for o in list(_LIVE_OBSERVERS) if isinstance(o, TorchMinMaxObserver) and is_initial(o._quant_cfg) and device_of(o) == dev]
+        if ob not in sibs: sibs.append(ob)
+        _prefetch(sibs)
+    finally:
+        _PREFETCHING = False
+
+
 class BaseTensorObserver:
     """ppq/quantization/observer/base.py:9-30."""
     queue: Optional[ObservationQueue] = None      # set by RuntimeCalibrationPass(batch_observations=True)
@@ -235,6 +266,7 @@ class BaseTensorObserver:
     def __init__(self, watch_on, quant_cfg):
         self._watch_on = watch_on
         self._quant_cfg = quant_cfg
+        _LIVE_OBSERVERS.add(self)
 
     def _drain(self) -> None:
         """Statistics are about to be read: make sure nothing of this pass is still queued."""
@@ -364,6 +396,7 @@ class TorchMinMaxObserver(BaseTensorObserver):
         if not self._observed:
             raise ValueError('Can not render quantization config yet, Observer data collator is empty. '
                              'Invoke observe() function before render config.')
+        if self._host_range is None: _prefetch_siblings(self)
         if self._host_range is None:
             self._fold()
             self._host_range = self._range.cpu().numpy()
@@ -414,6 +447,8 @@ class TorchHistObserver(TorchMinMaxObserver):
                 self.queue.recorder.append((self, value))
             return super().observe(value)
         elif self._phase == 'Collating Hist':
+            self._losses = None                              # (a search result prefetched for an earlier state of the histogram)
+            if getattr(self, '_best', None) is not None: self._best = None
             if self._hist is None:
                 self._hist = torch.zeros(size=(self._hist_bins,), dtype=torch.int32, device=value.device)
                 if self._hist_bins <= 16384:
@@ -477,6 +512,7 @@ class TorchHistObserver(TorchMinMaxObserver):
         if OBSERVER_MIN_SCALE_MANUL_OVERRIDE in config.detail:
             scale_threshold = config.detail[OBSERVER_MIN_SCALE_MANUL_OVERRIDE]
         quant_bins = 2 ** (config.num_of_bits - 1)
+        if self._losses is None: _prefetch_siblings(self)
         if self._losses is None:
             self._losses = CUDA.KLLosses(histogram, config.num_of_bits).cpu().numpy()[0]
         losses = [{'kl': float(kl), 'bin_range': (j + 1) * quant_bins} for j, kl in enumerate(self._losses)]
@@ -656,6 +692,7 @@ class TorchMSEObserver(TorchHistObserver):
         if config.policy.has_property(P.PER_CHANNEL):
             raise PermissionError('Torch Mse observer do not support PER_CHANNEL policy now, please wait.')
         symmetrical = config.policy.has_property(P.SYMMETRICAL)
+        if self._best is None: _prefetch_siblings(self)
         if self._best is None:
             dev = histogram.device
             self._best = CUDA.MseSearch(histogram.reshape(1, -1),
@@ -1108,8 +1145,22 @@ def render_observers(observers: Sequence[BaseTensorObserver]) -> None:
 
     Results are identical to rendering the observers one by one."""
     observers = [ob for ob in observers if is_initial(ob._quant_cfg)]
+    _prefetch(observers)
+    # 3. host finish; the per-tensor (scale, offset) results travel to the device in one copy
+    global _DEFERRED_SETS
+    _DEFERRED_SETS = pending = []
+    try:
+        for ob in observers:
+            ob.render_quantization_config()
+    finally:
+        _DEFERRED_SETS = None
+        _flush_deferred_sets(pending)
+
+
+def _prefetch(observers: Sequence[BaseTensorObserver]) -> None:
+    """Steps 1-2 of render_observers: every device-to-host copy and every search the renders of `observers` will need."""
     # 1. ranges
-    pend = [(ob, ob.pending_range()) for ob in observers]
+    pend = [(ob, ob.pending_range()) for ob in observers if getattr(ob, '_host_range', None) is None]
     pend = [(ob, r) for ob, r in pend if r is not None]
     if pend:
         flat = torch.cat([r.reshape(-1) for _, r in pend]).cpu().numpy()
@@ -1122,6 +1173,7 @@ def render_observers(observers: Sequence[BaseTensorObserver]) -> None:
     groups: Dict[tuple, List[TorchHistObserver]] = {}
     for ob in observers:
         if isinstance(ob, TorchHistObserver) and ob._phase == 'Collating Hist' and ob._hist is not None:
+            if ob._losses is not None or getattr(ob, '_best', None) is not None: continue        # searched already
             if ob._quant_cfg.policy.has_property(P.PER_TENSOR):
                 groups.setdefault(ob.search_key(), []).append(ob)
     for key, obs in groups.items():
@@ -1156,12 +1208,3 @@ def render_observers(observers: Sequence[BaseTensorObserver]) -> None:
         pos = 0
         for ob, m in zip(fobs, means):
             ob.take_best(best[pos: pos + m.shape[0]]); pos += m.shape[0]
-    # 3. host finish; the per-tensor (scale, offset) results travel to the device in one copy
-    global _DEFERRED_SETS
-    _DEFERRED_SETS = pending = []
-    try:
-        for ob in observers:
-            ob.render_quantization_config()
-    finally:
-        _DEFERRED_SETS = None
-        _flush_deferred_sets(pending)
