@@ -363,6 +363,44 @@ def test_rows_and_slots_accumulators_match_oracle():
         assert np.array_equal(hist.cpu().numpy(), want + 5)
 
 
+def test_sibling_prefetch_renders_the_same_and_never_stale():
+    """observer.SIBLING_PREFETCH (on under install_plugins_into_ppq(observers=True), where PPQ's pass renders observer by observer):
+    the first stand-alone render fetches ranges / searches histograms for every live observer.  Same scales as rendering each
+    alone; an observer that observes AGAIN after a sibling's render must not be rendered from what was prefetched for it --
+    in the range phase and in the histogram phase."""
+    from ppq_amd import LinearQuantizationConfig, observer as obs_mod
+
+    def build(kind, n):
+        out = []
+        for i in range(n):
+            cfg = LinearQuantizationConfig(symmetrical=True, num_of_bits=8, quant_min=-128, quant_max=127)
+            cfg.observer_algorithm = kind
+            out.append(obs_mod.OBSERVER_TABLE[kind](watch_on=type('V', (), {'name': f'v{i}'})(), quant_cfg=cfg))
+        return out
+    g = torch.Generator().manual_seed(31)
+    data = [[(torch.randn(40_000, generator=g) * (1 + i) + 0.1 * b).to(DEV) for b in range(3)] for i in range(6)]
+    wide = (torch.randn(40_000, generator=g) * 50).to(DEV)
+
+    def run(prefetch, kind):
+        obs_mod.SIBLING_PREFETCH = prefetch
+        try:
+            obs = build(kind, 6)
+            phases = 2 if kind in ('kl', 'mse') else 1
+            for ph in range(phases):
+                for ob, ds in zip(obs, data):
+                    for d in ds: ob.observe(d)
+                obs[0].render_quantization_config()          # with prefetch on: fetches / searches for obs[1..5] too
+                obs[5].observe(wide)                         # .. but obs[5] observes once more before ITS render
+                for ob in obs[1:]: ob.render_quantization_config()
+            return [(float(ob._quant_cfg.scale), float(ob._quant_cfg.offset)) for ob in obs]
+        finally:
+            obs_mod.SIBLING_PREFETCH = False
+    for kind in ('minmax', 'kl', 'mse'):
+        a, b = run(False, kind), run(True, kind)
+        assert a == b, (kind, a, b)
+        assert a[5][0] > 2 * a[4][0]                         # the late, wide batch did reach observer 5
+
+
 @pytest.mark.parametrize('mode', ['hip_graph', 'async', 'graph+async'])
 def test_graph_and_async_modes_equal_eager(mode):
     """HIP-graph replay and side-stream observation change scheduling only: identical scales."""
