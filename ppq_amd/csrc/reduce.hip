@@ -380,6 +380,45 @@ __global__ __launch_bounds__(kBlock) void channel_sum_row_kernel(const float* __
     }
 }
 
+// One workgroup per channel, no partials, no second launch: for tensors with enough channels to fill the chip on their own
+// (C >= 2 per CU).  Two rows of the channel in flight per trip (8 16-B loads per lane); the rows are added in index order, the
+// lanes' sums in a fixed tree: deterministic like the two-launch form, whose dependent finish launch costs 4.7 us whatever it reads.
+__global__ __launch_bounds__(kBlock) void channel_sum_single_kernel(const float* __restrict__ x, uint32_t rows_per_channel, uint32_t C,
+                                                                    uint32_t epc, double* __restrict__ sums) {
+    __shared__ double lds[kBlock / kWave];
+    const uint32_t c = blockIdx.x;
+    const uint32_t v1 = epc >> 2;                                      // (vec_ok is a precondition of this kernel)
+    double acc = 0.0;
+    const double seed = threadIdx.x == 0 ? sums[c] : 0.0;             // in flight with the data
+    for (uint32_t n = 0; n < rows_per_channel; n += 2) {
+        const float4* x0 = reinterpret_cast<const float4*>(x + ((size_t)n * C + c) * epc);
+        const float4* x1 = reinterpret_cast<const float4*>(x + ((size_t)min(n + 1, rows_per_channel - 1) * C + c) * epc);
+        const bool two = n + 1 < rows_per_channel;
+        for (uint32_t v = threadIdx.x; v < v1; v += 4 * kBlock) {
+            float4 a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { a[u] = x0[min(v + u * kBlock, v1 - 1)]; b[u] = x1[min(v + u * kBlock, v1 - 1)]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (v + u * kBlock < v1) acc += ((double)a[u].x + (double)a[u].y) + ((double)a[u].z + (double)a[u].w);
+            if (two) {
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (v + u * kBlock < v1) acc += ((double)b[u].x + (double)b[u].y) + ((double)b[u].z + (double)b[u].w);
+            }
+        }
+    }
+    acc = wave_sum_f64(acc);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) lds[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = lds[0];
+        for (int w = 1; w < kBlock / kWave; w++) t += lds[w];
+        sums[c] = seed + t;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void channel_sum_finish_kernel(const double* __restrict__ partial, uint32_t S,
                                                                     uint32_t C, double* __restrict__ sums) {
     const uint32_t c = blockIdx.x * kBlock + threadIdx.x;
@@ -703,7 +742,12 @@ int ppqhip_channel_sum(const float* x, int64_t n, int64_t num_channel, int64_t e
     LaunchScope scope(K_CHANNEL_SUM, 4.0 * (double)n, s);
     const uint32_t C = (uint32_t)num_channel, epc = (uint32_t)elem_per_channel;
     const uint32_t outer = (uint32_t)(n / (num_channel * elem_per_channel));
-    if (epc >= 64) {
+#ifndef PPQHIP_CSUM_SINGLE
+#define PPQHIP_CSUM_SINGLE 1
+#endif
+    if (PPQHIP_CSUM_SINGLE && epc >= 64 && epc % 4 == 0 && aligned16(x) && C >= 2u * (uint32_t)num_cu()) {
+        hipLaunchKernelGGL(channel_sum_single_kernel, dim3(C), dim3(kBlock), 0, s, x, outer, C, epc, sums);
+    } else if (epc >= 64) {
         uint32_t S = (4 * (uint32_t)num_cu() + C - 1) / C;            // >= 4 workgroups per CU in total
         if (S > outer) S = outer;
         if (S < 1) S = 1;

@@ -582,7 +582,8 @@ def test_fp8_calibration_transformer_block():
 
 
 @pytest.mark.parametrize('shape,axis', [((8, 64, 28, 28), 1), ((4, 512, 7, 7), 1), ((3, 5, 17), 1), ((32, 1000), 1),
-                                         ((2, 6, 50, 50), 0), ((7, 33), -1), ((1, 16, 3), 2), ((64, 3, 224, 224), 1)])
+                                         ((2, 6, 50, 50), 0), ((7, 33), -1), ((1, 16, 3), 2), ((64, 3, 224, 224), 1),
+                                        ((3, 512, 56, 56), 1), ((2, 1024, 14, 14), 1), ((5, 600, 8, 12), 1)])       # C >= 2 per CU: the one-launch form (odd / even row counts, rows shorter and longer than a trip)
 def test_channel_mean(CUDA, shape, axis):
     """ChannelMean == the per-channel torch.mean of BiasCorrectionPass.collect_bias
     (training.py:438-448); accumulated in double and in a fixed order, so the float32 result is the
