@@ -1957,6 +1957,9 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
 #ifndef PPQHIP_QH_SPLIT_WANTED
 #define PPQHIP_QH_SPLIT_WANTED 2048
 #endif
+#ifndef PPQHIP_QH_HEADS_MIN
+#define PPQHIP_QH_HEADS_MIN 4u                 // expected keys per filter workgroup and side from which the heads travel with the records
+#endif
 #ifndef PPQHIP_QH_NT_ELEMS
 #define PPQHIP_QH_NT_ELEMS (48ll << 20)
 #endif
@@ -1988,7 +1991,7 @@ static void quantile_hot_launch(const QHot& a0, hipStream_t s) {
         // a filter workgroup is expected to list ~1.5 x wanted / g keys per side: more than the record holds -> the heads travel with
         // the records; lists of thousands of keys -> the two sides are selected by two workgroups
         const uint32_t wanted = a.n - a.k_hi > a.k_lo + 1u ? a.n - a.k_hi : a.k_lo + 1u;
-        a.heads = (wanted + wanted / 2u) / g >= 4u ? 1u : 0u;
+        a.heads = (wanted + wanted / 2u) / g >= PPQHIP_QH_HEADS_MIN ? 1u : 0u;
         a.split = (wanted >= PPQHIP_QH_SPLIT_WANTED && num_cu() >= 2) ? 1u : 0u;
         if ((int64_t)a.n >= PPQHIP_QH_NT_ELEMS) hipLaunchKernelGGL((quantile_hot_filter_kernel<2, true, true>), dim3(g), dim3(kQHBlock), 0, s, a);
         else hipLaunchKernelGGL((quantile_hot_filter_kernel<2, true, false>), dim3(g), dim3(kQHBlock), 0, s, a);
