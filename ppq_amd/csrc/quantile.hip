@@ -47,21 +47,31 @@ __device__ __forceinline__ float key2f(uint32_t k) {
 // (explicit unsigned min / max: `max` resolves to the int overload in the host pass of this translation unit)
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
-__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v += (uint32_t)__shfl_xor((int)v, m, 64);
+// Wave64 inclusive scan / reductions on the DPP path (row_shr 1,2,4,8 inside each row of 16 lanes, then row_bcast 15 / 31 across
+// the rows): six VALU instructions.  The __shfl_up / __shfl_xor forms compile to ds_bpermute_b32 -- a ~120-cycle LDS-crossbar round
+// trip each, and a scan is six of them in a dependent chain.
+template <typename Op>
+__device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t v, const uint32_t identity, Op op) {
+#define PPQ_DPP(ctrl, rows) (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, ctrl, rows, 0xf, false)
+    v = op(v, PPQ_DPP(0x111, 0xf));        // row_shr:1
+    v = op(v, PPQ_DPP(0x112, 0xf));        // row_shr:2
+    v = op(v, PPQ_DPP(0x114, 0xf));        // row_shr:4
+    v = op(v, PPQ_DPP(0x118, 0xf));        // row_shr:8
+    v = op(v, PPQ_DPP(0x142, 0xa));        // row_bcast:15 into rows 1 and 3
+    v = op(v, PPQ_DPP(0x143, 0xc));        // row_bcast:31 into rows 2 and 3
+#undef PPQ_DPP
     return v;
 }
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v = umin(v, (uint32_t)__shfl_xor((int)v, m, 64));
-    return v;
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) { return wave_scan_dpp(v, 0u, [](uint32_t a, uint32_t b) { return a + b; }); }
+__device__ __forceinline__ uint32_t wave_all_min(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_dpp(v, 0xFFFFFFFFu, [](uint32_t a, uint32_t b) { return a < b ? a : b; }), 63);
 }
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) v = umax(v, (uint32_t)__shfl_xor((int)v, m, 64));
-    return v;
+__device__ __forceinline__ uint32_t wave_all_max(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_dpp(v, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; }), 63);
 }
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_add(v), 63); }
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) { return wave_all_min(v); }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return wave_all_max(v); }
 __device__ __forceinline__ int popc_mask(unsigned long long m) {
     return __builtin_popcount((unsigned)m) + __builtin_popcount((unsigned)(m >> 32));
 }
@@ -197,12 +207,7 @@ __device__ __forceinline__ bool hint_valid(const uint32_t* __restrict__ hint, ui
 template <int THREADS>
 __device__ __forceinline__ void block_scan_excl(uint32_t v, uint32_t* scratch, uint32_t& excl, uint32_t& total) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    uint32_t inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64);
-        if (lane >= d) inc += o;
-    }
+    const uint32_t inc = wave_scan_add(v);
     __syncthreads();                  // scratch may still be read from a previous call
     if (lane == 63) scratch[wid] = inc;
     __syncthreads();
@@ -1434,28 +1439,6 @@ struct QHExactLds {
     uint32_t h[2 * (kQ1 + kQTrash)];
 };
 
-// Wave64 inclusive scan / reductions on the DPP path (row_shr 1,2,4,8 inside each row of 16 lanes, then row_bcast 15 / 31 across
-// the rows): six VALU instructions.  The __shfl_up / __shfl_xor forms compile to ds_bpermute_b32 -- a ~120-cycle LDS-crossbar round
-// trip each, and a scan is six of them in a dependent chain.
-template <typename Op>
-__device__ __forceinline__ uint32_t wave_scan_dpp(uint32_t v, const uint32_t identity, Op op) {
-#define PPQ_DPP(ctrl, rows) (uint32_t)__builtin_amdgcn_update_dpp((int)identity, (int)v, ctrl, rows, 0xf, false)
-    v = op(v, PPQ_DPP(0x111, 0xf));        // row_shr:1
-    v = op(v, PPQ_DPP(0x112, 0xf));        // row_shr:2
-    v = op(v, PPQ_DPP(0x114, 0xf));        // row_shr:4
-    v = op(v, PPQ_DPP(0x118, 0xf));        // row_shr:8
-    v = op(v, PPQ_DPP(0x142, 0xa));        // row_bcast:15 into rows 1 and 3
-    v = op(v, PPQ_DPP(0x143, 0xc));        // row_bcast:31 into rows 2 and 3
-#undef PPQ_DPP
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) { return wave_scan_dpp(v, 0u, [](uint32_t a, uint32_t b) { return a + b; }); }
-__device__ __forceinline__ uint32_t wave_all_min(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_dpp(v, 0xFFFFFFFFu, [](uint32_t a, uint32_t b) { return a < b ? a : b; }), 63);
-}
-__device__ __forceinline__ uint32_t wave_all_max(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_readlane((int)wave_scan_dpp(v, 0u, [](uint32_t a, uint32_t b) { return a > b ? a : b; }), 63);
-}
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
 // The rank-th smallest (0-based) of keys[0..count) in LDS, 1 <= count <= kQHWaveKeys, by ONE wavefront and without a barrier.
