@@ -1278,7 +1278,7 @@ __global__ __launch_bounds__(kBlock) void quantile_f123_single_kernel(const QSeq
 #define PPQHIP_QH_SELECT_WGS 0                      // grid of the select launch; 0: one workgroup per CU
 #endif
 #ifdef PPQHIP_QH_TIMING                             // developer builds: s_memrealtime stamps (10 ns) of the selecting workgroup -> ws[32 + i]
-#define QH_STAMP(i) do { if (threadIdx.x == 0) { a.ws[32 + (i)] = (uint32_t)wall_clock64(); a.ws[48 + (i)] = (uint32_t)__builtin_readcyclecounter(); } } while (0)
+#define QH_STAMP(i) do { if (threadIdx.x == 0) { a.ws[32 + (i)] = (uint32_t)wall_clock64(); } } while (0)
 #else
 #define QH_STAMP(i) do { } while (0)
 #endif
@@ -1707,25 +1707,37 @@ __device__ __forceinline__ void hot_select_records(const QHot& a, const uint32_t
     }
 }
 
-// One CHUNK of the tensor (kQHChunkRows rows of kQHBlock float4 = 64 KB; the last one also owns the n % 4 elements behind the
-// last float4): on_tile(sample, valid) once per four rows, on_elem(value, valid) for every slot -- trip counts are block uniform.
-constexpr uint32_t kQHChunkRows = 8, kQHChunkVec = kQHChunkRows * kQHBlock;
+// One CHUNK of the tensor: `rows` rows of kQHBlock float4 starting at row c * rows (a multiple of four rows; the last chunk also
+// owns the n % 4 elements behind the last float4): on_tile(sample, valid) once per four rows, on_elem(value, valid) for every
+// slot -- trip counts are block uniform.  Two register tiles of four rows ping-pong.
 template <typename FT, typename FE>
-__device__ __forceinline__ void hot_walk_chunk(const float* __restrict__ x, uint32_t n, uint32_t c, uint32_t chunks, FT on_tile, FE on_elem) {
+__device__ __forceinline__ void hot_walk_chunk(const float* __restrict__ x, uint32_t n, uint32_t c, uint32_t chunks, uint32_t rows, FT on_tile, FE on_elem) {
     const uint32_t nvec = n >> 2;
     const float4* xv = reinterpret_cast<const float4*>(x);
-#pragma unroll
-    for (uint32_t half = 0; half < kQHChunkRows / 4; half++) {
-        const uint32_t v0 = c * kQHChunkVec + half * 4u * kQHBlock + threadIdx.x;
-        float4 b[4];
+    const uint32_t v_begin = c * rows * kQHBlock + threadIdx.x, groups = rows / 4u;
+    float4 ba[4], bb[4];
+    auto fetch = [&](float4 (&b)[4], uint32_t grp) {
+        const uint32_t v0 = v_begin + umin(grp, groups - 1u) * 4u * kQHBlock;
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) b[u] = gload4<false>(xv + umin(v0 + u * kQHBlock, nvec - 1u));        // nvec >= 1: n >= 2^18
+    };
+    auto consume = [&](const float4 (&b)[4], uint32_t grp) {
+        const uint32_t v0 = v_begin + grp * 4u * kQHBlock;
         on_tile(b[0].x, v0 < nvec);
 #pragma unroll
         for (uint32_t u = 0; u < 4; u++) {
             const bool in = v0 + u * kQHBlock < nvec;
             on_elem(b[u].x, in); on_elem(b[u].y, in); on_elem(b[u].z, in); on_elem(b[u].w, in);
         }
+    };
+    fetch(ba, 0);
+    for (uint32_t grp = 0;;) {
+        fetch(bb, grp + 1);
+        consume(ba, grp);
+        if (++grp >= groups) break;
+        fetch(ba, grp + 1);
+        consume(bb, grp);
+        if (++grp >= groups) break;
     }
     if (c == chunks - 1u) {                                            // block uniform
         const uint32_t i = (nvec << 2) + threadIdx.x;
@@ -1748,7 +1760,7 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
     // is resident whenever any other one is; an arrival ticket instead -- measured: a returning device atomic ahead of the
     // records, +0.8 us on every call -- would not need that, the exact passes below do not need it either.)
 #ifdef PPQHIP_QH_TIMING
-    const uint32_t stamp0 = (uint32_t)wall_clock64(), stamp0c = (uint32_t)__builtin_readcyclecounter();
+    const uint32_t stamp0 = (uint32_t)wall_clock64();
 #endif
     const uint4 hdr = *reinterpret_cast<const uint4*>(ws);
     const uint32_t role = blockIdx.x == 0 ? 0u : ((a.split && blockIdx.x == 1) ? 1u : 0xFFFFFFFFu);
@@ -1769,7 +1781,7 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
     }
     if (role == 0u) {
 #ifdef PPQHIP_QH_TIMING
-        if (threadIdx.x == 0) { a.ws[32] = stamp0; a.ws[48] = stamp0c; }
+        if (threadIdx.x == 0) { a.ws[32] = stamp0; }
 #endif
         QH_STAMP(1);
         if (enabled) hot_select_records(a, T, a.split ? 1u : 3u, L.s, key_sel, done_sel, keep_sel);
@@ -1808,8 +1820,14 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
         __syncthreads();
         uint32_t* he = L.e.h;
         const uint32_t kk[2] = {a.k_hi, a.k_lo};
-        const uint32_t chunks = ((n >> 2) + kQHChunkVec - 1u) / kQHChunkVec;
+        // chunks of 8 .. 256 rows (64 KB .. 2 MB), about four per workgroup, handed out by a counter (a returning device atomic is
+        // a 1.8 us round trip: one per 64 KB, not overlapped, held the passes at 3.5 TB/s)
+        const uint32_t G = gridDim.x, total_rows = ((n >> 2) + kQHBlock - 1u) / kQHBlock;
+        uint32_t chunk_rows = (total_rows + 4u * G - 1u) / (4u * G);
+        chunk_rows = umin(256u, umax(8u, (chunk_rows + 3u) & ~3u));
+        const uint32_t chunks = (total_rows + chunk_rows - 1u) / chunk_rows;
         for (int level = 0; level < 3; level++) {
+            if (role == 0u) QH_STAMP(16 + 4 * level);
             for (uint32_t i = threadIdx.x; i < 2u * (kQ1 + kQTrash); i += kQHBlock) he[i] = 0u;
             __syncthreads();
             uint32_t mine = 0;
@@ -1824,19 +1842,24 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
             HotCounter hi_c, lo_c;
             hi_c.init(he, nb);
             lo_c.init(he + kQ1 + kQTrash, nb);
+            // every chunk comes from the counter (a chunk owned by a workgroup that is not resident would stall the level); the NEXT
+            // ticket is requested before the current chunk is walked, so only the first round trip of a level is exposed
+            uint32_t ticket = 0;
+            if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(&ws[kQHNext + level], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (;;) {
-                if (threadIdx.x == 0) bcast[0] = __hip_atomic_fetch_add(&ws[kQHNext + level], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (threadIdx.x == 0) bcast[0] = ticket;
                 __syncthreads();
                 const uint32_t c = bcast[0];
                 __syncthreads();
                 if (c >= chunks) break;
+                if (threadIdx.x == 0) ticket = __hip_atomic_fetch_add(&ws[kQHNext + level], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 mine++;
                 if (level == 0) {
-                    hot_walk_chunk(a.x, n, c, chunks,
+                    hot_walk_chunk(a.x, n, c, chunks, chunk_rows,
                                    [&](float v, bool in) { acc.elect((int)(f2key(v) >> 20), in); },
                                    [&](float v, bool in) { acc.template commit<false>((int)(f2key(v) >> 20), in); });
                 } else {
-                    hot_walk_chunk(a.x, n, c, chunks,
+                    hot_walk_chunk(a.x, n, c, chunks, chunk_rows,
                                    [&](float v, bool in) {
                                        const uint32_t key = f2key(v);
                                        hi_c.elect((int)((key >> shift) & dmask), in && (key >> pshift) == p_hi);
@@ -1850,6 +1873,7 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
                                    });
                 }
             }
+            if (role == 0u) QH_STAMP(17 + 4 * level);
             if (level == 0) acc.flush_hot(); else { hi_c.flush(); lo_c.flush(); }
             __syncthreads();
             if (mine) {                             // this workgroup's counts -> the global histograms of the level
@@ -1866,27 +1890,53 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
             // the level is complete when all its chunks are counted: publish mine, wait for the rest
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if (role == 0u) QH_STAMP(18 + 4 * level);
             if (threadIdx.x == 0) {
-                if (mine) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __hip_atomic_fetch_add(&ws[kQHDone + level], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                // (what this workgroup published are device atomics, drained above: no L2 write-back to wait for -- agent atomics on both
+                //  sides of a hand-off are a valid form, MI355X_MICROARCH.md "Valid forms"; a release fence here was 1.7 us per level)
+                if (mine) __hip_atomic_fetch_add(&ws[kQHDone + level], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 while (__hip_atomic_load(&ws[kQHDone + level], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < chunks) __builtin_amdgcn_s_sleep(8);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
             __syncthreads();
-            for (int w = 0; w < 2; w++) {
-                if (!(open_mask & (1u << w))) continue;                 // block uniform
-                if (level == 0) {
-                    select_bin<kQHBlock>(ws + kQHOffH0, kQ1, kk[w], scratch, sel);
-                    top[w] = sel[0]; r0k[w] = sel[1];
-                } else if (level == 1) {
-                    select_bin<kQHBlock>(ws + kQHOffH1 + w * kQ2, kQ2, r0k[w], scratch, sel);
-                    p24[w] = (top[w] << 12) | sel[0]; r24[w] = sel[1];
-                } else {
-                    select_bin<kQHBlock>(ws + kQHOffH2 + w * kQ3, kQ3, r24[w], scratch, sel);
-                    low[w] = sel[0];
+            if (role == 0u) QH_STAMP(19 + 4 * level);
+            {   // the bin of each open side's rank: half h of the workgroup scans side h's histogram of the level (both at once)
+                const uint32_t half = rfl(threadIdx.x >> 8), lt = threadIdx.x & 255u, wl = rfl(lt >> 6), lane = threadIdx.x & 63u;
+                const uint32_t nbins = level == 2 ? (uint32_t)kQ3 : (uint32_t)kQ1, per = nbins / 256u;          // 16 or 1 bins per thread
+                const uint32_t* Hs = level == 0 ? ws + kQHOffH0 : (level == 1 ? ws + kQHOffH1 + half * kQ2 : ws + kQHOffH2 + half * kQ3);
+                const uint32_t want = level == 0 ? kk[half] : (level == 1 ? r0k[half] : r24[half]);
+                // the histogram goes through LDS: 16-B loads at consecutive addresses (thread t reading its 16 bins straight from
+                // global memory is sixteen loads of 64 scattered lines each -- this stage took 6.6 us of a 20 us level)
+                {
+                    const uint4* H4 = reinterpret_cast<const uint4*>(Hs);
+                    uint4* he4 = reinterpret_cast<uint4*>(he + half * (kQ1 + kQTrash));
+                    for (uint32_t i = lt; i < nbins / 4u; i += 256u) he4[i] = H4[i];
+                }
+                __syncthreads();
+                const uint32_t* hl = he + half * (kQ1 + kQTrash);
+                uint32_t b[16], sum = 0u;
+#pragma unroll
+                for (uint32_t j = 0; j < 16; j++) { b[j] = j < per ? hl[lt * per + j] : 0u; sum += b[j]; }
+                const uint32_t inc = wave_scan_add(sum);
+                if (lane == 63u) scratch[half * 4u + wl] = inc;
+                __syncthreads();
+                uint32_t woff = 0u;
+#pragma unroll
+                for (uint32_t ww = 0; ww < 4; ww++) woff += ww < wl ? scratch[half * 4u + ww] : 0u;
+                const uint32_t excl = woff + inc - sum;
+                if (want >= excl && want < excl + sum) {                // one thread per half
+                    uint32_t rin = want - excl, digit = lt * per;
+#pragma unroll
+                    for (uint32_t j = 0; j < 15; j++) if (j + 1u < per && digit == lt * per + j && rin >= b[j]) { rin -= b[j]; digit++; }
+                    scratch[8u + half * 2u] = digit; scratch[9u + half * 2u] = rin;
+                }
+                __syncthreads();
+                for (int w = 0; w < 2; w++) {
+                    if (!(open_mask & (1u << w))) continue;
+                    const uint32_t digit = scratch[8 + 2 * w], rin = scratch[9 + 2 * w];
+                    if (level == 0) { top[w] = digit; r0k[w] = rin; }
+                    else if (level == 1) { p24[w] = (top[w] << 12) | digit; r24[w] = rin; }
+                    else low[w] = digit;
                 }
                 __syncthreads();
             }
