@@ -1287,12 +1287,15 @@ constexpr uint32_t kQHStage = 2048;                 // keys a workgroup can stag
 constexpr uint32_t kQHInline = 6;                   // keys per side inside the record
 constexpr uint32_t kQHMaxWg = 512;                  // filter grid limit (records, slots)
 constexpr uint32_t kQHListMax = 16384;              // longest list a hint may keep producing
+constexpr uint32_t kQHSpeculators = 16;              // workgroups of the select launch that request the records before they know their role
 constexpr uint32_t kQHWantedMax = 8192;             // the host routes here only when both wanted counts are at most this
 // workspace layout (uint32 words)
 enum { kQHEnabled = 0, kQHTHi = 1, kQHTLo = 2, kQHUses = 3,      // written by the filter's workgroup 0 (uses: hint word 7 as it found it)
        kQHZero0 = 4,                                // first word the filter zeroes
        kQHLoFlag = 4,                               // workgroup 1 -> workgroup 0 (split select): 0 pending, 1 settled, 2 open
-       kQHLoKey = 5, kQHLoKeep = 6,
+       kQHLoKey = 5, kQHLoKeep = 6, kQHLoT = 8,     // (8: the lo threshold for the next call)
+       kQHRoleTicket = 10,                          // arrival ticket of the select launch: the first arrival selects (the second: the lo side of a split select)
+       kQHLoClaim = 9,                              // workgroup 1 is running and WILL deliver the lo side
        kQHDecision = 7,                             // workgroup 0 -> everybody: 0 pending, 1 all settled, 0x10 | open mask
        kQHNext = 12,                                // [3] next chunk of each exact level
        kQHDone = 16 };                              // [3] chunks counted per exact level
@@ -1433,6 +1436,7 @@ struct QHSelLds {
     uint32_t wavehist[2][320];                      // wave_select: 256 counters + 64 trash counters per wave
     uint32_t total[2], tie[2], nsurv[2], nbig[2], nbigdesc[2], flags;
     uint32_t bin[2], rin[2], result[2];
+    uint32_t bin_up[2], bin_q[2];                    // re-centring the thresholds: the bin of rank total - target, of rank total / 4
     uint32_t sc[2][8];
 };
 struct QHExactLds {
@@ -1510,25 +1514,34 @@ __device__ __forceinline__ uint32_t wave_select(const uint32_t* keys, uint32_t c
 // slot are requested together, ONE round trip; longer slots go through LDS).  The lo side runs on ~key, so that both sides read
 // "the rank-th smallest of the keys ABOVE a threshold".  One histogram round on fixed bit positions of (key - T - 1) finds the
 // 2^13-key-wide bin of the answer; the keys of that bin are few and one wavefront per side finishes on them.
-__device__ __forceinline__ void hot_select_records(const QHot& a, const uint32_t (&T)[2], const uint32_t sides, QHSelLds& L, uint32_t (&key_out)[2], bool (&done)[2],
-                                                   bool (&keep)[2]) {
-    const uint32_t n = a.n, t = threadIdx.x, lane = t & 63u;
-    uint4 r4[4];                                                       // the 64-B record of workgroup t
+// What thread t of a selecting workgroup holds of filter workgroup t: its 64-B record and (big tensors, `heads`) the first 32 keys
+// of both its slots.  Requested BEFORE the workgroup knows whether it selects at all (see the kernel): one round trip for the
+// arrival ticket, the header and these.
+struct QHRecs {
+    uint4 r4[4];
     uint4 k4[2][kQHThreadKeys / 4];
-    r4[0] = r4[1] = r4[2] = r4[3] = make_uint4(0u, 0u, 0u, 0u);
-    if (t < a.wgs) {
-        const uint4* rec = reinterpret_cast<const uint4*>(a.ws + kQHOffRec) + (size_t)t * 4;
-        r4[0] = rec[0]; r4[1] = rec[1]; r4[2] = rec[2]; r4[3] = rec[3];
+};
+__device__ __forceinline__ void hot_load_records(const QHot& a, QHRecs& R) {
+    R.r4[0] = R.r4[1] = R.r4[2] = R.r4[3] = make_uint4(0u, 0u, 0u, 0u);
+    if (threadIdx.x < a.wgs) {
+        const uint4* rec = reinterpret_cast<const uint4*>(a.ws + kQHOffRec) + (size_t)threadIdx.x * 4;
+        R.r4[0] = rec[0]; R.r4[1] = rec[1]; R.r4[2] = rec[2]; R.r4[3] = rec[3];
         if (a.heads) {                                                 // (the filter wrote every head in this mode)
 #pragma unroll
             for (int w = 0; w < 2; w++) {
-                if (!(sides & (1u << w))) continue;
-                const uint4* head = reinterpret_cast<const uint4*>(a.ws + kQHOffHeads) + ((size_t)t * 2 + w) * (kQHThreadKeys / 4);
+                const uint4* head = reinterpret_cast<const uint4*>(a.ws + kQHOffHeads) + ((size_t)threadIdx.x * 2 + w) * (kQHThreadKeys / 4);
 #pragma unroll
-                for (uint32_t i = 0; i < kQHThreadKeys / 4; i++) k4[w][i] = head[i];
+                for (uint32_t i = 0; i < kQHThreadKeys / 4; i++) R.k4[w][i] = head[i];
             }
         }
     }
+}
+
+__device__ __forceinline__ void hot_select_records(const QHot& a, QHRecs& R, const uint32_t (&T)[2], const uint32_t sides, QHSelLds& L, uint32_t (&key_out)[2],
+                                                   bool (&done)[2], bool (&keep)[2], uint32_t (&T_next)[2]) {
+    const uint32_t n = a.n, t = threadIdx.x, lane = t & 63u;
+    uint4 (&r4)[4] = R.r4;
+    uint4 (&k4)[2][kQHThreadKeys / 4] = R.k4;
     if (t < 2) { L.total[t] = 0u; L.tie[t] = 0u; L.nsurv[t] = 0u; L.nbig[t] = 0u; L.nbigdesc[t] = 0u; L.flags = 0u; }
     {
         uint4* z = reinterpret_cast<uint4*>(&L.hist[0][0]);           // (2 x 2112 words = 1056 uint4)
@@ -1629,12 +1642,16 @@ __device__ __forceinline__ void hot_select_records(const QHot& a, const uint32_t
         rank[w] = w ? total[w] - 1u - k : k - (n - total[w]);
         done[w] = false; keep[w] = false; key_out[w] = T[w]; how[w] = 0;
         if ((flags & (1u << w)) || !(sides & (1u << w))) continue;
-        const uint32_t limit = umin(q_list_limit(wanted[w], quantile_spec_cap(n)), kQHListMax);
         if (total[w] >= wanted[w]) {
-            how[w] = 2; done[w] = true;
-            keep[w] = total[w] - wanted[w] >= (wanted[w] >> 3) + 8u && total[w] <= limit;
+            // settled by the list.  The hint is KEPT and its threshold re-centred on this batch (below): select A's rule -- drop a hint
+            // whose list came out nearly too short or needlessly long -- costs three exact passes on the next batch here
+            how[w] = 2; done[w] = true; keep[w] = total[w] <= kQHListMax;
         } else if (wanted[w] - total[w] <= L.tie[w]) { how[w] = 1; done[w] = true; keep[w] = true; }     // the tie value itself
     }
+    uint32_t target[2];
+#pragma unroll
+    for (int w = 0; w < 2; w++) target[w] = wanted[w] + (wanted[w] >> 1) + 32u;                          // keys the NEXT list should hold
+    if (t < 2) { L.bin_up[t] = 0u; L.bin_q[t] = 0u; }
     {   // the bin of the rank: half h of the workgroup scans side h (thread lt owns bins [8 lt, 8 lt + 8))
         const uint32_t half = rfl(t >> 8), lt = t & 255u, wl = rfl(lt >> 6);
         const uint4* h4 = reinterpret_cast<const uint4*>(&L.hist[half][0]);       // ((kQHBins + 64) * 4 B: 16-B aligned rows)
@@ -1655,9 +1672,36 @@ __device__ __forceinline__ void hot_select_records(const QHot& a, const uint32_t
             for (int j = 0; j < 7; j++) if (digit == lt * 8u + (uint32_t)j && rin >= b[j]) { rin -= b[j]; digit++; }
             L.bin[half] = digit; L.rin[half] = rin;
         }
+        // the same prefix sums place two more ranks: total - target (everything from that bin up is what the next list should be)
+        // and total / 4 (how densely the keys lie just above the threshold, should the list have to grow)
+        const uint32_t tot = half ? total[1] : total[0], tgt = half ? target[1] : target[0];
+        if ((half ? how[1] : how[0]) == 2 && sum != 0u) {
+            auto place = [&](uint32_t rr) {
+                uint32_t rin = rr - excl, digit = lt * 8u;
+#pragma unroll
+                for (int j = 0; j < 7; j++) if (digit == lt * 8u + (uint32_t)j && rin >= b[j]) { rin -= b[j]; digit++; }
+                return digit;
+            };
+            if (tot > tgt && tot - tgt >= excl && tot - tgt < excl + sum) L.bin_up[half] = place(tot - tgt);
+            if (tot < tgt && tot / 4u >= excl && tot / 4u < excl + sum) L.bin_q[half] = place(tot / 4u);
+        }
     }
     __syncthreads();
     QH_STAMP(13);
+#pragma unroll
+    for (int w = 0; w < 2; w++) {                                       // next call's thresholds (on the key' axis, then back)
+        T_next[w] = T[w];
+        if (how[w] != 2 || !keep[w]) continue;
+        uint32_t Tpn = Tp[w];
+        if (total[w] > target[w]) Tpn = Tp[w] + (L.bin_up[w] << kQHDigitShift);         // exact: the hist says how many keys lie above
+        else if (total[w] < target[w]) {                                   // extrapolated from the density of the lowest quarter of the list
+            const unsigned long long span = ((unsigned long long)L.bin_q[w] + 1ull) << kQHDigitShift;
+            unsigned long long delta = (unsigned long long)(target[w] - total[w]) * span * 4ull / (unsigned long long)umax(total[w], 1u);
+            if (delta > 8ull * span) delta = 8ull * span;
+            Tpn = (unsigned long long)Tp[w] > delta ? Tp[w] - (uint32_t)delta : 0u;
+        }
+        T_next[w] = w ? ~Tpn : Tpn;
+    }
 #pragma unroll
     for (int w = 0; w < 2; w++) {
         if (how[w] != 2) continue;
@@ -1756,37 +1800,65 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
     __shared__ uint32_t scratch[32], sel[2], bcast[4];
     const uint32_t n = a.n;
     uint32_t* ws = a.ws;
-    // Workgroup 0 selects; the others wait for its decision.  (Workgroups of a grid are dispatched in index order, so workgroup 0
-    // is resident whenever any other one is; an arrival ticket instead -- measured: a returning device atomic ahead of the
-    // records, +0.8 us on every call -- would not need that, the exact passes below do not need it either.)
+    // The selecting role goes to the workgroup that ARRIVES first (a ticket), the second side of a split select to the second.
+    // Rounds of measurements with "workgroup 0 selects, the others wait" ended in launches of 7 .. 55 s: with three queues busy
+    // (two of these launches on two streams beside a copy on a third) workgroup 0 of a grid is NOT always resident when its
+    // siblings are, and two launches whose pollers hold each other's CUs only move again when the queue scheduler time-slices
+    // them (tools/quantile_soak.py single, profiles/r06_quantile_soak.txt).  Nothing here depends on dispatch order now.  The
+    // ticket's round trip is hidden: the lowest kQHSpeculators workgroups -- in practice the first to arrive -- request the
+    // records together with it.
 #ifdef PPQHIP_QH_TIMING
     const uint32_t stamp0 = (uint32_t)wall_clock64();
 #endif
     const uint4 hdr = *reinterpret_cast<const uint4*>(ws);
-    const uint32_t role = blockIdx.x == 0 ? 0u : ((a.split && blockIdx.x == 1) ? 1u : 0xFFFFFFFFu);
+    if (threadIdx.x == 0) bcast[0] = __hip_atomic_fetch_add(&ws[kQHRoleTicket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    QHRecs R;
+    const bool speculated = blockIdx.x < kQHSpeculators;
+    if (speculated) hot_load_records(a, R);
+    __syncthreads();
+    const uint32_t arrival = bcast[0];
+    __syncthreads();
+    const uint32_t role = arrival == 0u ? 0u : ((a.split && arrival == 1u) ? 1u : 0xFFFFFFFFu);
+    if (role < 2u && !speculated) hot_load_records(a, R);
     const bool enabled = hdr.x != 0u;
     const uint32_t T[2] = {hdr.y, hdr.z};
     uint32_t key_sel[2] = {T[0], T[1]};
     bool done_sel[2] = {false, false}, keep_sel[2] = {false, false};
-    // ---- the decision: workgroup 0 publishes, everybody else polls ----
+    uint32_t T_next[2] = {T[0], T[1]};
+    // ---- the decision: the selecting workgroup publishes, everybody else polls ----
     uint32_t open_mask;
-    if (role == 1u) {                                                  // (split select: the lo side, handed to workgroup 0)
-        if (enabled) hot_select_records(a, T, 2u, L.s, key_sel, done_sel, keep_sel);
-        if (threadIdx.x == 0) {
-            __hip_atomic_store(&ws[kQHLoKey], key_sel[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ws[kQHLoKeep], keep_sel[1] ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&ws[kQHLoFlag], done_sel[1] ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    // the second arrival of a split select says FIRST that it is running: the first waits for the lo side only then (a workgroup
+    // that is not resident must never be waited for), and takes the lo side itself otherwise
+    if (role == 1u && threadIdx.x == 0) __hip_atomic_store(&ws[kQHLoClaim], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool lo_elsewhere = false;
     if (role == 0u) {
 #ifdef PPQHIP_QH_TIMING
         if (threadIdx.x == 0) { a.ws[32] = stamp0; }
 #endif
         QH_STAMP(1);
-        if (enabled) hot_select_records(a, T, a.split ? 1u : 3u, L.s, key_sel, done_sel, keep_sel);
+    }
+    // ONE call site for both roles (the function is a few thousand instructions, inlined: a second copy costs registers and scratch)
+    if (role < 2u && enabled) hot_select_records(a, R, T, role == 1u ? 2u : (a.split ? 1u : 3u), L.s, key_sel, done_sel, keep_sel, T_next);
+    if (role == 0u) {
         QH_STAMP(6);
-        if (a.split) {
+        if (a.split) {                               // is the lo side being computed?  If the second arrival has not even started, the
+            if (threadIdx.x == 0) bcast[0] = __hip_atomic_load(&ws[kQHLoClaim], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // lo side stays OPEN:
+            __syncthreads();                         // the exact passes settle it (never seen outside a chip shared with other queues)
+            lo_elsewhere = bcast[0] != 0u;
+            __syncthreads();
+        }
+    }
+    if (role == 1u) {
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(&ws[kQHLoKey], key_sel[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws[kQHLoKeep], keep_sel[1] ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws[kQHLoT], T_next[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(&ws[kQHLoFlag], done_sel[1] ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (role == 0u) {
+        if (lo_elsewhere) {
             if (threadIdx.x == 0) {
                 uint32_t f;
                 while ((f = __hip_atomic_load(&ws[kQHLoFlag], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(1);
@@ -1794,9 +1866,10 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
                 bcast[0] = f;
                 bcast[1] = __hip_atomic_load(&ws[kQHLoKey], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 bcast[2] = __hip_atomic_load(&ws[kQHLoKeep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                bcast[3] = __hip_atomic_load(&ws[kQHLoT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
-            done_sel[1] = bcast[0] == 1u; key_sel[1] = bcast[1]; keep_sel[1] = bcast[2] != 0u;
+            done_sel[1] = bcast[0] == 1u; key_sel[1] = bcast[1]; keep_sel[1] = bcast[2] != 0u; T_next[1] = bcast[3];
             __syncthreads();
         }
         open_mask = (done_sel[0] ? 0u : 1u) | (done_sel[1] ? 0u : 2u);
@@ -1904,7 +1977,7 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
                 const uint32_t half = rfl(threadIdx.x >> 8), lt = threadIdx.x & 255u, wl = rfl(lt >> 6), lane = threadIdx.x & 63u;
                 const uint32_t nbins = level == 2 ? (uint32_t)kQ3 : (uint32_t)kQ1, per = nbins / 256u;          // 16 or 1 bins per thread
                 const uint32_t* Hs = level == 0 ? ws + kQHOffH0 : (level == 1 ? ws + kQHOffH1 + half * kQ2 : ws + kQHOffH2 + half * kQ3);
-                const uint32_t want = level == 0 ? kk[half] : (level == 1 ? r0k[half] : r24[half]);
+                const uint32_t want = level == 0 ? (half ? kk[1] : kk[0]) : (level == 1 ? (half ? r0k[1] : r0k[0]) : (half ? r24[1] : r24[0]));
                 // the histogram goes through LDS: 16-B loads at consecutive addresses (thread t reading its 16 bins straight from
                 // global memory is sixteen loads of 64 scattered lines each -- this stage took 6.6 us of a 20 us level)
                 {
@@ -1931,6 +2004,7 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
                     scratch[8u + half * 2u] = digit; scratch[9u + half * 2u] = rin;
                 }
                 __syncthreads();
+#pragma unroll
                 for (int w = 0; w < 2; w++) {
                     if (!(open_mask & (1u << w))) continue;
                     const uint32_t digit = scratch[8 + 2 * w], rin = scratch[9 + 2 * w];
@@ -1945,8 +2019,9 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
     if (role != 0u) return;
     // ---- role 0 writes the results and the hint (the only writer of either in this launch) ----
     uint32_t out_key[2], out_valid[2], out_T[2];
+#pragma unroll
     for (int w = 0; w < 2; w++) {
-        if (!(open_mask & (1u << w))) { out_key[w] = key_sel[w]; out_valid[w] = keep_sel[w] ? 1u : 0u; out_T[w] = T[w]; continue; }
+        if (!(open_mask & (1u << w))) { out_key[w] = key_sel[w]; out_valid[w] = keep_sel[w] ? 1u : 0u; out_T[w] = keep_sel[w] ? T_next[w] : T[w]; continue; }
         // the side went through the exact passes: leave a threshold that works (rules of F2's and F3's tails)
         const uint32_t V = (p24[w] << 8) | low[w];
         out_key[w] = V;

@@ -87,13 +87,17 @@ if single:
                 t_hi = int(rng.integers(0x80000000, 0xC2000000)); t_lo = int(rng.integers(0x3D000000, 0x7FFFFFFF))
                 h = torch.tensor([1, t_hi - (1 << 32), 1, t_lo, n, k_hi, k_lo, 0], dtype=torch.int64).to(torch.int32).to(dev)
             w = want(x, q)
-            disturb()
-            two = rng.random() < 0.3
+            if not os.environ.get('SOAK_NODISTURB'): disturb()
+            two = rng.random() < 0.3 and not os.environ.get('SOAK_NOTWO')
             if two:
                 h2 = quantile_hint(dev) if rng.random() < 0.5 else streams.setdefault((kind, n, q, 'b'), quantile_hint(dev))
                 other.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(other): o2 = CUDA.Quantile_Hinted(x, q, h2)
+            if os.environ.get('SOAK_TIMES'): torch.cuda.synchronize(); tc = time.time()
             o = CUDA.Quantile_Hinted(x, q, h)
+            if os.environ.get('SOAK_TIMES'):
+                torch.cuda.synchronize(); tc = time.time() - tc
+                if tc > 0.02: print(f'SLOW {tc * 1e3:.1f} ms: round {r} key {key} batch {b} mode {mode:.2f} two {two} hint {h.cpu().tolist()}', flush=True)
             calls += 1
             if two:
                 torch.cuda.current_stream().wait_stream(other)
