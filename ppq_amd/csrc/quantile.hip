@@ -28,7 +28,7 @@
 // The result is exact in every case; the hint only decides how much is read.  Hot path: 7 launches, 4 of them return on one load;
 // ONE small tensor with an extreme q and no hint: 5 launches -- F1 F2 F3 are one launch of one workgroup there
 // (quantile_f123_single_kernel).  ONE tensor WITH a hint (what the reference's percentile observer calls per tensor and batch
-// through install_into_ppq()): two launches, see "ONE hinted tensor" below -- 26.4 -> 10.1 us on [1,512,56,56], 0.36 -> 0.59 of
+// through install_into_ppq()): two launches, see "ONE hinted tensor" below -- 26.4 -> 10.3 us on [1,512,56,56], 0.36 -> 0.55 of
 // 8 TB/s on 32 x that (rocprofv3 medians, profiles/r06_*).
 #include <cmath>
 #include <cstdlib>
@@ -1514,25 +1514,29 @@ __device__ __forceinline__ uint32_t wave_select(const uint32_t* keys, uint32_t c
 // slot are requested together, ONE round trip; longer slots go through LDS).  The lo side runs on ~key, so that both sides read
 // "the rank-th smallest of the keys ABOVE a threshold".  One histogram round on fixed bit positions of (key - T - 1) finds the
 // 2^13-key-wide bin of the answer; the keys of that bin are few and one wavefront per side finishes on them.
-// What thread t of a selecting workgroup holds of filter workgroup t: its 64-B record and (big tensors, `heads`) the first 32 keys
-// of both its slots.  Requested BEFORE the workgroup knows whether it selects at all (see the kernel): one round trip for the
-// arrival ticket, the header and these.
+// What thread t of a selecting workgroup holds of filter workgroup t: its 64-B record.  Requested BEFORE the workgroup knows whether it
+// selects at all (see the kernel): one round trip for the arrival ticket, the header and these.  (The heads of big tensors --
+// 164 KB -- are fetched by the selecting workgroups only: requested up front they held the ticket back by 3 us.)
 struct QHRecs {
     uint4 r4[4];
-    uint4 k4[2][kQHThreadKeys / 4];
+    uint4 head[kQHThreadKeys / 4];      // split select of a big tensor: the heads of side `head_side` (2: none held)
+    uint32_t head_side;
 };
-__device__ __forceinline__ void hot_load_records(const QHot& a, QHRecs& R) {
+// `guess`: the side this workgroup will probably select (split select: the first arrival takes hi, the second lo -- in practice
+// workgroups 0 and 1); 2: no guess.  A wrong guess costs the reload inside hot_select_records, nothing else.
+__device__ __forceinline__ void hot_load_records(const QHot& a, QHRecs& R, uint32_t guess) {
     R.r4[0] = R.r4[1] = R.r4[2] = R.r4[3] = make_uint4(0u, 0u, 0u, 0u);
+    R.head_side = 2u;
     if (threadIdx.x < a.wgs) {
         const uint4* rec = reinterpret_cast<const uint4*>(a.ws + kQHOffRec) + (size_t)threadIdx.x * 4;
         R.r4[0] = rec[0]; R.r4[1] = rec[1]; R.r4[2] = rec[2]; R.r4[3] = rec[3];
-        if (a.heads) {                                                 // (the filter wrote every head in this mode)
+    }
+    if (a.heads && guess < 2u) {
+        R.head_side = guess;
+        if (threadIdx.x < a.wgs) {
+            const uint4* head = reinterpret_cast<const uint4*>(a.ws + kQHOffHeads) + ((size_t)threadIdx.x * 2 + guess) * (kQHThreadKeys / 4);
 #pragma unroll
-            for (int w = 0; w < 2; w++) {
-                const uint4* head = reinterpret_cast<const uint4*>(a.ws + kQHOffHeads) + ((size_t)threadIdx.x * 2 + w) * (kQHThreadKeys / 4);
-#pragma unroll
-                for (uint32_t i = 0; i < kQHThreadKeys / 4; i++) R.k4[w][i] = head[i];
-            }
+            for (uint32_t i = 0; i < kQHThreadKeys / 4; i++) R.head[i] = head[i];
         }
     }
 }
@@ -1541,7 +1545,21 @@ __device__ __forceinline__ void hot_select_records(const QHot& a, QHRecs& R, con
                                                    bool (&done)[2], bool (&keep)[2], uint32_t (&T_next)[2]) {
     const uint32_t n = a.n, t = threadIdx.x, lane = t & 63u;
     uint4 (&r4)[4] = R.r4;
-    uint4 (&k4)[2][kQHThreadKeys / 4] = R.k4;
+    uint4 k4[2][kQHThreadKeys / 4];
+    if (a.heads && t < a.wgs) {                                        // big tensors: the filter wrote every head; this workgroup's sides only
+#pragma unroll
+        for (int w = 0; w < 2; w++) {
+            if (!(sides & (1u << w))) continue;
+            if (R.head_side == (uint32_t)w) {                          // (block uniform) requested with the ticket
+#pragma unroll
+                for (uint32_t i = 0; i < kQHThreadKeys / 4; i++) k4[w][i] = R.head[i];
+                continue;
+            }
+            const uint4* head = reinterpret_cast<const uint4*>(a.ws + kQHOffHeads) + ((size_t)t * 2 + w) * (kQHThreadKeys / 4);
+#pragma unroll
+            for (uint32_t i = 0; i < kQHThreadKeys / 4; i++) k4[w][i] = head[i];
+        }
+    }
     if (t < 2) { L.total[t] = 0u; L.tie[t] = 0u; L.nsurv[t] = 0u; L.nbig[t] = 0u; L.nbigdesc[t] = 0u; L.flags = 0u; }
     {
         uint4* z = reinterpret_cast<uint4*>(&L.hist[0][0]);           // (2 x 2112 words = 1056 uint4)
@@ -1695,10 +1713,10 @@ __device__ __forceinline__ void hot_select_records(const QHot& a, QHRecs& R, con
         uint32_t Tpn = Tp[w];
         if (total[w] > target[w]) Tpn = Tp[w] + (L.bin_up[w] << kQHDigitShift);         // exact: the hist says how many keys lie above
         else if (total[w] < target[w]) {                                   // extrapolated from the density of the lowest quarter of the list
-            const unsigned long long span = ((unsigned long long)L.bin_q[w] + 1ull) << kQHDigitShift;
-            unsigned long long delta = (unsigned long long)(target[w] - total[w]) * span * 4ull / (unsigned long long)umax(total[w], 1u);
-            if (delta > 8ull * span) delta = 8ull * span;
-            Tpn = (unsigned long long)Tp[w] > delta ? Tp[w] - (uint32_t)delta : 0u;
+            const float span = (float)((L.bin_q[w] + 1u) << kQHDigitShift);                 // (< 2^22: exact; the rest is an estimate anyway)
+            const float want_more = (float)(target[w] - total[w]) * span * 4.f / (float)umax(total[w], 1u);
+            const uint32_t delta = (uint32_t)fminf(want_more, 8.f * span);
+            Tpn = Tp[w] > delta ? Tp[w] - delta : 0u;
         }
         T_next[w] = w ? ~Tpn : Tpn;
     }
@@ -1814,12 +1832,12 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
     if (threadIdx.x == 0) bcast[0] = __hip_atomic_fetch_add(&ws[kQHRoleTicket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     QHRecs R;
     const bool speculated = blockIdx.x < kQHSpeculators;
-    if (speculated) hot_load_records(a, R);
+    if (speculated) hot_load_records(a, R, (a.split && blockIdx.x < 2u) ? blockIdx.x : 2u);
     __syncthreads();
     const uint32_t arrival = bcast[0];
     __syncthreads();
     const uint32_t role = arrival == 0u ? 0u : ((a.split && arrival == 1u) ? 1u : 0xFFFFFFFFu);
-    if (role < 2u && !speculated) hot_load_records(a, R);
+    if (role < 2u && !speculated) hot_load_records(a, R, 2u);
     const bool enabled = hdr.x != 0u;
     const uint32_t T[2] = {hdr.y, hdr.z};
     uint32_t key_sel[2] = {T[0], T[1]};
