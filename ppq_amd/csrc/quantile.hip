@@ -32,6 +32,8 @@
 // 8 TB/s on 32 x that (rocprofv3 medians, profiles/r06_*).
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_set>
 #include "common.hpp"
 
 namespace ppqhip {
@@ -2095,6 +2097,19 @@ static bool quantile_hot_enabled() {
 #endif
     return true;
 }
+// A hint this process hands over for the first time is almost always a fresh one (an observer's first batch), and the two-launch
+// path has only its exact passes for a tensor without usable thresholds: three reads behind LDS histograms, 73 us on B / 221 us on
+// B x 32 where the general sequence -- sample, thresholds, filter, select -- takes 35 / 73 us and leaves the same kind of hint
+// behind.  So the first call on a hint ADDRESS goes through the sequence; every later one through the two launches.  The memo only
+// ever chooses between two exact paths: an address met again after its tensor was freed and zeroed costs one call of exact passes,
+// a valid hint met for the first time (written by the multi-tensor entry point) costs one call of the sequence from its hint.
+static bool quantile_hint_met_before(const uint32_t* hint) {
+    static std::mutex lock;
+    static std::unordered_set<const void*> met;
+    std::lock_guard<std::mutex> guard(lock);
+    if (met.size() > (1u << 16)) met.clear();
+    return !met.insert((const void*)hint).second;
+}
 static void quantile_hot_launch(const QHot& a0, hipStream_t s) {
     QHot a = a0;
     const uint32_t full_rows = (a.n >> 2) / kQHBlock;
@@ -2227,7 +2242,7 @@ int ppqhip_quantile_t(const float* x, int64_t n, float q, float* dest, uint32_t*
         QHot a;
         a.x = x; a.dest = dest; a.hint = hint; a.ws = (uint32_t*)workspace; a.n = (uint32_t)n;
         a.k_hi = quantile_pos(n, q); a.k_lo = quantile_pos(n, 1 - q); a.wgs = 0; a.split = 0; a.heads = 0; a.pad0 = a.pad1 = 0;
-        if (a.n - a.k_hi <= kQHWantedMax && a.k_lo + 1u <= kQHWantedMax) {
+        if (a.n - a.k_hi <= kQHWantedMax && a.k_lo + 1u <= kQHWantedMax && quantile_hint_met_before(hint)) {
             quantile_hot_launch(a, s);
             return finish_launch("quantile_t");
         }
