@@ -52,6 +52,7 @@ median duration from a clean `rocprofv3 --kernel-trace` child pass of this comma
 import argparse
 import csv
 import glob
+import gc
 import json
 import os
 import shutil
@@ -495,6 +496,7 @@ def inprocess_variants(dev, args):
             times = []
             for _ in range(5):          # (five: on shared hosts one pass in three or four runs 1.5-2x slow -- r06 run 2: 2904, 1657, 1660 samples/s)
                 del graph, ex
+                gc.collect()            # the pass objects hold reference cycles: uncollected, the next pass's 600 MB of histogram rows are NEW device allocations
                 graph, ex = fresh()
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 run_pass(graph, ex, bs, steps, method, False, False, True)
