@@ -62,7 +62,39 @@ import sys
 import tempfile
 import time
 
-import torch
+
+
+def host_cpus() -> int:
+    """CPUs this process can really keep busy: its affinity mask cut by the container's CPU quota (cgroup v2 cpu.max, v1
+    cfs_quota_us).  The GPU boxes of this pool show 256 CPUs and grant 16: a default-sized thread pool (128 OpenMP threads spinning
+    behind every parallel region) spends the quota in a few milliseconds and the kernel then parks EVERY thread of the container --
+    the one that launches kernels too -- until the next 100 ms period: whole timed passes came out 75-85 ms long (one in five)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f: quota, period = f.read().split()[:2]
+        if quota != 'max': n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f: quota = int(f.read())
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as f: period = int(f.read())
+            if quota > 0: n = min(n, max(1, quota // period))
+        except (OSError, ValueError): pass
+    return max(1, n)
+
+
+def cgroup_cpu_stat() -> dict:
+    """usage_usec / nr_throttled / throttled_usec of this container (cgroup v2), {} where there is no such file."""
+    try:
+        with open('/sys/fs/cgroup/cpu.stat') as f: return {k: int(v) for k, v in (line.split() for line in f)}
+    except (OSError, ValueError): return {}
+
+
+HOST_CPUS = host_cpus()
+for _var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):      # before torch / numpy build their pools
+    os.environ.setdefault(_var, str(HOST_CPUS))
+os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')                             # idle workers sleep instead of spinning the quota away
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -78,7 +110,7 @@ def maybe_spawn(args) -> None:
         sock.bind(('127.0.0.1', 0)); port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL / cross-process sharing needs it here
-    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    env['OMP_NUM_THREADS'] = str(max(1, HOST_CPUS // args.gpus))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.exit(subprocess.call(cmd, env=env))
@@ -781,6 +813,7 @@ def main():
     # timed region(s): `repeats` independent passes of exactly K steps each
     global TRACE_STEPS
     times, trace, p, graph = [], None, None, None
+    host_passes = []          # per timed pass: how long the container was parked by its CPU quota, how many CPUs it kept busy
     repeats = 1 if (args.trace_steps or args.pmc_child or args.kt_child) else max(1, args.repeats)
     for rep in range(repeats):
         if args.trace_steps:
@@ -789,12 +822,17 @@ def main():
         del p, graph
         graph, ex = build_workload(dev, args.bins, args.method, args.cache_params, args.fuse_params, bool(args.channels_last))
         barrier(world)
+        cg0 = cgroup_cpu_stat()
         t0 = time.perf_counter()
         if args.trace_steps: ev0.record()
         p = run_pass(graph, ex, batches, args.steps, args.method, bool(args.async_observe), hip_graph,
                      bool(args.batch_observations), bool(args.reuse_activations), (args.queue_mib << 20) or None)
         barrier(world)
         elapsed = time.perf_counter() - t0
+        cg1 = cgroup_cpu_stat()
+        if cg0 and cg1:
+            host_passes.append({'throttled_ms': round((cg1.get('throttled_usec', 0) - cg0.get('throttled_usec', 0)) / 1e3, 1),
+                                'cpus_busy': round((cg1.get('usage_usec', 0) - cg0.get('usage_usec', 0)) / 1e6 / max(elapsed, 1e-9), 1)})
         if args.trace_steps:
             trace = [{'host_ms': round((t - t0) * 1e3, 2), 'dev_ms': round(ev0.elapsed_time(e), 2)} if not isinstance(e, float)
                      else {'render_start_ms': round((t - t0) * 1e3, 2), 'render_ms': round((e - t) * 1e3, 2)} for t, e in TRACE_STEPS]
@@ -960,6 +998,11 @@ def main():
             'dtype': 'f32' if WORKLOAD != 'vit_b16_fp8' else 'f32 (FP8 E4M3 simulated)', 'data': 'synthetic',
             'repeats': len(times), 'values': [round(samples / t, 2) for t in times],
             'spread_pct': round(100.0 * (max(times) - min(times)) / elapsed, 2),
+            # the host side of the timed passes: CPUs the container may use (affinity cut by its cgroup quota), the thread pools sized
+            # to that, and per pass how long the kernel parked the container for exceeding the quota -- a pass with tens of ms here
+            # is a host artefact (value = the median pass)
+            'host': {'cpus_visible': os.cpu_count(), 'cpus_granted': HOST_CPUS, 'torch_threads': torch.get_num_threads(),
+                     'passes': host_passes},
             'config': {'workload': (f'ResNet-50 topology (53 Conv + 1 Gemm, BN folded, seeded He init), '
                                     f'RuntimeCalibrationPass {args.method} {args.bins} bins, per-tensor INT8 activations, '
                                     f'per-channel INT8 weights, {args.steps} batches x {args.batch} x 3x224x224 per GPU'

@@ -8,6 +8,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _host_cpus() -> int:
+    """CPUs the container grants (affinity cut by the cgroup quota; bench.py: host_cpus has the story): thread pools sized to the
+    256 CPUs a GPU box SHOWS spend its 16-CPU quota spinning and the kernel parks the whole suite for the rest of each 100 ms."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f: quota, period = f.read().split()[:2]
+        if quota != 'max': n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError): pass
+    return max(1, n)
+
+
+for _var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):      # before torch / numpy build their pools
+    os.environ.setdefault(_var, str(_host_cpus()))
+os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run through gpurun / at round end)')
     # a fresh checkout has no built artefacts (they are git-ignored): build the HIP library and the
