@@ -240,7 +240,8 @@ int ppqhip_hist_asym_c_ranges(const float* x, int64_t n, int64_t num_channel, in
  * stream of similar tensors (an observer: the same activation, batch after batch).  The library keeps the
  * thresholds that worked in it, and the next call with the same n and q skips the sampling launch that
  * otherwise estimates them (words: [0] hi valid, [1] T_hi key, [2] lo valid, [3] T_lo key, [4] n, [5] k_hi,
- * [6] k_lo, [7] calls settled from the hint).  A stale or foreign hint costs time, never correctness -- but the words belong
+ * [6] k_lo, [7] calls settled from the hint; a valid word is 1 in its low byte -- bits 8-9 hold how long a list the side's next
+ * threshold is aimed at, raised when a batch used the list up, see quantile.hip: qh_target).  A stale or foreign hint costs time, never correctness -- but the words belong
  * to the call until `stream` has passed it: its launches read and write them, so nothing else may touch them meanwhile.
  * One tensor WITH a hint (16-B aligned, n >= 2^18, at most 8192 wanted keys per side) takes two launches: a filter that
  * leaves every workgroup's keys in its own record, and a select that settles both sides from the records or -- no usable

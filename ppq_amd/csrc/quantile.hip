@@ -201,7 +201,8 @@ __device__ __forceinline__ bool aligned16_dev(const void* p) { return (reinterpr
 
 __device__ __forceinline__ bool hint_valid(const uint32_t* __restrict__ hint, uint32_t n, uint32_t k_hi, uint32_t k_lo) {
     if (hint == nullptr) return false;
-    return hint[kHValidHi] == 1u && hint[kHValidLo] == 1u && hint[kHN] == n && hint[kHKHi] == k_hi && hint[kHKLo] == k_lo;
+    // (the valid words' low byte: the two-launch path of one tensor keeps its list-length level in bits 8-9, see qh_target)
+    return (hint[kHValidHi] & 0xFFu) == 1u && (hint[kHValidLo] & 0xFFu) == 1u && hint[kHN] == n && hint[kHKHi] == k_hi && hint[kHKLo] == k_lo;
 }
 
 // ---- block-wide helpers (THREADS = blockDim.x, a multiple of 64) --------------------------------------------------
@@ -1291,6 +1292,22 @@ constexpr uint32_t kQHMaxWg = 512;                  // filter grid limit (record
 constexpr uint32_t kQHListMax = 16384;              // longest list a hint may keep producing
 constexpr uint32_t kQHSpeculators = 16;              // workgroups of the select launch that request the records before they know their role
 constexpr uint32_t kQHWantedMax = 8192;             // the host routes here only when both wanted counts are at most this
+constexpr uint32_t kQHThreadKeys = 32;              // keys of one filter workgroup and side a thread of the select holds in registers
+// How long a list the NEXT call's threshold is aimed at.  The wanted keys sit 3.7 sigma out (q = 0.9999): the number of keys beyond a
+// FIXED threshold moves with the 14th power of the activation's scale, so a list of 1.5 x the wanted keys -- the shortest, fastest
+// choice: six keys per filter workgroup, inline in the records -- is used up by a batch whose scale is 3 % smaller, and the call then
+// pays the exact passes (tools/quantile_drift.py: 5 % jitter between batches -> one call in three, 31 us per call instead of 10.7).
+// Each side of the hint therefore carries a LEVEL 0..3 (bits 8-9 of its valid word): level 0 aims at 1.5 x wanted, level 3 at the
+// geometric middle of [wanted, what the select holds in registers] (as much room below as above), 1 and 2 in between.  A call the
+// hint could not settle raises the side to level 3, a list that came within a quarter of failing raises it by one, and every 64th
+// settled call lowers it by one: a stationary stream works with the short lists, a restless one with the long ones.
+__device__ __forceinline__ uint32_t qh_target(uint32_t wanted, uint32_t wgs, uint32_t level) {
+    const uint32_t least = wanted + (wanted >> 1);
+    const uint32_t room = umin(kQHThreadKeys * wgs, kQHListMax);
+    const uint32_t middle = (uint32_t)sqrtf((float)room * (float)wanted);
+    const uint32_t most = umax(least, umin(middle, room / 2u));
+    return least + (most - least) * umin(level, 3u) / 3u + 32u;
+}
 // workspace layout (uint32 words)
 enum { kQHEnabled = 0, kQHTHi = 1, kQHTLo = 2, kQHUses = 3,      // written by the filter's workgroup 0 (uses: hint word 7 as it found it)
        kQHZero0 = 4,                                // first word the filter zeroes
@@ -1338,12 +1355,13 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_filter_kernel(const QHo
     // the hint: ONE scalar load of its eight words (a short-circuit && chain compiles to five dependent round trips)
     const uint32_t* __restrict__ H = a.hint;
     const uint32_t h0 = H[kHValidHi], t_hi = H[kHTHi], h2 = H[kHValidLo], t_lo = H[kHTLo], h4 = H[kHN], h5 = H[kHKHi], h6 = H[kHKLo], h7 = H[kHUses];
-    const bool enabled = ((h0 == 1u) & (h2 == 1u) & (h4 == n) & (h5 == a.k_hi) & (h6 == a.k_lo) & (t_lo <= t_hi)) != 0;   // the same in every workgroup
+    const bool enabled = (((h0 & 0xFFu) == 1u) & ((h2 & 0xFFu) == 1u) & (h4 == n) & (h5 == a.k_hi) & (h6 == a.k_lo) & (t_lo <= t_hi)) != 0;   // the same in every workgroup
     if (threadIdx.x < 2) { staged_n[threadIdx.x] = 0; ties[threadIdx.x] = 0; }
     {   // the state of the launch behind this one: flags, barrier counter, exact histograms (zeroed whether needed or not)
         constexpr uint32_t words = kQHZeroEnd - kQHZero0;
         for (uint32_t i = g * kQHBlock + threadIdx.x; i < words; i += G * kQHBlock) a.ws[kQHZero0 + i] = 0u;
-        if (g == 0 && threadIdx.x == 0) *reinterpret_cast<uint4*>(a.ws) = make_uint4(enabled ? 1u : 0u, t_hi, t_lo, h7);
+        // (word 0: enabled | the sides' list-length levels, qh_target)
+        if (g == 0 && threadIdx.x == 0) *reinterpret_cast<uint4*>(a.ws) = make_uint4(enabled ? (1u | (h0 & 0x300u) | ((h2 & 0x300u) << 8)) : 0u, t_hi, t_lo, h7);
     }
     if (!enabled) return;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // LDS counters are zero; the loads stay in flight
@@ -1427,7 +1445,6 @@ constexpr uint32_t kQHBins = 2048;                  // the select's one histogra
 constexpr int kQHDigitShift = 11;                   // .. of (key - T - 1) >> 11, saturating: bins of 2^-12 relative width over the half binade above T
                                                     // (the answer is the wanted-th largest of ~1.5 x wanted keys: it lies in the dense third next to T)
 constexpr uint32_t kQHSurvCap = 2048;               // keys of the chosen bin ("survivors") a wavefront finishes on
-constexpr uint32_t kQHThreadKeys = 32;              // keys of a slot its own thread keeps in registers (8 16-B loads)
 constexpr uint32_t kQHBigCap = 8192;                // LDS room per side for the keys of slots longer than that
 constexpr uint32_t kQHWaveKeys = kQHSurvCap;
 struct QHSelLds {
@@ -1543,8 +1560,9 @@ __device__ __forceinline__ void hot_load_records(const QHot& a, QHRecs& R, uint3
     }
 }
 
+// keep[w]: the side's valid word for the hint -- 0: drop it, else 1 | level << 8 (qh_target); level[w] / uses: as the filter found them
 __device__ __forceinline__ void hot_select_records(const QHot& a, QHRecs& R, const uint32_t (&T)[2], const uint32_t sides, QHSelLds& L, uint32_t (&key_out)[2],
-                                                   bool (&done)[2], bool (&keep)[2], uint32_t (&T_next)[2]) {
+                                                   bool (&done)[2], uint32_t (&keep)[2], uint32_t (&T_next)[2], const uint32_t (&level)[2], const uint32_t uses) {
     const uint32_t n = a.n, t = threadIdx.x, lane = t & 63u;
     uint4 (&r4)[4] = R.r4;
     uint4 k4[2][kQHThreadKeys / 4];
@@ -1660,17 +1678,22 @@ __device__ __forceinline__ void hot_select_records(const QHot& a, QHRecs& R, con
         wanted[w] = w ? k + 1u : n - k;
         // hi: the (k - (n - total))-th smallest listed key; lo: the k-th smallest = the (total - 1 - k)-th smallest of the ~keys
         rank[w] = w ? total[w] - 1u - k : k - (n - total[w]);
-        done[w] = false; keep[w] = false; key_out[w] = T[w]; how[w] = 0;
+        done[w] = false; keep[w] = 0u; key_out[w] = T[w]; how[w] = 0;
         if ((flags & (1u << w)) || !(sides & (1u << w))) continue;
         if (total[w] >= wanted[w]) {
             // settled by the list.  The hint is KEPT and its threshold re-centred on this batch (below): select A's rule -- drop a hint
-            // whose list came out nearly too short or needlessly long -- costs three exact passes on the next batch here
-            how[w] = 2; done[w] = true; keep[w] = total[w] <= kQHListMax;
-        } else if (wanted[w] - total[w] <= L.tie[w]) { how[w] = 1; done[w] = true; keep[w] = true; }     // the tie value itself
+            // whose list came out nearly too short or needlessly long -- costs three exact passes on the next batch here.  The level
+            // goes up when the list came within a quarter of failing, down on every 64th settled call.
+            how[w] = 2; done[w] = true;
+            uint32_t lv = level[w];
+            if (total[w] - wanted[w] < (wanted[w] >> 2)) lv = umin(lv + 1u, 3u);
+            else if ((uses & 63u) == 63u && lv > 0u) lv -= 1u;
+            keep[w] = 1u | (lv << 8);
+        } else if (wanted[w] - total[w] <= L.tie[w]) { how[w] = 1; done[w] = true; keep[w] = 1u | (level[w] << 8); }     // the tie value itself
     }
     uint32_t target[2];
 #pragma unroll
-    for (int w = 0; w < 2; w++) target[w] = wanted[w] + (wanted[w] >> 1) + 32u;                          // keys the NEXT list should hold
+    for (int w = 0; w < 2; w++) target[w] = qh_target(wanted[w], a.wgs, keep[w] >> 8);                  // keys the NEXT list should hold
     if (t < 2) { L.bin_up[t] = 0u; L.bin_q[t] = 0u; }
     {   // the bin of the rank: half h of the workgroup scans side h (thread lt owns bins [8 lt, 8 lt + 8))
         const uint32_t half = rfl(t >> 8), lt = t & 255u, wl = rfl(lt >> 6);
@@ -1711,7 +1734,7 @@ __device__ __forceinline__ void hot_select_records(const QHot& a, QHRecs& R, con
 #pragma unroll
     for (int w = 0; w < 2; w++) {                                       // next call's thresholds (on the key' axis, then back)
         T_next[w] = T[w];
-        if (how[w] != 2 || !keep[w]) continue;
+        if (how[w] != 2) continue;
         uint32_t Tpn = Tp[w];
         if (total[w] > target[w]) Tpn = Tp[w] + (L.bin_up[w] << kQHDigitShift);         // exact: the hist says how many keys lie above
         else if (total[w] < target[w]) {                                   // extrapolated from the density of the lowest quarter of the list
@@ -1767,7 +1790,7 @@ __device__ __forceinline__ void hot_select_records(const QHot& a, QHRecs& R, con
         if (how[w] != 2) continue;
         const uint32_t ns = L.nsurv[w];
         if (ns >= 1u && ns <= kQHSurvCap) key_out[w] = L.result[w];
-        else { done[w] = false; keep[w] = false; }                     // a bin too crowded for one wavefront (ties, saturation): exact passes
+        else { done[w] = false; keep[w] = 0u; }                        // a bin too crowded for one wavefront (ties, saturation): exact passes
     }
 }
 
@@ -1843,7 +1866,9 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
     const bool enabled = hdr.x != 0u;
     const uint32_t T[2] = {hdr.y, hdr.z};
     uint32_t key_sel[2] = {T[0], T[1]};
-    bool done_sel[2] = {false, false}, keep_sel[2] = {false, false};
+    bool done_sel[2] = {false, false};
+    uint32_t keep_sel[2] = {0u, 0u};                                 // the sides' valid words for the hint (0: drop; 1 | level << 8)
+    const uint32_t level[2] = {(hdr.x >> 8) & 3u, (hdr.x >> 16) & 3u};
     uint32_t T_next[2] = {T[0], T[1]};
     // ---- the decision: the selecting workgroup publishes, everybody else polls ----
     uint32_t open_mask;
@@ -1858,7 +1883,7 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
         QH_STAMP(1);
     }
     // ONE call site for both roles (the function is a few thousand instructions, inlined: a second copy costs registers and scratch)
-    if (role < 2u && enabled) hot_select_records(a, R, T, role == 1u ? 2u : (a.split ? 1u : 3u), L.s, key_sel, done_sel, keep_sel, T_next);
+    if (role < 2u && enabled) hot_select_records(a, R, T, role == 1u ? 2u : (a.split ? 1u : 3u), L.s, key_sel, done_sel, keep_sel, T_next, level, hdr.w);
     if (role == 0u) {
         QH_STAMP(6);
         if (a.split) {                               // is the lo side being computed?  If the second arrival has not even started, the
@@ -1871,7 +1896,7 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
     if (role == 1u) {
         if (threadIdx.x == 0) {
             __hip_atomic_store(&ws[kQHLoKey], key_sel[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ws[kQHLoKeep], keep_sel[1] ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ws[kQHLoKeep], keep_sel[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&ws[kQHLoT], T_next[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __hip_atomic_store(&ws[kQHLoFlag], done_sel[1] ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1889,7 +1914,7 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
                 bcast[3] = __hip_atomic_load(&ws[kQHLoT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
-            done_sel[1] = bcast[0] == 1u; key_sel[1] = bcast[1]; keep_sel[1] = bcast[2] != 0u; T_next[1] = bcast[3];
+            done_sel[1] = bcast[0] == 1u; key_sel[1] = bcast[1]; keep_sel[1] = bcast[2]; T_next[1] = bcast[3];
             __syncthreads();
         }
         open_mask = (done_sel[0] ? 0u : 1u) | (done_sel[1] ? 0u : 2u);
@@ -2041,7 +2066,7 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
     uint32_t out_key[2], out_valid[2], out_T[2];
 #pragma unroll
     for (int w = 0; w < 2; w++) {
-        if (!(open_mask & (1u << w))) { out_key[w] = key_sel[w]; out_valid[w] = keep_sel[w] ? 1u : 0u; out_T[w] = keep_sel[w] ? T_next[w] : T[w]; continue; }
+        if (!(open_mask & (1u << w))) { out_key[w] = key_sel[w]; out_valid[w] = keep_sel[w]; out_T[w] = keep_sel[w] ? T_next[w] : T[w]; continue; }
         // the side went through the exact passes: leave a threshold that works (rules of F2's and F3's tails)
         const uint32_t V = (p24[w] << 8) | low[w];
         out_key[w] = V;
@@ -2049,7 +2074,9 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
         const uint32_t inb = ws[kQHOffH0 + top[w]];
         const uint32_t outer = w ? k - r0k[w] : n - (k - r0k[w]) - inb;
         const uint32_t wanted = w ? k + 1u : n - k;
-        const uint32_t target = wanted + (wanted >> 1) + 32u;
+        // a hint that was in use and did not settle this side: the stream is restless, the longest lists from here on (qh_target)
+        const uint32_t lv = enabled ? 3u : 0u;
+        const uint32_t target = qh_target(wanted, a.wgs, lv);
         const uint32_t limit = umin(q_list_limit(wanted, quantile_spec_cap(n)), kQHListMax);
         const uint32_t need_in = target > outer ? target - outer : 1u;
         const uint32_t r = w ? umin(inb, need_in) - 1u : (inb > need_in ? inb - need_in : 0u);
@@ -2060,9 +2087,22 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
         if (w) { listed = outer + (r - sel[1]) + ws[kQHOffH1 + kQ2 + m]; ok = q24 < 0xFFFFFFu; Tn = (q24 + 1u) << 8; }
         else { listed = outer + inb - (r - sel[1]); ok = q24 > 0u; Tn = (q24 << 8) - 1u; }
         ok = ok && listed <= limit;
+        if (need_in > inb) {
+            // the bucket of the answer (1/8 of a binade) does not hold the list this level asks for: whole first-level buckets beyond
+            // it, as many as it takes (coarse -- a bucket can double the list -- and exact again after the next settled call)
+            uint32_t cum = outer + inb, b = top[w];
+            for (int step = 0; step < 16 && cum < target; step++) {
+                if (w ? b >= 0xFFEu : b <= 1u) break;
+                b = w ? b + 1u : b - 1u;
+                cum += ws[kQHOffH0 + b];
+            }
+            // (never a list the select could not hold even if it were spread evenly: the same data would fail again, and again)
+            const uint32_t room = umin(kQHThreadKeys * a.wgs, kQHListMax);
+            if (b != top[w] && cum <= umin(limit, room - room / 4u)) { listed = cum; ok = true; Tn = w ? (b + 1u) << 20 : (b << 20) - 1u; }
+        }
         const uint32_t mult = ws[kQHOffH2 + w * kQ3 + low[w]];
         if (mult / 16u >= wanted + 16u) { Tn = V; ok = true; }          // a heavy tie: the threshold ON the value (1 key in 8 is counted)
-        out_valid[w] = ok ? 1u : 0u; out_T[w] = Tn;
+        out_valid[w] = ok ? (1u | (lv << 8)) : 0u; out_T[w] = Tn;
         __syncthreads();
     }
     if (threadIdx.x == 0) {
