@@ -33,6 +33,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <unordered_set>
 #include "common.hpp"
 
@@ -1289,10 +1290,12 @@ constexpr int kQHBlock = 512;                       // both kernels
 constexpr uint32_t kQHStage = 2048;                 // keys a workgroup can stage per side (== its slot)
 constexpr uint32_t kQHInline = 6;                   // keys per side inside the record
 constexpr uint32_t kQHMaxWg = 512;                  // filter grid limit (records, slots)
-constexpr uint32_t kQHListMax = 16384;              // longest list a hint may keep producing
+constexpr uint32_t kQHListMax = 65536;              // longest list a hint may keep producing
 constexpr uint32_t kQHSpeculators = 16;              // workgroups of the select launch that request the records before they know their role
 constexpr uint32_t kQHWantedMax = 8192;             // the host routes here only when both wanted counts are at most this
 constexpr uint32_t kQHThreadKeys = 32;              // keys of one filter workgroup and side a thread of the select holds in registers
+constexpr uint32_t kQHThreadMore = 256;             // .. and up to this many it sweeps straight from the workgroup's slot (longer slots: through LDS)
+constexpr uint32_t kQHRoomPerWg = 128;              // keys per filter workgroup and side the thresholds may count on (half of that: slots are uneven)
 // How long a list the NEXT call's threshold is aimed at.  The wanted keys sit 3.7 sigma out (q = 0.9999): the number of keys beyond a
 // FIXED threshold moves with the 14th power of the activation's scale, so a list of 1.5 x the wanted keys -- the shortest, fastest
 // choice: six keys per filter workgroup, inline in the records -- is used up by a batch whose scale is 3 % smaller, and the call then
@@ -1303,7 +1306,7 @@ constexpr uint32_t kQHThreadKeys = 32;              // keys of one filter workgr
 // settled call lowers it by one: a stationary stream works with the short lists, a restless one with the long ones.
 __device__ __forceinline__ uint32_t qh_target(uint32_t wanted, uint32_t wgs, uint32_t level) {
     const uint32_t least = wanted + (wanted >> 1);
-    const uint32_t room = umin(kQHThreadKeys * wgs, kQHListMax);
+    const uint32_t room = umin(kQHRoomPerWg * wgs, kQHListMax);
     const uint32_t middle = (uint32_t)sqrtf((float)room * (float)wanted);
     const uint32_t most = umax(least, umin(middle, room / 2u));
     return least + (most - least) * umin(level, 3u) / 3u + 32u;
@@ -1611,7 +1614,7 @@ __device__ __forceinline__ void hot_select_records(const QHot& a, QHRecs& R, con
         const uint32_t wc = wave_scan_add(c[w]), wt = wave_scan_add(tie[w]);
         if (lane == 63u) { if (wc) atomicAdd(&L.total[w], wc); if (wt) atomicAdd(&L.tie[w], wt); }
         if (cnt[w] > kQHStage) atomicOr(&L.flags, 1u << w);                              // the workgroup could not stage all its keys
-        if (c[w] > kQHThreadKeys) {
+        if (c[w] > kQHThreadMore) {
             const uint32_t base = atomicAdd(&L.nbig[w], c[w]);
             if (base + c[w] <= kQHBigCap) {
                 const uint32_t at = atomicAdd(&L.nbigdesc[w], 1u);
@@ -1634,12 +1637,33 @@ __device__ __forceinline__ void hot_select_records(const QHot& a, QHRecs& R, con
             }
         }
     };
+    // a slot of 33 .. kQHThreadMore keys: its thread sweeps it straight from the workspace, sixteen keys per trip (every lane its own
+    // lines, L2-resident: a restless stream's lists -- qh_target -- are a few dozen keys per filter workgroup, not six)
+    auto for_slot_keys = [&](int w, auto f) __attribute__((always_inline)) {
+        const uint32_t cw = (c[w] > kQHThreadKeys && c[w] <= kQHThreadMore) ? c[w] : 0u;
+        const uint32_t cmax = wave_all_max(cw);
+        if (cmax == 0u) return;
+        const uint32_t flip = w ? 0xFFFFFFFFu : 0u;
+        const uint4* slot = reinterpret_cast<const uint4*>(a.ws + kQHOffSlots + ((size_t)t * 2 + w) * kQHStage);
+#pragma nounroll
+        for (uint32_t i = 0; 4u * i < cmax; i += 4u) {                    // (scalar trip count; the slot is kQHStage keys long: no clamp needed)
+            const uint4 q0 = slot[i], q1 = slot[i + 1u], q2 = slot[i + 2u], q3 = slot[i + 3u];
+            const uint32_t at = 4u * i;
+            f(q0.x ^ flip, at + 0u < cw); f(q0.y ^ flip, at + 1u < cw); f(q0.z ^ flip, at + 2u < cw); f(q0.w ^ flip, at + 3u < cw);
+            f(q1.x ^ flip, at + 4u < cw); f(q1.y ^ flip, at + 5u < cw); f(q1.z ^ flip, at + 6u < cw); f(q1.w ^ flip, at + 7u < cw);
+            f(q2.x ^ flip, at + 8u < cw); f(q2.y ^ flip, at + 9u < cw); f(q2.z ^ flip, at + 10u < cw); f(q2.w ^ flip, at + 11u < cw);
+            f(q3.x ^ flip, at + 12u < cw); f(q3.y ^ flip, at + 13u < cw); f(q3.z ^ flip, at + 14u < cw); f(q3.w ^ flip, at + 15u < cw);
+        }
+    };
     auto digit_of = [&](int w, uint32_t kp) { return umin((kp - Tp[w] - 1u) >> kQHDigitShift, kQHBins - 1u); };
     const uint32_t trash = kQHBins + lane;
     // the histogram round does not wait for the totals (whether a side selects at all is decided behind the next barrier)
 #pragma unroll
     for (int w = 0; w < 2; w++)
-        if (sides & (1u << w)) for_my_keys(w, [&](uint32_t kp, bool valid) { atomicAdd(&L.hist[w][valid ? digit_of(w, kp) : trash], 1u); });
+        if (sides & (1u << w)) {
+            for_my_keys(w, [&](uint32_t kp, bool valid) { atomicAdd(&L.hist[w][valid ? digit_of(w, kp) : trash], 1u); });
+            for_slot_keys(w, [&](uint32_t kp, bool valid) { atomicAdd(&L.hist[w][valid ? digit_of(w, kp) : trash], 1u); });
+        }
     __syncthreads();
     QH_STAMP(9);
     uint32_t nbigkeys[2] = {0u, 0u};
@@ -1771,6 +1795,7 @@ __device__ __forceinline__ void hot_select_records(const QHot& a, QHRecs& R, con
                 }
             }
         }
+        for_slot_keys(w, [&](uint32_t kp, bool valid) { if (valid && kp - lo <= width) take(kp); });
         for (uint32_t i = t; i < nbigkeys[w]; i += kQHBlock) { const uint32_t kp = L.big[w][i] ^ (w ? 0xFFFFFFFFu : 0u); if (kp - lo <= width) take(kp); }
     }
     __syncthreads();
@@ -2064,9 +2089,11 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
     if (role != 0u) return;
     // ---- role 0 writes the results and the hint (the only writer of either in this launch) ----
     uint32_t out_key[2], out_valid[2], out_T[2];
-#pragma unroll
-    for (int w = 0; w < 2; w++) {
-        if (!(open_mask & (1u << w))) { out_key[w] = key_sel[w]; out_valid[w] = keep_sel[w]; out_T[w] = keep_sel[w] ? T_next[w] : T[w]; continue; }
+    // (one body, instantiated per side: as a loop the compiler stopped unrolling it once the select grew, and every array indexed by
+    //  the side -- thresholds, keys, valid words -- moved to scratch)
+    auto side_out = [&](auto W) __attribute__((always_inline)) {
+        constexpr int w = decltype(W)::value;
+        if (!(open_mask & (1u << w))) { out_key[w] = key_sel[w]; out_valid[w] = keep_sel[w]; out_T[w] = keep_sel[w] ? T_next[w] : T[w]; return; }
         // the side went through the exact passes: leave a threshold that works (rules of F2's and F3's tails)
         const uint32_t V = (p24[w] << 8) | low[w];
         out_key[w] = V;
@@ -2097,14 +2124,16 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
                 cum += ws[kQHOffH0 + b];
             }
             // (never a list the select could not hold even if it were spread evenly: the same data would fail again, and again)
-            const uint32_t room = umin(kQHThreadKeys * a.wgs, kQHListMax);
+            const uint32_t room = umin(kQHRoomPerWg * a.wgs, kQHListMax);
             if (b != top[w] && cum <= umin(limit, room - room / 4u)) { listed = cum; ok = true; Tn = w ? (b + 1u) << 20 : (b << 20) - 1u; }
         }
         const uint32_t mult = ws[kQHOffH2 + w * kQ3 + low[w]];
         if (mult / 16u >= wanted + 16u) { Tn = V; ok = true; }          // a heavy tie: the threshold ON the value (1 key in 8 is counted)
         out_valid[w] = ok ? (1u | (lv << 8)) : 0u; out_T[w] = Tn;
         __syncthreads();
-    }
+    };
+    side_out(std::integral_constant<int, 0>{});
+    side_out(std::integral_constant<int, 1>{});
     if (threadIdx.x == 0) {
         a.dest[0] = key2f(out_key[0]); a.dest[1] = key2f(out_key[1]);
         uint32_t* H = a.hint;
