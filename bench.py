@@ -451,6 +451,26 @@ def rocprof_kernel_median(kernel_name: str, child_args: list, timeout_s: float =
         shutil.rmtree(work, ignore_errors=True)
 
 
+def count_dispatches(child_args: list, timeout_s: float = 240.0):
+    """Kernel dispatches of a `rocprofv3 --kernel-trace` child of this file (every kernel: the library's, torch's, MIOpen's)."""
+    rocprof = shutil.which('rocprofv3') or ('/opt/rocm/bin/rocprofv3' if os.path.exists('/opt/rocm/bin/rocprofv3') else None)
+    if rocprof is None: return None, 'rocprofv3 not available'
+    work = tempfile.mkdtemp(prefix='ppq_kd_', dir='/tmp')
+    try:
+        cmd = [rocprof, '--output-format', 'csv', '--kernel-trace', '-d', work, '-o', 'kd', '--', sys.executable, os.path.abspath(__file__)] + child_args
+        try:
+            r = subprocess.run(cmd, cwd='/tmp', env=dict(os.environ, TMPDIR='/tmp'), capture_output=True, text=True, timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            return None, f'timeout after {timeout_s:.0f} s'
+        files = glob.glob(os.path.join(work, '**', '*kernel_trace.csv'), recursive=True)
+        if not files: return None, f'no kernel_trace.csv (rc={r.returncode}): {(r.stderr or "")[-200:]!r}'
+        with open(files[0]) as f: return sum(1 for _ in csv.DictReader(f)), 'ok'
+    except Exception as e:
+        return None, f'{type(e).__name__}: {e}'
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def seam_variants(dev, batches, steps, bins, method):
     """The plugin seams INSIDE the unmodified reference, timed on this box: the reference's own BaseGraph +
     TensorRT quantizer + TorchExecutor are the host (driven through oracle/reference_import.py, which only imports and calls
@@ -638,6 +658,11 @@ def main_lsq(args, rank, world, dev):
         graph, ex = build()
         LearnedStepSizePass(steps=1, lr=1e-5, block_size=5, process_group=group).optimize(graph, batches[:1], ex)
         del graph, ex
+    if args.kt_child:            # under rocprofv3 --kernel-trace (count_dispatches): ONE pass of `--steps` steps per block, nothing else
+        graph, ex = build()
+        LearnedStepSizePass(steps=args.steps, lr=1e-5, block_size=5).optimize(graph, batches, ex)
+        torch.cuda.synchronize()
+        return
     times, p = [], None
     for rep in range(max(1, args.repeats)):
         graph, ex = build()
@@ -693,6 +718,19 @@ def main_lsq(args, rank, world, dev):
                        'fused_adam_blocks': r5_stats.get('fused_adam_blocks', 0), 'grouped_activations': r5_stats.get('grouped_activations', 0),
                        'steps500_blocks3': {'replay_ms_per_step': long_ms, 'wall_s': round(t5, 2),
                                             'samples_per_s': round(3 * 500 * args.batch / t5, 1), 'graph_replays': long_stats['graph_replays']}}
+        # kernel dispatches of ONE replayed step: two kernel-traced child passes that differ only in the steps per block (8 and 24);
+        # everything else -- calibration, collection, the eager first step and the capture of each block -- cancels in the difference
+        kd_args = ['--workload', 'yolov6s_int4_lsq', '--batch', str(args.batch), '--warmup', '1', '--kt-child', '--variants', '0', '--pmc', '0',
+                   '--no-cpu-baseline', '--no-cpu-ops']
+        n8, note8 = count_dispatches(kd_args + ['--steps', '8'])
+        n24, note24 = count_dispatches(kd_args + ['--steps', '24'])
+        if n8 is not None and n24 is not None:
+            step_report['launches_per_replayed_step'] = round((n24 - n8) / (16.0 * blocks), 2)
+            step_report['launches_per_replayed_step_source'] = (f'rocprofv3 --kernel-trace dispatch counts of two child passes: {n24} at 24 steps per block, '
+                                                                f'{n8} at 8, over {blocks} blocks')
+        else:
+            step_report['launches_per_replayed_step'] = None
+            step_report['launches_per_replayed_step_source'] = f'{note8}; {note24}'
         # the same pass without this round's execution choices: per-tensor launches, eager steps (what round 3 measured)
         graph3, ex3 = build()
         torch.cuda.synchronize(); t1 = time.perf_counter()
@@ -975,6 +1013,7 @@ def main():
             'cfg5_samples_per_s': val(lambda v: v.get('name') == 'yolov6s_int4_lsq'),
             'cfg5_steps_per_block': next((v.get('steps') for v in variants if v.get('name') == 'yolov6s_int4_lsq'), None),
             'cfg5_replay_ms_per_step': next((((v.get('step') or {}).get('replay_ms_per_step')) for v in variants if v.get('name') == 'yolov6s_int4_lsq'), None),
+            'cfg5_launches_per_replayed_step': next((((v.get('step') or {}).get('launches_per_replayed_step')) for v in variants if v.get('name') == 'yolov6s_int4_lsq'), None),
             'cfg5_replay_ms_per_step_round4_form': next((((v.get('step') or {}).get('replay_ms_per_step_round4_form')) for v in variants if v.get('name') == 'yolov6s_int4_lsq'), None),
             'cfg5_steps500_blocks3_samples_per_s': next(((((v.get('step') or {}).get('steps500_blocks3') or {}).get('samples_per_s')) for v in variants if v.get('name') == 'yolov6s_int4_lsq'), None),
             'kl4096_samples_per_s': val(lambda v: v.get('name') == 'resnet50_kl_bins4096'),
@@ -987,6 +1026,17 @@ def main():
                 scalars[f'{key}_spread_pct'] = v.get('spread_pct')
                 if v.get('range_pct') is not None: scalars[f'{key}_range_pct'] = v.get('range_pct')
         scalars.update(north_star_b(args.bins))   # B_* keys: rocprofv3 medians + graph-replay bound + floors + B_status
+        # config 5's dominant launch against the floor OF ITS SIZE rather than against 8 TB/s alone: its launches move ~10 MB, where a
+        # launch is a latency chain -- the floor for that many bytes is read off this box's own floors (the empty kernel + the share of
+        # B's copy floor, 12.85 MB of traffic, that the launch's bytes are)
+        for v in variants:
+            roofv = v.get('roofline') or {}
+            if v.get('name') == 'yolov6s_int4_lsq' and roofv.get('avg_launch_us') and scalars.get('B_floor_copy_us') and scalars.get('B_floor_empty_us'):
+                e, c = scalars['B_floor_empty_us'], scalars['B_floor_copy_us']
+                floor_us = e + (c - e) * roofv['algorithmic_bytes_per_launch'] / (8.0 * 512 * 56 * 56)
+                scalars['cfg5_dominant_launch_us'] = roofv['avg_launch_us']
+                scalars['cfg5_dominant_launch_floor_us'] = round(floor_us, 2)
+                scalars['cfg5_dominant_launch_over_floor'] = round(roofv['avg_launch_us'] / floor_us, 2)
     if rank == 0:
         samples = world * args.steps * args.batch
         out = {
