@@ -720,8 +720,8 @@ def main_lsq(args, rank, world, dev):
                                             'samples_per_s': round(3 * 500 * args.batch / t5, 1), 'graph_replays': long_stats['graph_replays']}}
         # kernel dispatches of ONE replayed step: two kernel-traced child passes that differ only in the steps per block (8 and 24);
         # everything else -- calibration, collection, the eager first step and the capture of each block -- cancels in the difference
-        # (immediate mode: the dispatch count of a replayed step does not depend on which convolution kernels MIOpen picks, and a
-        #  find-mode search over 56 convolutions x 3 directions under the tracer ran into the 240 s limit)
+        # (MIOpen in immediate mode, as the driver's line runs this child: the count includes whatever helper kernels the picked
+        #  convolution solvers launch, and a find-mode search over 56 convolutions x 3 directions under the tracer ran into the 240 s limit)
         kd_args = ['--workload', 'yolov6s_int4_lsq', '--batch', str(args.batch), '--warmup', '1', '--kt-child', '--variants', '0', '--pmc', '0',
                    '--no-cpu-baseline', '--no-cpu-ops', '--miopen-find', '0']
         n8, note8 = count_dispatches(kd_args + ['--steps', '8'])
