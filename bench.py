@@ -90,8 +90,9 @@ def cgroup_cpu_stat() -> dict:
 
 
 HOST_CPUS = host_cpus()
+_RANK_CPUS = max(1, HOST_CPUS // max(1, int(os.environ.get('LOCAL_WORLD_SIZE', '1'))))     # the ranks of one node share the grant
 for _var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):      # before torch / numpy build their pools
-    os.environ.setdefault(_var, str(HOST_CPUS))
+    os.environ.setdefault(_var, str(_RANK_CPUS))
 os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')                             # idle workers sleep instead of spinning the quota away
 
 import torch  # noqa: E402
