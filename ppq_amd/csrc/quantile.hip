@@ -1256,17 +1256,19 @@ __global__ __launch_bounds__(kBlock) void quantile_f123_single_kernel(const QSeq
 //                                leaves its keys in ITS OWN record (count, tie count, six keys inline; more keys in its slot) --
 //                                no reservation atomics, nothing shared, no fences: the kernel boundary publishes the records.
 //                                It also publishes the thresholds it used and zeroes the state of the launch behind it.
-//   quantile_hot_select_kernel   one workgroup per CU.  Workgroup 0 (big lists: workgroups 0 and 1, one side each) reads the records
-//                                -- thread t holds the keys of filter workgroup t in registers --, counts ONE histogram round on
+//   quantile_hot_select_kernel   one workgroup per CU.  The workgroup that ARRIVES first (a ticket; big lists: the first two, one side
+//                                each -- never "workgroup 0": see the kernel) reads the records -- thread t holds the keys of filter
+//                                workgroup t in registers, sweeps a slot of 33-256 keys itself --, counts ONE histogram round on
 //                                fixed bit positions of (key - T - 1), picks the 2^11-key-wide bin of the wanted rank, collects the
 //                                handful of keys of that bin and lets one wavefront finish on them (select A's rules decide
 //                                settled / keep-the-hint); the other workgroups poll ONE word.
-//                                Settled (the common case): workgroup 0 writes dest and the hint, everybody returns.  Not
+//                                Settled (the common case): that workgroup writes dest and the hint, everybody returns.  Not
 //                                settled (no usable hint yet, a list that overflowed or came up short): the SAME launch runs
 //                                the exact radix select over the whole tensor -- 12 + 12 + 8 key bits, three levels whose chunks
 //                                are handed out through a counter, so nothing waits for a workgroup that is not resident --
-//                                and leaves a hint computed from the exact histograms (F2's rule: a threshold that lists ~1.5x
-//                                the wanted keys; F3's rule: ON a heavily tied answer), so the next batch is settled by the filter.
+//                                and leaves a hint computed from the exact histograms (F2's rule: a threshold that lists what
+//                                qh_target asks for; F3's rule: ON a heavily tied answer), so the next batch is settled by the filter.
+// The FIRST call on a hint does not come here: it takes the general sequence, which samples its thresholds (quantile_hint_met_before).
 // What shaped the select (s_memrealtime stamps, tools/quantile_hot_stamps.py): a single workgroup's chain of barrier-separated
 // LDS stages costs 0.3-0.6 us per stage whatever it computes; __shfl-based scans are ds_bpermute round trips (DPP instead); 512
 // LDS atomics on one address serialise (one per wavefront instead); values that are wave uniform but live in vector registers
