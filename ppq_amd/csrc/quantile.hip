@@ -1316,11 +1316,10 @@ __device__ __forceinline__ uint32_t qh_target(uint32_t wanted, uint32_t wgs, uin
 // workspace layout (uint32 words)
 enum { kQHEnabled = 0, kQHTHi = 1, kQHTLo = 2, kQHUses = 3,      // written by the filter's workgroup 0 (uses: hint word 7 as it found it)
        kQHZero0 = 4,                                // first word the filter zeroes
-       kQHLoFlag = 4,                               // workgroup 1 -> workgroup 0 (split select): 0 pending, 1 settled, 2 open
-       kQHLoKey = 5, kQHLoKeep = 6, kQHLoT = 8,     // (8: the lo threshold for the next call)
+       kQHLoFlag = 4,                               // the lo side's decision, published by its owner: 0 pending, 1 settled, 2 open
        kQHRoleTicket = 10,                          // arrival ticket of the select launch: the first arrival selects (the second: the lo side of a split select)
-       kQHLoClaim = 9,                              // workgroup 1 is running and WILL deliver the lo side
-       kQHDecision = 7,                             // workgroup 0 -> everybody: 0 pending, 1 all settled, 0x10 | open mask
+       kQHLoClaim = 9,                              // who owns the lo side of a split select: 0 nobody yet, 1 the second arrival, 2 the first
+       kQHDecision = 7,                             // the hi side's decision, published by its owner: 0 pending, 1 settled, 2 open
        kQHNext = 12,                                // [3] next chunk of each exact level
        kQHDone = 16 };                              // [3] chunks counted per exact level
 constexpr uint32_t kQHOffH0 = 64;                                   // hist of key >> 20 (both sides select from it)
@@ -1897,12 +1896,24 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
     uint32_t keep_sel[2] = {0u, 0u};                                 // the sides' valid words for the hint (0: drop; 1 | level << 8)
     const uint32_t level[2] = {(hdr.x >> 8) & 3u, (hdr.x >> 16) & 3u};
     uint32_t T_next[2] = {T[0], T[1]};
-    // ---- the decision: the selecting workgroup publishes, everybody else polls ----
+    // ---- the decisions: every side has an OWNER that selects it, writes its results and publishes one word; everybody else polls ----
+    // One selecting workgroup owns both sides; of two, the first arrival owns the hi side and the second the lo side -- if it is
+    // there: it claims the side FIRST (a compare-and-swap), and the first arrival, done with its own side, claims the lo side for the
+    // exact passes should nobody have (a workgroup that is not resident must never be waited for).  Nothing is handed from one
+    // owner to the other: each writes its side of `dest` and of the hint itself (the hi side's owner also the words they share), and an
+    // owner whose sides are settled returns at once.  (Until round 6's last day the lo side's result travelled to the first arrival
+    // through a flag: 3.4 us of waiting on B x 32, profiles/r06_quantile_select_stamps.txt.)
     uint32_t open_mask;
-    // the second arrival of a split select says FIRST that it is running: the first waits for the lo side only then (a workgroup
-    // that is not resident must never be waited for), and takes the lo side itself otherwise
-    if (role == 1u && threadIdx.x == 0) __hip_atomic_store(&ws[kQHLoClaim], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bool lo_elsewhere = false;
+    uint32_t own = role == 0u ? (a.split ? 1u : 3u) : 0u;            // sides this workgroup owns (block uniform)
+    if (role == 1u) {
+        if (threadIdx.x == 0) {
+            uint32_t expected = 0u;
+            bcast[0] = __hip_atomic_compare_exchange_strong(&ws[kQHLoClaim], &expected, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+        }
+        __syncthreads();
+        own = bcast[0] ? 2u : 0u;
+        __syncthreads();
+    }
     if (role == 0u) {
 #ifdef PPQHIP_QH_TIMING
         if (threadIdx.x == 0) { a.ws[32] = stamp0; }
@@ -1910,52 +1921,45 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
         QH_STAMP(1);
     }
     // ONE call site for both roles (the function is a few thousand instructions, inlined: a second copy costs registers and scratch)
-    if (role < 2u && enabled) hot_select_records(a, R, T, role == 1u ? 2u : (a.split ? 1u : 3u), L.s, key_sel, done_sel, keep_sel, T_next, level, hdr.w);
+    if (own != 0u && enabled) hot_select_records(a, R, T, own, L.s, key_sel, done_sel, keep_sel, T_next, level, hdr.w);
     if (role == 0u) {
         QH_STAMP(6);
-        if (a.split) {                               // is the lo side being computed?  If the second arrival has not even started, the
-            if (threadIdx.x == 0) bcast[0] = __hip_atomic_load(&ws[kQHLoClaim], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // lo side stays OPEN:
-            __syncthreads();                         // the exact passes settle it (never seen outside a chip shared with other queues)
-            lo_elsewhere = bcast[0] != 0u;
-            __syncthreads();
-        }
-    }
-    if (role == 1u) {
-        if (threadIdx.x == 0) {
-            __hip_atomic_store(&ws[kQHLoKey], key_sel[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ws[kQHLoKeep], keep_sel[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&ws[kQHLoT], T_next[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __hip_atomic_store(&ws[kQHLoFlag], done_sel[1] ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    if (role == 0u) {
-        if (lo_elsewhere) {
-            if (threadIdx.x == 0) {
-                uint32_t f;
-                while ((f = __hip_atomic_load(&ws[kQHLoFlag], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                bcast[0] = f;
-                bcast[1] = __hip_atomic_load(&ws[kQHLoKey], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bcast[2] = __hip_atomic_load(&ws[kQHLoKeep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                bcast[3] = __hip_atomic_load(&ws[kQHLoT], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.split) {                               // is the lo side taken?  If the second arrival has not even started, it stays OPEN and is
+            if (threadIdx.x == 0) {                  // this workgroup's: the exact passes settle it (never seen outside a chip shared with other queues)
+                uint32_t expected = 0u;
+                bcast[0] = __hip_atomic_compare_exchange_strong(&ws[kQHLoClaim], &expected, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
             }
             __syncthreads();
-            done_sel[1] = bcast[0] == 1u; key_sel[1] = bcast[1]; keep_sel[1] = bcast[2]; T_next[1] = bcast[3];
+            if (bcast[0]) own |= 2u;
             __syncthreads();
         }
-        open_mask = (done_sel[0] ? 0u : 1u) | (done_sel[1] ? 0u : 2u);
-        if (threadIdx.x == 0)
-            __hip_atomic_store(&ws[kQHDecision], open_mask ? (0x10u | open_mask) : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        if (threadIdx.x == 0) {
-            uint32_t d;
-            if (role != 1u) __builtin_amdgcn_s_sleep(PPQHIP_QH_POLL_FIRST);          // the decision is microseconds away
-            while ((d = __hip_atomic_load(&ws[kQHDecision], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(PPQHIP_QH_POLL_SLEEP);
-            bcast[3] = d;
+    }
+    if (own != 0u && threadIdx.x == 0) {
+        // the decisions FIRST (a few hundred workgroups are waiting for them; the stores behind them queue in order), then the settled
+        // sides' results and hint words -- nobody reads those before the launch ends; open sides: after the exact passes (below)
+        if (own & 1u) __hip_atomic_store(&ws[kQHDecision], done_sel[0] ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (own & 2u) __hip_atomic_store(&ws[kQHLoFlag], done_sel[1] ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t* H = a.hint;
+        if ((own & 1u) && done_sel[0]) { a.dest[0] = key2f(key_sel[0]); H[kHValidHi] = keep_sel[0]; H[kHTHi] = keep_sel[0] ? T_next[0] : T[0]; }
+        if ((own & 2u) && done_sel[1]) { a.dest[1] = key2f(key_sel[1]); H[kHValidLo] = keep_sel[1]; H[kHTLo] = keep_sel[1] ? T_next[1] : T[1]; }
+        if (role == 0u) {
+            H[kHN] = n; H[kHKHi] = a.k_hi; H[kHKLo] = a.k_lo;
+            if (enabled && done_sel[0]) H[kHUses] = hdr.w + 1u;
+        }
+    }
+    {
+        const uint32_t mine_open = ((own & 1u) && !done_sel[0] ? 1u : 0u) | ((own & 2u) && !done_sel[1] ? 2u : 0u);
+        if (own != 0u && mine_open == 0u) { QH_STAMP(7); return; }   // an owner with nothing open is done: the exact passes (if the other side needs
+                                                                     // them) hand their chunks out through a counter, whoever is there takes them
+        if (threadIdx.x == 0) {                      // everybody else needs BOTH decisions: one open mask for all who count
+            uint32_t dh, dl;
+            if (own == 0u) __builtin_amdgcn_s_sleep(PPQHIP_QH_POLL_FIRST);           // the decisions are microseconds away
+            while ((dh = __hip_atomic_load(&ws[kQHDecision], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(PPQHIP_QH_POLL_SLEEP);
+            while ((dl = __hip_atomic_load(&ws[kQHLoFlag], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(PPQHIP_QH_POLL_SLEEP);
+            bcast[3] = (dh == 2u ? 1u : 0u) | (dl == 2u ? 2u : 0u);
         }
         __syncthreads();
-        open_mask = bcast[3] == 1u ? 0u : (bcast[3] & 3u);
+        open_mask = bcast[3];
         if (open_mask == 0u) return;
     }
     // ---- not settled: exact radix select over the whole tensor (12 + 12 + 8 key bits) ----
@@ -2088,14 +2092,14 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
             }
         }
     }
-    if (role != 0u) return;
-    // ---- role 0 writes the results and the hint (the only writer of either in this launch) ----
+    if ((own & open_mask) == 0u) return;
+    // ---- the owner of a side that went through the exact passes writes its result and its half of the hint ----
     uint32_t out_key[2], out_valid[2], out_T[2];
     // (one body, instantiated per side: as a loop the compiler stopped unrolling it once the select grew, and every array indexed by
     //  the side -- thresholds, keys, valid words -- moved to scratch)
     auto side_out = [&](auto W) __attribute__((always_inline)) {
         constexpr int w = decltype(W)::value;
-        if (!(open_mask & (1u << w))) { out_key[w] = key_sel[w]; out_valid[w] = keep_sel[w]; out_T[w] = keep_sel[w] ? T_next[w] : T[w]; return; }
+        if (!(own & open_mask & (1u << w))) { out_key[w] = 0u; out_valid[w] = 0u; out_T[w] = 0u; return; }      // (block uniform; written above, or another owner's)
         // the side went through the exact passes: leave a threshold that works (rules of F2's and F3's tails)
         const uint32_t V = (p24[w] << 8) | low[w];
         out_key[w] = V;
@@ -2137,12 +2141,9 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
     side_out(std::integral_constant<int, 0>{});
     side_out(std::integral_constant<int, 1>{});
     if (threadIdx.x == 0) {
-        a.dest[0] = key2f(out_key[0]); a.dest[1] = key2f(out_key[1]);
         uint32_t* H = a.hint;
-        const uint32_t uses = hdr.w;
-        H[kHValidHi] = out_valid[0]; H[kHTHi] = out_T[0]; H[kHValidLo] = out_valid[1]; H[kHTLo] = out_T[1];
-        H[kHN] = n; H[kHKHi] = a.k_hi; H[kHKLo] = a.k_lo;
-        if (enabled && !(open_mask & 1u)) H[kHUses] = uses + 1u;
+        if (own & open_mask & 1u) { a.dest[0] = key2f(out_key[0]); H[kHValidHi] = out_valid[0]; H[kHTHi] = out_T[0]; }
+        if (own & open_mask & 2u) { a.dest[1] = key2f(out_key[1]); H[kHValidLo] = out_valid[1]; H[kHTLo] = out_T[1]; }
     }
     QH_STAMP(7);
 }
