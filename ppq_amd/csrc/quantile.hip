@@ -1293,7 +1293,6 @@ constexpr uint32_t kQHStage = 2048;                 // keys a workgroup can stag
 constexpr uint32_t kQHInline = 6;                   // keys per side inside the record
 constexpr uint32_t kQHMaxWg = 512;                  // filter grid limit (records, slots)
 constexpr uint32_t kQHListMax = 65536;              // longest list a hint may keep producing
-constexpr uint32_t kQHSpeculators = 16;              // workgroups of the select launch that request the records before they know their role
 constexpr uint32_t kQHWantedMax = 8192;             // the host routes here only when both wanted counts are at most this
 constexpr uint32_t kQHThreadKeys = 32;              // keys of one filter workgroup and side a thread of the select holds in registers
 constexpr uint32_t kQHThreadMore = 256;             // .. and up to this many it sweeps straight from the workgroup's slot (longer slots: through LDS)
@@ -1873,22 +1872,22 @@ __global__ __launch_bounds__(kQHBlock) void quantile_hot_select_kernel(const QHo
     // Rounds of measurements with "workgroup 0 selects, the others wait" ended in launches of 7 .. 55 s: with three queues busy
     // (two of these launches on two streams beside a copy on a third) workgroup 0 of a grid is NOT always resident when its
     // siblings are, and two launches whose pollers hold each other's CUs only move again when the queue scheduler time-slices
-    // them (tools/quantile_soak.py single, profiles/r06_quantile_soak.txt).  Nothing here depends on dispatch order now.  The
-    // ticket's round trip is hidden: the lowest kQHSpeculators workgroups -- in practice the first to arrive -- request the
-    // records together with it.
+    // them (tools/quantile_soak.py single, profiles/r06_quantile_soak.txt).  Nothing here depends on dispatch order now.
 #ifdef PPQHIP_QH_TIMING
     const uint32_t stamp0 = (uint32_t)wall_clock64();
 #endif
     const uint4 hdr = *reinterpret_cast<const uint4*>(ws);
     if (threadIdx.x == 0) bcast[0] = __hip_atomic_fetch_add(&ws[kQHRoleTicket], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     QHRecs R;
-    const bool speculated = blockIdx.x < kQHSpeculators;
-    if (speculated) hot_load_records(a, R, (a.split && blockIdx.x < 2u) ? blockIdx.x : 2u);
     __syncthreads();
     const uint32_t arrival = bcast[0];
     __syncthreads();
     const uint32_t role = arrival == 0u ? 0u : ((a.split && arrival == 1u) ? 1u : 0xFFFFFFFFu);
-    if (role < 2u && !speculated) hot_load_records(a, R, 2u);
+    // the records are requested once the role is known, the owner's own side's heads with them.  (Until the round's last day the 16
+    // lowest workgroups requested them together with the ticket, "in practice the first to arrive": the stamps say the first arrivals
+    // are workgroups 5, 47, 101, 135, 149, 237 .. -- hardly ever one of those; 0 / 8 / 16 / 32 / 64 speculators measured alike.)
+    if (role < 2u) hot_load_records(a, R, role);
+    else { R.r4[0] = R.r4[1] = R.r4[2] = R.r4[3] = make_uint4(0u, 0u, 0u, 0u); R.head_side = 2u; }
     const bool enabled = hdr.x != 0u;
     const uint32_t T[2] = {hdr.y, hdr.z};
     uint32_t key_sel[2] = {T[0], T[1]};
