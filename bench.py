@@ -100,6 +100,7 @@ import torch  # noqa: E402
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+JSON_OUT = sys.stdout        # the real stdout, kept for the one JSON line (see __main__)
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -182,7 +183,7 @@ def host_selftest(args) -> None:
                           'unit': 'ms', 'n_gpus': world, 'rccl_ranks': world, 'backend': 'gloo', 'selftest': True,
                           'merged_counts_ok': ok,
                           'merge': [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in m.items()} for m in (phase1, phase2)]}),
-              flush=True)
+              file=JSON_OUT, flush=True)
     if world > 1: dist.destroy_process_group()
 
 
@@ -766,7 +767,7 @@ def main_lsq(args, rank, world, dev):
                        'per_tensor_eager_samples_per_s': round(samples / per_tensor_eager_s, 2) if (rank == 0 and world == 1) else None},
             'roofline': roof, 'cpu_baseline': None,
             'kernels': [{'name': r['name'], 'launches': r['launches'], 'total_ms': round(r['total_ms'], 3),
-                         'GBps': round(r['total_bytes'] / max(r['total_ms'], 1e-9) / 1e6, 1)} for r in prof_rows]}), flush=True)
+                         'GBps': round(r['total_bytes'] / max(r['total_ms'], 1e-9) / 1e6, 1)} for r in prof_rows]}), file=JSON_OUT, flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
@@ -1087,11 +1088,13 @@ def main():
             'scale_checksum': scale_checksum,
         }
         if trace is not None: out['trace_steps'] = trace
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=JSON_OUT, flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
 
 
 if __name__ == '__main__':
+    # stdout carries ONE line, the JSON; whatever a library prints on the way (the staged reference greets with a banner) goes to stderr
+    sys.stdout = sys.stderr
     main()
